@@ -1,0 +1,152 @@
+/*
+ * nam_hip.h — C ABI of the MI355X-native NAM inference core (libnam_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of sdatkinson/NeuralAmpModelerCore: running many independent
+ * audio streams through one .nam model (`nam::get_dsp(path)` + `nam::DSP::process(in, out, n)`).
+ * The reference exposes that path as a C++ class API, not a C ABI; the entry points below are what
+ * a binding for that path needs, each citing the reference interface it replaces
+ * (file:line relative to the reference tree). The C++ adapter in cpp/NAM/ re-creates the
+ * reference's `nam::DSP` / `nam::get_dsp` signatures on top of this ABI.
+ *
+ * Conventions
+ *   - every function returns NAM_HIP_OK (0) or a negative error code; the message of the last
+ *     error on the calling thread is available from nam_hip_last_error(). No C++ exception ever
+ *     crosses this boundary (the reference throws at load time: NAM/nam_file.h:11,
+ *     NAM/get_dsp.cpp:116-121, NAM/wavenet/model.cpp:671-682, and asserts at run time
+ *     NAM/wavenet/model.cpp:824).
+ *   - audio is planar: buffer[stream][channel][frame]; the *_f32 / *_f64 entry points take HOST
+ *     pointers (they copy to and from the GPU), the *_device entry point takes DEVICE pointers and
+ *     an optional hipStream_t and does not synchronise.
+ *   - a `nam_hip_model` is immutable host data (parsed file + device plans); a `nam_hip_batch`
+ *     owns the GPU memory (weights, per-stream history) for N streams of one model on one device
+ *     and must be used from one host thread at a time, like a reference `nam::DSP` instance.
+ */
+#ifndef NAM_HIP_H
+#define NAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+  #define NAM_HIP_API __attribute__((visibility("default")))
+#else
+  #define NAM_HIP_API
+#endif
+
+#define NAM_HIP_OK 0
+#define NAM_HIP_ERR_INVALID_ARGUMENT (-1)
+#define NAM_HIP_ERR_FILE (-2) /* nam::NamFileValidationError — NAM/nam_file.cpp:9-40 */
+#define NAM_HIP_ERR_MODEL (-3) /* std::runtime_error at load: bad version / config / weight count */
+#define NAM_HIP_ERR_UNSUPPORTED (-4) /* valid .nam the device path cannot run (e.g. ConvNet / Linear) */
+#define NAM_HIP_ERR_DEVICE (-5) /* HIP runtime error */
+#define NAM_HIP_ERR_TOO_MANY_FRAMES (-6) /* num_frames > max_frames (assert in NAM/wavenet/model.cpp:824) */
+
+#define NAM_HIP_ARCH_WAVENET 1
+#define NAM_HIP_ARCH_LSTM 2
+
+/* kernel selection for nam_hip_batch_set_kernel */
+#define NAM_HIP_KERNEL_AUTO 0
+#define NAM_HIP_KERNEL_GENERIC 1 /* op-program interpreter (every WaveNet feature) */
+#define NAM_HIP_KERNEL_A1 2 /* register-resident kernel for the plain A1 family */
+
+typedef struct nam_hip_model nam_hip_model;
+typedef struct nam_hip_batch nam_hip_batch;
+
+/* What nam::DSP's getters report — NAM/dsp.h:100-149,153, NAM/slimmable.h:23-29. */
+typedef struct nam_hip_model_info
+{
+  int32_t architecture; /* NAM_HIP_ARCH_* */
+  int32_t in_channels; /* DSP::NumInputChannels  dsp.h:104 */
+  int32_t out_channels; /* DSP::NumOutputChannels dsp.h:108 */
+  int32_t prewarm_samples; /* DSP::GetPrewarmSamples dsp.h:153 (WaveNet: model.cpp:653-658; LSTM: lstm.cpp:127-134) */
+  double expected_sample_rate; /* DSP::GetExpectedSampleRate dsp.h:100; -1.0 when the file has none */
+  int32_t has_loudness; /* DSP::HasLoudness dsp.h:137 */
+  int32_t has_input_level; /* DSP::HasInputLevel */
+  int32_t has_output_level; /* DSP::HasOutputLevel */
+  int32_t is_slimmable; /* dynamic_cast<SlimmableModel*> succeeds — slimmable.h:13 */
+  double loudness; /* DSP::GetLoudness dsp.h:125 */
+  double input_level; /* DSP::GetInputLevel dsp.h:116 */
+  double output_level; /* DSP::GetOutputLevel dsp.h:133 */
+  int64_t num_weights;
+  int32_t fast_tanh; /* load-time switch replacing the global Activation::enable_fast_tanh (activations.cpp:168) */
+  int32_t has_a1_kernel; /* the specialised kernel can run this model */
+  int64_t state_bytes_per_stream; /* HBM history per stream */
+  char version[32]; /* .nam "version" */
+} nam_hip_model_info;
+
+/* Message of the last failure on this thread ("" if none). */
+NAM_HIP_API const char* nam_hip_last_error(void);
+
+/* ---- loading: nam::get_dsp(path / json) — NAM/get_dsp.h:85-116, NAM/get_dsp.cpp:156-273 ----
+ * fast_tanh != 0 mirrors calling nam::activations::Activation::enable_fast_tanh() before get_dsp
+ * (tools/benchmodel.cpp:69-73): "Tanh" layers use the rational approximation (activations.h:91-98)
+ * and LSTM cells use fast_sigmoid / fast_tanh (lstm.cpp:48-58). */
+NAM_HIP_API int nam_hip_model_load(const char* nam_path, int fast_tanh, nam_hip_model** out_model);
+NAM_HIP_API int nam_hip_model_load_json(const char* json_text, int fast_tanh, nam_hip_model** out_model);
+NAM_HIP_API void nam_hip_model_free(nam_hip_model* model);
+NAM_HIP_API int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info);
+
+/* SlimmableModel::GetSlimmableSizeBreakpoints — NAM/slimmable.h:29, NAM/wavenet/slimmable.cpp:108-121.
+ * Writes up to `capacity` values, returns the number available (>= 0) or an error code. */
+NAM_HIP_API int nam_hip_model_slimmable_breakpoints(const nam_hip_model* model, double* out, int capacity);
+
+/* ---- batches: N independent streams of one model on one GPU ----
+ * Replaces N instances of nam::DSP. `max_frames` plays the role of maxBufferSize in
+ * DSP::Reset(sampleRate, maxBufferSize) (NAM/dsp.cpp:130-140): the largest n_frames a process call
+ * may pass, and the chunk size used for prewarming (NAM/dsp.cpp:86-100). History starts zeroed
+ * (Conv1D::SetMaxBufferSize, NAM/conv1d.cpp:128-149); LSTM state starts from the file's h0/c0
+ * (NAM/lstm.cpp:24-28). `device` is the HIP device ordinal. */
+NAM_HIP_API int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, int max_frames,
+                         nam_hip_batch** out_batch);
+NAM_HIP_API void nam_hip_batch_destroy(nam_hip_batch* batch);
+
+/* DSP::Reset (NAM/dsp.cpp:130-140): WaveNet history is zeroed; if `prewarm` != 0 the model then
+ * processes ceil(prewarm_samples / max_frames) * max_frames frames of silence (DSP::prewarm,
+ * NAM/dsp.cpp:67-101). LSTM recurrent state is NOT re-initialised by Reset in the reference
+ * (NAM/lstm.cpp has no SetMaxBufferSize override); this call mirrors that: LSTM batches only prewarm. */
+NAM_HIP_API int nam_hip_batch_reset(nam_hip_batch* batch, int prewarm);
+
+/* SlimmableModel::SetSlimmableSize(val) for a subset of the streams (NAM/slimmable.h:23,
+ * NAM/wavenet/slimmable.cpp:420-431,527-530): the listed streams switch to the sub-model of width
+ * ratio_to_channels(ratio) and start from a freshly reset (and, if the batch was last reset with
+ * prewarm, prewarmed) state, as the reference's rebuilt model does. stream_ids == NULL selects all. */
+NAM_HIP_API int nam_hip_batch_set_slimmable_size(nam_hip_batch* batch, const int* stream_ids, int n_ids, double ratio);
+
+/* DSP::process(NAM_SAMPLE** input, NAM_SAMPLE** output, int num_frames) — NAM/dsp.h:97,
+ * NAM/wavenet/model.cpp:822-910, NAM/lstm.cpp:103-125 — for all streams of the batch at once.
+ * in  : [n_streams][in_channels ][n_frames]   out : [n_streams][out_channels][n_frames]  (host memory)
+ * n_frames must be <= max_frames. Blocks until the output is in `out`. The _f64 form is for callers
+ * built with NAM_SAMPLE = double (NAM/dsp.h:18-22); the model itself computes in float32
+ * (cast-in NAM/wavenet/model.cpp:817, cast-out :896). */
+NAM_HIP_API int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out, int n_frames);
+NAM_HIP_API int nam_hip_batch_process_f64(nam_hip_batch* batch, const double* in, double* out, int n_frames);
+
+/* Same computation on buffers already resident in HBM (offline re-amping / batch render):
+ * d_in / d_out are DEVICE pointers laid out [n_streams][channels][frame_stride]; frames
+ * [0, n_frames) of every row are consumed / produced. n_frames may be any length (the kernel walks
+ * it in 64-frame blocks, exactly as tools/render.cpp:146-197 walks a file in 64-frame buffers).
+ * Enqueues on `hip_stream` (a hipStream_t, NULL = the batch's own stream) and returns without
+ * synchronising. */
+NAM_HIP_API int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float* d_out, int n_frames,
+                                 int64_t frame_stride, void* hip_stream);
+
+/* Wait for everything enqueued on the batch's own stream. */
+NAM_HIP_API int nam_hip_batch_synchronize(nam_hip_batch* batch);
+
+/* Choose the kernel (NAM_HIP_KERNEL_*); AUTO picks the A1 kernel when the model allows it. */
+NAM_HIP_API int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel);
+NAM_HIP_API int nam_hip_batch_get_kernel(const nam_hip_batch* batch);
+NAM_HIP_API int nam_hip_batch_n_streams(const nam_hip_batch* batch);
+
+/* Library identification: "nam_hip <version> gfx950". */
+NAM_HIP_API const char* nam_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NAM_HIP_H */

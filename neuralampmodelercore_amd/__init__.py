@@ -1,0 +1,297 @@
+"""
+neuralampmodelercore_amd — MI355X-native NAM inference core (Python host-side binding).
+
+The product is ``lib/libnam_hip.so`` (hand-written HIP kernels for gfx950 + the C ABI declared in
+``include/nam_hip.h``).  This module is only a thin ctypes mirror of the reference's operator
+surface for the hot path — ``nam::get_dsp(path)`` (NAM/get_dsp.h:85) and
+``nam::DSP::process / Reset / prewarm`` (NAM/dsp.h:89-163) — batched over many independent audio
+streams.  There is no CPU fallback: if the shared library cannot be loaded, importing the batch API
+raises.  PyTorch is used by callers only for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+__all__ = [
+    "NamHipError", "NamFileValidationError", "Model", "Batch", "get_dsp", "get_dsp_json", "lib_path", "load_library",
+    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_A1", "ABI_SYMBOLS",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_A1 = 0, 1, 2
+
+ERR_INVALID_ARGUMENT, ERR_FILE, ERR_MODEL, ERR_UNSUPPORTED, ERR_DEVICE, ERR_TOO_MANY_FRAMES = -1, -2, -3, -4, -5, -6
+
+# every symbol include/nam_hip.h declares (tests check the built library exports exactly these)
+ABI_SYMBOLS = [
+    "nam_hip_last_error", "nam_hip_version", "nam_hip_model_load", "nam_hip_model_load_json", "nam_hip_model_free",
+    "nam_hip_model_get_info", "nam_hip_model_slimmable_breakpoints", "nam_hip_batch_create", "nam_hip_batch_destroy",
+    "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
+    "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_synchronize",
+    "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams",
+]
+
+
+class NamHipError(RuntimeError):
+    """std::runtime_error of the reference's load path / any device failure."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[nam_hip {code}] {message}")
+        self.code = code
+
+
+class NamFileValidationError(NamHipError):
+    """nam::NamFileValidationError (NAM/nam_file.h:11)."""
+
+
+class _Info(ctypes.Structure):
+    _fields_ = [
+        ("architecture", ctypes.c_int32), ("in_channels", ctypes.c_int32), ("out_channels", ctypes.c_int32),
+        ("prewarm_samples", ctypes.c_int32), ("expected_sample_rate", ctypes.c_double),
+        ("has_loudness", ctypes.c_int32), ("has_input_level", ctypes.c_int32), ("has_output_level", ctypes.c_int32),
+        ("is_slimmable", ctypes.c_int32), ("loudness", ctypes.c_double), ("input_level", ctypes.c_double),
+        ("output_level", ctypes.c_double), ("num_weights", ctypes.c_int64), ("fast_tanh", ctypes.c_int32),
+        ("has_a1_kernel", ctypes.c_int32), ("state_bytes_per_stream", ctypes.c_int64), ("version", ctypes.c_char * 32),
+    ]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libnam_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libnam_hip.so. Raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"neuralampmodelercore_amd: {path} is missing — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C neuralampmodelercore_amd/csrc`. "
+            "There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    L.nam_hip_last_error.restype = ctypes.c_char_p
+    L.nam_hip_version.restype = ctypes.c_char_p
+    L.nam_hip_model_load.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    L.nam_hip_model_load_json.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    L.nam_hip_model_free.argtypes = [vp]
+    L.nam_hip_model_free.restype = None
+    L.nam_hip_model_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
+    L.nam_hip_model_slimmable_breakpoints.argtypes = [vp, ctypes.POINTER(cd), ci]
+    L.nam_hip_batch_create.argtypes = [vp, ci, ci, ci, ctypes.POINTER(vp)]
+    L.nam_hip_batch_destroy.argtypes = [vp]
+    L.nam_hip_batch_destroy.restype = None
+    L.nam_hip_batch_reset.argtypes = [vp, ci]
+    L.nam_hip_batch_set_slimmable_size.argtypes = [vp, ctypes.POINTER(ci), ci, cd]
+    L.nam_hip_batch_process_f32.argtypes = [vp, vp, vp, ci]
+    L.nam_hip_batch_process_f64.argtypes = [vp, vp, vp, ci]
+    L.nam_hip_batch_process_device.argtypes = [vp, vp, vp, ci, ctypes.c_int64, vp]
+    L.nam_hip_batch_synchronize.argtypes = [vp]
+    L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
+    L.nam_hip_batch_get_kernel.argtypes = [vp]
+    L.nam_hip_batch_n_streams.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc >= 0:
+        return rc
+    msg = load_library().nam_hip_last_error().decode("utf-8", "replace")
+    if rc == ERR_FILE:
+        raise NamFileValidationError(rc, msg)
+    raise NamHipError(rc, msg)
+
+
+class Model:
+    """A loaded .nam model (host side): what ``nam::get_dsp`` returns, minus the per-stream state."""
+
+    def __init__(self, handle: int):
+        self._L = load_library()
+        self._h = ctypes.c_void_p(handle)
+        info = _Info()
+        _check(self._L.nam_hip_model_get_info(self._h, ctypes.byref(info)))
+        self.info = info
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.nam_hip_model_free(self._h)
+            self._h = None
+
+    # --- nam::DSP getters (NAM/dsp.h:100-149) ---
+    def NumInputChannels(self) -> int:
+        return self.info.in_channels
+
+    def NumOutputChannels(self) -> int:
+        return self.info.out_channels
+
+    def GetExpectedSampleRate(self) -> float:
+        return self.info.expected_sample_rate
+
+    def GetPrewarmSamples(self) -> int:
+        return self.info.prewarm_samples
+
+    def HasLoudness(self) -> bool:
+        return bool(self.info.has_loudness)
+
+    def GetLoudness(self) -> float:
+        if not self.info.has_loudness:
+            raise RuntimeError("Asked for loudness of a model that doesn't know how loud it is!")
+        return self.info.loudness
+
+    def HasInputLevel(self) -> bool:
+        return bool(self.info.has_input_level)
+
+    def GetInputLevel(self) -> float:
+        return self.info.input_level
+
+    def HasOutputLevel(self) -> bool:
+        return bool(self.info.has_output_level)
+
+    def GetOutputLevel(self) -> float:
+        return self.info.output_level
+
+    @property
+    def architecture(self) -> str:
+        return {1: "WaveNet", 2: "LSTM"}.get(self.info.architecture, "?")
+
+    @property
+    def is_slimmable(self) -> bool:
+        return bool(self.info.is_slimmable)
+
+    @property
+    def num_weights(self) -> int:
+        return int(self.info.num_weights)
+
+    @property
+    def version(self) -> str:
+        return self.info.version.decode()
+
+    def GetSlimmableSizeBreakpoints(self) -> List[float]:
+        buf = (ctypes.c_double * 64)()
+        n = _check(self._L.nam_hip_model_slimmable_breakpoints(self._h, buf, 64))
+        return [buf[i] for i in range(min(n, 64))]
+
+    def batch(self, n_streams: int, max_frames: int = 64, device: int = 0) -> "Batch":
+        return Batch(self, n_streams, max_frames, device)
+
+
+class Batch:
+    """N independent streams of one model on one GPU (replaces N ``nam::DSP`` instances)."""
+
+    def __init__(self, model: Model, n_streams: int, max_frames: int, device: int = 0):
+        self._L = load_library()
+        self.model = model
+        self.n_streams = int(n_streams)
+        self.max_frames = int(max_frames)
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _check(self._L.nam_hip_batch_create(model._h, device, n_streams, max_frames, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nam_hip_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # DSP::Reset(sampleRate, maxBufferSize) — the buffer size was fixed at creation
+    def Reset(self, prewarm: bool = True):
+        _check(self._L.nam_hip_batch_reset(self._h, 1 if prewarm else 0))
+
+    reset = Reset
+
+    def SetSlimmableSize(self, ratio: float, stream_ids: Optional[Sequence[int]] = None):
+        if stream_ids is None:
+            _check(self._L.nam_hip_batch_set_slimmable_size(self._h, None, 0, float(ratio)))
+        else:
+            arr = (ctypes.c_int * len(stream_ids))(*[int(s) for s in stream_ids])
+            _check(self._L.nam_hip_batch_set_slimmable_size(self._h, arr, len(stream_ids), float(ratio)))
+
+    def set_kernel(self, kernel: int):
+        _check(self._L.nam_hip_batch_set_kernel(self._h, int(kernel)))
+
+    def get_kernel(self) -> int:
+        return _check(self._L.nam_hip_batch_get_kernel(self._h))
+
+    def synchronize(self):
+        _check(self._L.nam_hip_batch_synchronize(self._h))
+
+    def process(self, x: np.ndarray) -> np.ndarray:
+        """x: host array [n_streams, in_channels, n_frames] (or [n_streams, n_frames] for mono),
+        float32 or float64 (NAM_SAMPLE). Returns [n_streams, out_channels, n_frames], same dtype."""
+        ic, oc = self.model.NumInputChannels(), self.model.NumOutputChannels()
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[:, None, :]
+        if x.shape[0] != self.n_streams or x.shape[1] != ic:
+            raise ValueError(f"expected input [{self.n_streams}, {ic}, n], got {tuple(x.shape)}")
+        n = x.shape[2]
+        if x.dtype == np.float64:
+            x = np.ascontiguousarray(x)
+            out = np.empty((self.n_streams, oc, n), dtype=np.float64)
+            fn = self._L.nam_hip_batch_process_f64
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            out = np.empty((self.n_streams, oc, n), dtype=np.float32)
+            fn = self._L.nam_hip_batch_process_f32
+        _check(fn(self._h, x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n))
+        return out
+
+    def process_stream(self, x: np.ndarray, block: Optional[int] = None) -> np.ndarray:
+        """Feed a long host signal in `block`-frame process() calls (what benchmodel / render do)."""
+        block = block or self.max_frames
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[:, None, :]
+        outs = [self.process(x[:, :, s:s + block]) for s in range(0, x.shape[2], block)]
+        return np.concatenate(outs, axis=2)
+
+    def process_device(self, d_in: int, d_out: int, n_frames: int, frame_stride: Optional[int] = None,
+                       stream: int = 0):
+        """Raw device-pointer form (ints, e.g. torch.Tensor.data_ptr()). Enqueues only."""
+        fs = n_frames if frame_stride is None else frame_stride
+        _check(self._L.nam_hip_batch_process_device(self._h, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), n_frames,
+                                                    fs, ctypes.c_void_p(stream) if stream else None))
+
+    def process_tensor(self, x, out=None, n_frames: Optional[int] = None, stream=None):
+        """torch.Tensor form: x [n_streams, in_ch, T] float32 on this batch's GPU; returns `out`
+        [n_streams, out_ch, T]. Enqueued on `stream` (default: torch's current stream)."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+        T = x.shape[2]
+        n = T if n_frames is None else n_frames
+        if out is None:
+            out = torch.empty((self.n_streams, self.model.NumOutputChannels(), T), dtype=torch.float32, device=x.device)
+        assert out.is_contiguous() and out.shape[2] == T
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        self.process_device(x.data_ptr(), out.data_ptr(), n, T, s.cuda_stream)
+        return out
+
+
+def get_dsp(path: str, fast_tanh: bool = False) -> Model:
+    """nam::get_dsp(path). ``fast_tanh`` mirrors Activation::enable_fast_tanh() before loading."""
+    L = load_library()
+    h = ctypes.c_void_p()
+    _check(L.nam_hip_model_load(os.fsencode(path), 1 if fast_tanh else 0, ctypes.byref(h)))
+    return Model(h.value)
+
+
+def get_dsp_json(text: str, fast_tanh: bool = False) -> Model:
+    """nam::get_dsp(json)."""
+    L = load_library()
+    h = ctypes.c_void_p()
+    _check(L.nam_hip_model_load_json(text.encode("utf-8"), 1 if fast_tanh else 0, ctypes.byref(h)))
+    return Model(h.value)

@@ -1,0 +1,67 @@
+// kernels.h — kernel argument blocks and host-side launch wrappers (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace namhip
+{
+
+// I/O convention for every kernel: planar float32 in HBM,
+//   in [stream][in_ch ][io_stride]   out [stream][out_ch][io_stride]
+// of which frames [0, n_frames) are processed by this launch (the caller may point `in`/`out` into
+// the middle of a longer resident buffer; io_stride is the row pitch in floats).
+// `in == nullptr` means silence (prewarm); `out == nullptr` discards the output.
+struct GenericArgs
+{
+  const NamOp* ops;
+  const float* blob;
+  float* state;
+  long state_stride; // floats per stream
+  const int* stream_map; // optional: blockIdx -> stream index (mixed-width batches); nullptr = identity
+  const float* in;
+  float* out;
+  long io_stride;
+  int n_frames;
+  int in_ch, out_ch;
+};
+
+struct A1Args
+{
+  const A1Plan* plan; // device copy
+  const float* blob;
+  float* state;
+  long state_stride;
+  const int* stream_map;
+  const float* in;
+  float* out;
+  long io_stride;
+  int n_frames;
+  float act_p0; // LeakyReLU slope when the arrays use it
+};
+
+struct LSTMArgs
+{
+  const float* blob;
+  float* state;
+  long state_stride;
+  const float* in;
+  float* out;
+  long io_stride;
+  int n_frames;
+  int n_streams;
+  int n_layers, input_size, hidden, in_ch, out_ch, fast;
+  int head_w, head_b;
+  int layer_w[16];
+  int layer_b[16];
+};
+
+hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
+hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
+hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);
+int lstm_lds_bytes(const LSTMArgs& a);
+hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,
+                             int n_init, int state_floats, hipStream_t stream);
+
+} // namespace namhip

@@ -1,0 +1,668 @@
+// nam_hip_api.cpp — implementation of the C ABI declared in include/nam_hip.h.
+//
+// Host-side runtime around the HIP kernels: model handles (parsed .nam + device plans), batch
+// handles (device weights, per-stream history in HBM, staging), stream sharding by slimmable width,
+// reset / prewarm semantics of nam::DSP (NAM/dsp.cpp:67-140). No exception leaves this file.
+#include "../../include/nam_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "model_spec.h"
+#include "plan.h"
+
+using namespace namhip;
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+#define NAM_HIP_CHECK(expr)                                                                                           \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess)                                                                                              \
+      return fail(NAM_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                             \
+  } while (0)
+
+template <typename F>
+int guarded(F&& f)
+{
+  try
+  {
+    return f();
+  }
+  catch (const FileValidationError& e)
+  {
+    return fail(NAM_HIP_ERR_FILE, e.what());
+  }
+  catch (const std::exception& e)
+  {
+    return fail(NAM_HIP_ERR_MODEL, e.what());
+  }
+  catch (...)
+  {
+    return fail(NAM_HIP_ERR_MODEL, "unknown error");
+  }
+}
+} // namespace
+
+struct nam_hip_model
+{
+  std::shared_ptr<ModelSpec> spec;
+  // One plan per distinct width (slimmable WaveNets have several; everything else exactly one).
+  std::vector<std::vector<int>> width_channels;
+  std::vector<Plan> plans;
+  int full_width = 0; // index of the full-size plan
+
+  int width_for_ratio(double ratio) const
+  {
+    if (!spec->wavenet.slimmable || spec->arch != ARCH_WAVENET)
+      return 0;
+    const std::vector<int> ch = channels_for_ratio(spec->wavenet, ratio);
+    for (size_t i = 0; i < width_channels.size(); i++)
+      if (width_channels[i] == ch)
+        return (int)i;
+    return -1;
+  }
+};
+
+namespace
+{
+struct WidthGroup
+{
+  const Plan* plan = nullptr;
+  float* d_blob = nullptr;
+  NamOp* d_ops = nullptr;
+  A1Plan* d_a1 = nullptr;
+  float* d_state = nullptr; // [n_streams][state_stride] (allocated when the first stream joins)
+  float* d_init = nullptr; // LSTM initial state
+  long state_stride = 0;
+  std::vector<int> streams; // members, ascending
+  int* d_map = nullptr; // device copy of `streams` (nullptr when the group is all streams in order)
+};
+} // namespace
+
+struct nam_hip_batch
+{
+  const nam_hip_model* model = nullptr;
+  int device = 0;
+  int n_streams = 0;
+  int max_frames = 0;
+  hipStream_t stream = nullptr;
+  std::vector<WidthGroup> groups;
+  std::vector<int> stream_width;
+  float* d_in = nullptr; // staging for the host-pointer entry points
+  float* d_out = nullptr;
+  float* h_stage = nullptr; // pinned, used by the f64 path
+  int kernel = NAM_HIP_KERNEL_AUTO;
+  bool was_reset = false;
+  bool reset_with_prewarm = true; // thread_local gPrewarmOnResetDefault = true (NAM/dsp.cpp:20)
+};
+
+namespace
+{
+
+int upload_group(nam_hip_batch* b, WidthGroup& g)
+{
+  const Plan& p = *g.plan;
+  NAM_HIP_CHECK(hipMalloc(&g.d_blob, std::max<size_t>(p.blob.size(), 1) * sizeof(float)));
+  if (!p.blob.empty())
+    NAM_HIP_CHECK(hipMemcpy(g.d_blob, p.blob.data(), p.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (p.arch == ARCH_WAVENET)
+  {
+    NAM_HIP_CHECK(hipMalloc(&g.d_ops, p.ops.size() * sizeof(NamOp)));
+    NAM_HIP_CHECK(hipMemcpy(g.d_ops, p.ops.data(), p.ops.size() * sizeof(NamOp), hipMemcpyHostToDevice));
+    if (p.a1.valid)
+    {
+      NAM_HIP_CHECK(hipMalloc(&g.d_a1, sizeof(A1Plan)));
+      NAM_HIP_CHECK(hipMemcpy(g.d_a1, &p.a1, sizeof(A1Plan), hipMemcpyHostToDevice));
+    }
+  }
+  else if (p.arch == ARCH_LSTM)
+  {
+    const auto& init = p.lstm.init_state;
+    NAM_HIP_CHECK(hipMalloc(&g.d_init, std::max<size_t>(init.size(), 1) * sizeof(float)));
+    NAM_HIP_CHECK(hipMemcpy(g.d_init, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  g.state_stride = p.state_floats;
+  (void)b;
+  return NAM_HIP_OK;
+}
+
+int ensure_state(nam_hip_batch* b, WidthGroup& g)
+{
+  if (g.d_state)
+    return NAM_HIP_OK;
+  const size_t bytes = (size_t)b->n_streams * g.state_stride * sizeof(float);
+  NAM_HIP_CHECK(hipMalloc(&g.d_state, bytes));
+  NAM_HIP_CHECK(hipMemsetAsync(g.d_state, 0, bytes, b->stream));
+  return NAM_HIP_OK;
+}
+
+int refresh_map(nam_hip_batch* b, WidthGroup& g)
+{
+  if (g.d_map)
+  {
+    NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
+    NAM_HIP_CHECK(hipFree(g.d_map));
+    g.d_map = nullptr;
+  }
+  bool identity = (int)g.streams.size() == b->n_streams;
+  for (size_t i = 0; identity && i < g.streams.size(); i++)
+    identity = g.streams[i] == (int)i;
+  if (g.streams.empty() || identity)
+    return NAM_HIP_OK;
+  NAM_HIP_CHECK(hipMalloc(&g.d_map, g.streams.size() * sizeof(int)));
+  NAM_HIP_CHECK(hipMemcpy(g.d_map, g.streams.data(), g.streams.size() * sizeof(int), hipMemcpyHostToDevice));
+  return NAM_HIP_OK;
+}
+
+bool use_a1(const nam_hip_batch* b, const WidthGroup& g)
+{
+  if (!g.plan->a1.valid || !g.d_a1)
+    return false;
+  return b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1;
+}
+
+// Launch one group's kernel over `n` streams given by `d_map` (nullptr = streams 0..n-1).
+int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const float* d_in, float* d_out,
+                 int n_frames, long io_stride, hipStream_t s)
+{
+  if (n <= 0 || n_frames <= 0)
+    return NAM_HIP_OK;
+  const Plan& p = *g.plan;
+  if (p.arch == ARCH_WAVENET)
+  {
+    if (use_a1(b, g))
+    {
+      A1Args a;
+      a.plan = g.d_a1;
+      a.blob = g.d_blob;
+      a.state = g.d_state;
+      a.state_stride = g.state_stride;
+      a.stream_map = d_map;
+      a.in = d_in;
+      a.out = d_out;
+      a.io_stride = io_stride;
+      a.n_frames = n_frames;
+      a.act_p0 = 0.01f;
+      for (const auto& arr : b->model->spec->wavenet.arrays)
+        if (!arr.activations.empty() && arr.activations[0].type == ACT_LEAKYRELU)
+          a.act_p0 = arr.activations[0].p[0];
+      NAM_HIP_CHECK(launch_a1(a, n, s));
+    }
+    else
+    {
+      GenericArgs a;
+      a.ops = g.d_ops;
+      a.blob = g.d_blob;
+      a.state = g.d_state;
+      a.state_stride = g.state_stride;
+      a.stream_map = d_map;
+      a.in = d_in;
+      a.out = d_out;
+      a.io_stride = io_stride;
+      a.n_frames = n_frames;
+      a.in_ch = p.in_channels;
+      a.out_ch = p.out_channels;
+      NAM_HIP_CHECK(launch_generic(a, n, p.lds_rows * kBlock * (int)sizeof(float), s));
+    }
+  }
+  else
+  {
+    if (d_map)
+      return fail(NAM_HIP_ERR_UNSUPPORTED, "LSTM batches do not support stream subsets");
+    const LSTMPlan& L = p.lstm;
+    LSTMArgs a;
+    a.blob = g.d_blob;
+    a.state = g.d_state;
+    a.state_stride = g.state_stride;
+    a.in = d_in;
+    a.out = d_out;
+    a.io_stride = io_stride;
+    a.n_frames = n_frames;
+    a.n_streams = n;
+    a.n_layers = L.n_layers;
+    a.input_size = L.input_size;
+    a.hidden = L.hidden;
+    a.in_ch = L.in_ch;
+    a.out_ch = L.out_ch;
+    a.fast = L.fast;
+    a.head_w = L.head_w;
+    a.head_b = L.head_b;
+    for (int i = 0; i < 16; i++)
+    {
+      a.layer_w[i] = L.layer_w[i];
+      a.layer_b[i] = L.layer_b[i];
+    }
+    if (lstm_lds_bytes(a) > 160 * 1024)
+      return fail(NAM_HIP_ERR_UNSUPPORTED, "LSTM too large for the LDS-resident kernel");
+    NAM_HIP_CHECK(launch_lstm(a, s));
+  }
+  return NAM_HIP_OK;
+}
+
+// DSP::prewarm (NAM/dsp.cpp:67-101): process whole max_frames-sized buffers of silence until at
+// least prewarm_samples have gone through.
+int prewarm_frames(const nam_hip_batch* b, const Plan& p)
+{
+  const int bs = std::max(b->max_frames, 1);
+  if (p.prewarm_samples <= 0)
+    return 0;
+  return (p.prewarm_samples + bs - 1) / bs * bs;
+}
+
+int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool prewarm)
+{
+  if (n <= 0)
+    return NAM_HIP_OK;
+  const Plan& p = *g.plan;
+  if (p.arch == ARCH_WAVENET)
+    NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, d_map, n, nullptr, 0, p.state_floats, b->stream));
+  if (prewarm)
+  {
+    const int rc = launch_group(b, g, d_map, n, nullptr, nullptr, prewarm_frames(b, p), 0, b->stream);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  return NAM_HIP_OK;
+}
+
+void free_group(WidthGroup& g)
+{
+  if (g.d_blob)
+    (void)hipFree(g.d_blob);
+  if (g.d_ops)
+    (void)hipFree(g.d_ops);
+  if (g.d_a1)
+    (void)hipFree(g.d_a1);
+  if (g.d_state)
+    (void)hipFree(g.d_state);
+  if (g.d_init)
+    (void)hipFree(g.d_init);
+  if (g.d_map)
+    (void)hipFree(g.d_map);
+  g = WidthGroup();
+}
+
+int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
+{
+  auto m = std::make_unique<nam_hip_model>();
+  m->spec = std::move(spec);
+  if (m->spec->arch == ARCH_WAVENET && m->spec->wavenet.slimmable)
+  {
+    // enumerate the distinct widths: one probe ratio per interval between breakpoints
+    std::vector<double> bp = slimmable_breakpoints(m->spec->wavenet);
+    std::vector<double> probes;
+    double lo = 0.0;
+    for (double x : bp)
+    {
+      probes.push_back(0.5 * (lo + x));
+      lo = x;
+    }
+    probes.push_back(0.5 * (lo + 1.0));
+    probes.push_back(1.0);
+    for (double r : probes)
+    {
+      const std::vector<int> ch = channels_for_ratio(m->spec->wavenet, r);
+      if (std::find(m->width_channels.begin(), m->width_channels.end(), ch) == m->width_channels.end())
+      {
+        m->width_channels.push_back(ch);
+        m->plans.push_back(build_wavenet_plan(slim_wavenet(m->spec->wavenet, ch)));
+      }
+    }
+    m->full_width = m->width_for_ratio(1.0);
+  }
+  else
+  {
+    m->plans.push_back(build_plan(*m->spec));
+    m->width_channels.push_back({});
+    m->full_width = 0;
+  }
+  *out = m.release();
+  return NAM_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* nam_hip_last_error(void)
+{
+  return g_last_error.c_str();
+}
+
+const char* nam_hip_version(void)
+{
+  return "nam_hip 0.1.0 gfx950";
+}
+
+int nam_hip_model_load(const char* nam_path, int fast_tanh, nam_hip_model** out_model)
+{
+  if (!nam_path || !out_model)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_load: null argument");
+  *out_model = nullptr;
+  return guarded([&]() { return build_model(load_nam_file(nam_path, fast_tanh != 0), out_model); });
+}
+
+int nam_hip_model_load_json(const char* json_text, int fast_tanh, nam_hip_model** out_model)
+{
+  if (!json_text || !out_model)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_load_json: null argument");
+  *out_model = nullptr;
+  return guarded([&]() { return build_model(load_nam_text(json_text, fast_tanh != 0), out_model); });
+}
+
+void nam_hip_model_free(nam_hip_model* model)
+{
+  delete model;
+}
+
+int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
+{
+  if (!model || !info)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_get_info: null argument");
+  std::memset(info, 0, sizeof(*info));
+  const ModelSpec& s = *model->spec;
+  const Plan& p = model->plans[model->full_width];
+  info->architecture = s.arch == ARCH_WAVENET ? NAM_HIP_ARCH_WAVENET : NAM_HIP_ARCH_LSTM;
+  info->in_channels = s.in_channels();
+  info->out_channels = s.out_channels();
+  info->prewarm_samples = p.prewarm_samples;
+  info->expected_sample_rate = s.sample_rate;
+  info->has_loudness = s.has_loudness;
+  info->has_input_level = s.has_input_level;
+  info->has_output_level = s.has_output_level;
+  info->is_slimmable = (s.arch == ARCH_WAVENET && s.wavenet.slimmable) ? 1 : 0;
+  info->loudness = s.loudness;
+  info->input_level = s.input_level;
+  info->output_level = s.output_level;
+  info->num_weights = s.arch == ARCH_WAVENET ? (int64_t)s.wavenet.weights.size() : (int64_t)s.lstm.weights.size();
+  info->fast_tanh = s.fast_tanh ? 1 : 0;
+  info->has_a1_kernel = p.a1.valid;
+  info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
+  std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
+  return NAM_HIP_OK;
+}
+
+int nam_hip_model_slimmable_breakpoints(const nam_hip_model* model, double* out, int capacity)
+{
+  if (!model)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_slimmable_breakpoints: null model");
+  if (model->spec->arch != ARCH_WAVENET || !model->spec->wavenet.slimmable)
+    return 0;
+  const std::vector<double> bp = slimmable_breakpoints(model->spec->wavenet);
+  for (int i = 0; i < (int)bp.size() && i < capacity && out; i++)
+    out[i] = bp[i];
+  return (int)bp.size();
+}
+
+int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, int max_frames,
+                         nam_hip_batch** out_batch)
+{
+  if (!model || !out_batch || n_streams <= 0 || max_frames <= 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_create: bad argument");
+  *out_batch = nullptr;
+  int count = 0;
+  NAM_HIP_CHECK(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count)
+    return fail(NAM_HIP_ERR_DEVICE, "nam_hip_batch_create: no such HIP device " + std::to_string(device));
+  NAM_HIP_CHECK(hipSetDevice(device));
+  auto b = std::make_unique<nam_hip_batch>();
+  b->model = model;
+  b->device = device;
+  b->n_streams = n_streams;
+  b->max_frames = max_frames;
+  NAM_HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  b->groups.resize(model->plans.size());
+  for (size_t i = 0; i < model->plans.size(); i++)
+  {
+    b->groups[i].plan = &model->plans[i];
+    const int rc = upload_group(b.get(), b->groups[i]);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  b->stream_width.assign(n_streams, model->full_width);
+  WidthGroup& g = b->groups[model->full_width];
+  g.streams.resize(n_streams);
+  for (int i = 0; i < n_streams; i++)
+    g.streams[i] = i;
+  int rc = ensure_state(b.get(), g);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  if (g.plan->arch == ARCH_LSTM)
+    NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, nullptr, n_streams, g.d_init,
+                                    (int)g.plan->lstm.init_state.size(), g.plan->state_floats, b->stream));
+  const size_t in_floats = (size_t)n_streams * model->spec->in_channels() * max_frames;
+  const size_t out_floats = (size_t)n_streams * model->spec->out_channels() * max_frames;
+  NAM_HIP_CHECK(hipMalloc(&b->d_in, in_floats * sizeof(float)));
+  NAM_HIP_CHECK(hipMalloc(&b->d_out, out_floats * sizeof(float)));
+  NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), std::max(in_floats, out_floats) * sizeof(float),
+                              hipHostMallocDefault));
+  NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
+  *out_batch = b.release();
+  return NAM_HIP_OK;
+}
+
+void nam_hip_batch_destroy(nam_hip_batch* batch)
+{
+  if (!batch)
+    return;
+  (void)hipSetDevice(batch->device);
+  if (batch->stream)
+    (void)hipStreamSynchronize(batch->stream);
+  for (auto& g : batch->groups)
+    free_group(g);
+  if (batch->d_in)
+    (void)hipFree(batch->d_in);
+  if (batch->d_out)
+    (void)hipFree(batch->d_out);
+  if (batch->h_stage)
+    (void)hipHostFree(batch->h_stage);
+  if (batch->stream)
+    (void)hipStreamDestroy(batch->stream);
+  delete batch;
+}
+
+int nam_hip_batch_reset(nam_hip_batch* batch, int prewarm)
+{
+  if (!batch)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_reset: null batch");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  batch->was_reset = true;
+  batch->reset_with_prewarm = prewarm != 0;
+  for (auto& g : batch->groups)
+  {
+    if (g.streams.empty())
+      continue;
+    const int rc = reset_streams(batch, g, g.d_map, (int)g.streams.size(), prewarm != 0);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_set_slimmable_size(nam_hip_batch* batch, const int* stream_ids, int n_ids, double ratio)
+{
+  if (!batch)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_slimmable_size: null batch");
+  const nam_hip_model* m = batch->model;
+  if (m->spec->arch != ARCH_WAVENET || !m->spec->wavenet.slimmable)
+    return NAM_HIP_OK; // not a SlimmableModel: the reference's dynamic_cast fails and callers skip
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  const int w = m->width_for_ratio(ratio);
+  if (w < 0)
+    return fail(NAM_HIP_ERR_MODEL, "nam_hip_batch_set_slimmable_size: no plan for this ratio");
+  std::vector<int> ids;
+  if (!stream_ids)
+  {
+    ids.resize(batch->n_streams);
+    for (int i = 0; i < batch->n_streams; i++)
+      ids[i] = i;
+  }
+  else
+  {
+    for (int i = 0; i < n_ids; i++)
+    {
+      if (stream_ids[i] < 0 || stream_ids[i] >= batch->n_streams)
+        return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_slimmable_size: stream id out of range");
+      ids.push_back(stream_ids[i]);
+    }
+  }
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  std::vector<int> moved;
+  for (int s : ids)
+    if (batch->stream_width[s] != w) // same width: no-op (slimmable.cpp:459-464)
+      moved.push_back(s);
+  if (moved.empty())
+    return NAM_HIP_OK;
+  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  for (int s : moved)
+  {
+    auto& old = batch->groups[batch->stream_width[s]].streams;
+    old.erase(std::remove(old.begin(), old.end(), s), old.end());
+    batch->stream_width[s] = w;
+    batch->groups[w].streams.push_back(s);
+  }
+  std::sort(batch->groups[w].streams.begin(), batch->groups[w].streams.end());
+  int rc = ensure_state(batch, batch->groups[w]);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  for (auto& g : batch->groups)
+  {
+    rc = refresh_map(batch, g);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  // fresh sub-model state for the streams that moved: Reset (+ prewarm) as in slimmable.cpp:433-447
+  int* d_moved = nullptr;
+  NAM_HIP_CHECK(hipMalloc(&d_moved, moved.size() * sizeof(int)));
+  NAM_HIP_CHECK(hipMemcpy(d_moved, moved.data(), moved.size() * sizeof(int), hipMemcpyHostToDevice));
+  rc = reset_streams(batch, batch->groups[w], d_moved, (int)moved.size(), batch->was_reset && batch->reset_with_prewarm);
+  hipError_t e = hipStreamSynchronize(batch->stream);
+  (void)hipFree(d_moved);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  NAM_HIP_CHECK(e);
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float* d_out, int n_frames,
+                                 int64_t frame_stride, void* hip_stream)
+{
+  if (!batch || !d_in || !d_out || n_frames < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_process_device: bad argument");
+  if (frame_stride < n_frames)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_process_device: frame_stride < n_frames");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : batch->stream;
+  for (auto& g : batch->groups)
+  {
+    if (g.streams.empty())
+      continue;
+    const int rc = launch_group(batch, g, g.d_map, (int)g.streams.size(), d_in, d_out, n_frames, (long)frame_stride, s);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out, int n_frames)
+{
+  if (!batch || !in || !out || n_frames < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_process_f32: bad argument");
+  if (n_frames > batch->max_frames)
+    return fail(NAM_HIP_ERR_TOO_MANY_FRAMES, "nam_hip_batch_process_f32: n_frames exceeds max_frames");
+  if (n_frames == 0)
+    return NAM_HIP_OK;
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  const size_t in_bytes = (size_t)batch->n_streams * batch->model->spec->in_channels() * n_frames * sizeof(float);
+  const size_t out_bytes = (size_t)batch->n_streams * batch->model->spec->out_channels() * n_frames * sizeof(float);
+  NAM_HIP_CHECK(hipMemcpyAsync(batch->d_in, in, in_bytes, hipMemcpyHostToDevice, batch->stream));
+  const int rc = nam_hip_batch_process_device(batch, batch->d_in, batch->d_out, n_frames, n_frames, nullptr);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  NAM_HIP_CHECK(hipMemcpyAsync(out, batch->d_out, out_bytes, hipMemcpyDeviceToHost, batch->stream));
+  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_process_f64(nam_hip_batch* batch, const double* in, double* out, int n_frames)
+{
+  if (!batch || !in || !out || n_frames < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_process_f64: bad argument");
+  if (n_frames > batch->max_frames)
+    return fail(NAM_HIP_ERR_TOO_MANY_FRAMES, "nam_hip_batch_process_f64: n_frames exceeds max_frames");
+  if (n_frames == 0)
+    return NAM_HIP_OK;
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  const size_t n_in = (size_t)batch->n_streams * batch->model->spec->in_channels() * n_frames;
+  const size_t n_out = (size_t)batch->n_streams * batch->model->spec->out_channels() * n_frames;
+  // double -> float exactly as _set_condition_array does (NAM/wavenet/model.cpp:817)
+  for (size_t i = 0; i < n_in; i++)
+    batch->h_stage[i] = (float)in[i];
+  NAM_HIP_CHECK(hipMemcpyAsync(batch->d_in, batch->h_stage, n_in * sizeof(float), hipMemcpyHostToDevice, batch->stream));
+  const int rc = nam_hip_batch_process_device(batch, batch->d_in, batch->d_out, n_frames, n_frames, nullptr);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  NAM_HIP_CHECK(
+    hipMemcpyAsync(batch->h_stage, batch->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, batch->stream));
+  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  for (size_t i = 0; i < n_out; i++)
+    out[i] = (double)batch->h_stage[i];
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_synchronize(nam_hip_batch* batch)
+{
+  if (!batch)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_synchronize: null batch");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
+{
+  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
+  if (kernel == NAM_HIP_KERNEL_A1)
+    for (const auto& g : batch->groups)
+      if (g.plan->arch != ARCH_WAVENET || !g.plan->a1.valid)
+        return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 kernel cannot run this model");
+  batch->kernel = kernel;
+  return NAM_HIP_OK;
+}
+
+int nam_hip_batch_get_kernel(const nam_hip_batch* batch)
+{
+  if (!batch)
+    return NAM_HIP_ERR_INVALID_ARGUMENT;
+  if (batch->kernel != NAM_HIP_KERNEL_AUTO)
+    return batch->kernel;
+  const WidthGroup& g = batch->groups[batch->model->full_width];
+  return (g.plan->arch == ARCH_WAVENET && g.plan->a1.valid) ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
+}
+
+int nam_hip_batch_n_streams(const nam_hip_batch* batch)
+{
+  return batch ? batch->n_streams : NAM_HIP_ERR_INVALID_ARGUMENT;
+}
+
+} // extern "C"

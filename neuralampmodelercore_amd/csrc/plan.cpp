@@ -1,0 +1,616 @@
+// plan.cpp — ModelSpec -> device Plan (host side).
+//
+// The op program is a straight transcription of the reference's per-block control flow:
+//   WaveNet::process            NAM/wavenet/model.cpp:822-910
+//   LayerArray::Process(Inner)  NAM/wavenet/model.cpp:463-549
+//   Layer::Process              NAM/wavenet/model.cpp:183-393
+//   detail::Head::process       NAM/wavenet/model.cpp:86-103
+// and the weight blob is built by walking the flat weight stream in set_weights_ order
+// (model.cpp:152-181, 563-569, 661-683; Conv1D conv1d.cpp:40-55; Conv1x1 dsp.cpp:384-397).
+#include "plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+
+namespace namhip
+{
+namespace
+{
+
+struct RowAlloc
+{
+  int top = 0;
+  int high = 0;
+  int alloc(int rows)
+  {
+    const int r = top;
+    top += rows;
+    high = std::max(high, top);
+    return r * kBlock; // float offset
+  }
+  int mark() const { return top; }
+  void release(int m) { top = m; }
+};
+
+struct Builder
+{
+  Plan& plan;
+  RowAlloc rows;
+  int state_floats = 0; // ring area only; write-position table is prepended at the end
+
+  explicit Builder(Plan& p)
+  : plan(p)
+  {
+  }
+
+  int blob_reserve(size_t n, size_t align = 16)
+  {
+    while (plan.blob.size() % align)
+      plan.blob.push_back(0.0f);
+    const int off = (int)plan.blob.size();
+    plan.blob.resize(plan.blob.size() + n, 0.0f);
+    return off;
+  }
+
+  NamOp& push(int type)
+  {
+    NamOp op;
+    std::memset(&op, 0, sizeof(op));
+    op.type = type;
+    op.w = -1;
+    op.b = -1;
+    op.state = -1;
+    plan.ops.push_back(op);
+    return plan.ops.back();
+  }
+
+  // Dense conv (K >= 1) consuming weights from the flat stream. Returns nothing; dst rows must exist.
+  void conv(const float*& w, int dst, int src, int cin, int cout, int K, int dil, int groups, bool bias)
+  {
+    const int cb = (cout >= 8) ? 8 : 4;
+    const int cout_pad = (cout + cb - 1) / cb * cb;
+    const int woff = blob_reserve((size_t)K * cin * cout_pad);
+    const int opg = cout / groups, ipg = cin / groups;
+    for (int g = 0; g < groups; g++)
+      for (int i = 0; i < opg; i++)
+        for (int j = 0; j < ipg; j++)
+          for (int k = 0; k < K; k++)
+            plan.blob[(size_t)woff + ((size_t)k * cin + (g * ipg + j)) * cout_pad + (g * opg + i)] = *(w++);
+    int boff = -1;
+    if (bias)
+    {
+      boff = blob_reserve((size_t)cout_pad);
+      for (int i = 0; i < cout; i++)
+        plan.blob[(size_t)boff + i] = *(w++);
+    }
+    NamOp& op = push(OP_CONV);
+    op.dst = dst;
+    op.src = src;
+    op.cin = cin;
+    op.cout = cout;
+    op.cout_pad = cout_pad;
+    op.cb = cb;
+    op.w = woff;
+    op.b = boff;
+    op.k = K;
+    op.dil = dil;
+    const int lookback = (K - 1) * dil;
+    if (lookback > 0)
+    {
+      op.ring = lookback + kBlock;
+      op.state = state_floats;
+      op.ring_id = plan.n_rings++;
+      state_floats += cin * op.ring;
+    }
+  }
+
+  // FiLM (film.h:76-204): scale/shift = Conv1x1(cond) + bias; dst = src * scale (+ shift)
+  void film(const float*& w, const FilmSpec& f, int dst, int src, int cond, int cond_dim, int dim)
+  {
+    const int m = rows.mark();
+    const int ss_rows = (f.shift ? 2 : 1) * dim;
+    const int ss = rows.alloc(ss_rows);
+    conv(w, ss, cond, cond_dim, ss_rows, 1, 1, f.groups, true);
+    NamOp& op = push(OP_FILM);
+    op.dst = dst;
+    op.src = src;
+    op.aux = ss;
+    op.cout = dim;
+    op.flag = f.shift ? 1 : 0;
+    rows.release(m);
+  }
+
+  int act_params(const ActSpec& a)
+  {
+    const int off = blob_reserve(4 + std::max<size_t>(a.slopes.size(), 1), 4);
+    for (int i = 0; i < 4; i++)
+      plan.blob[(size_t)off + i] = a.p[i];
+    for (size_t i = 0; i < a.slopes.size(); i++)
+      plan.blob[(size_t)off + 4 + i] = a.slopes[i];
+    return off;
+  }
+
+  void act(const ActSpec& a, int buf, int channels)
+  {
+    if (a.type == ACT_IDENTITY)
+      return;
+    NamOp& op = push(OP_ACT);
+    op.dst = buf;
+    op.cout = channels;
+    op.k = a.type;
+    op.ring = (int)a.slopes.size();
+    const int off = act_params(a);
+    plan.ops.back().w = off;
+  }
+
+  void simple(int type, int dst, int src, int aux, int channels)
+  {
+    NamOp& op = push(type);
+    op.dst = dst;
+    op.src = src;
+    op.aux = aux;
+    op.cout = channels;
+  }
+
+  // Emits one WaveNet; returns the LDS offset of its (already head_scale-d) output rows.
+  // `in_rows` holds the raw input (in_channels rows). Rows allocated for the result stay allocated.
+  int wavenet(const WaveNetSpec& wn, int in_rows)
+  {
+    if ((long)wn.weights.size() != wn.expected_weight_count())
+      throw std::runtime_error("plan: WaveNet weight count mismatch");
+    const float* w = wn.weights.data();
+
+    // _process_condition model.cpp:777-807
+    int cond = in_rows;
+    int cond_dim = wn.in_channels;
+    if (wn.condition_dsp)
+    {
+      if (wn.condition_dsp->arch != ARCH_WAVENET)
+        throw std::runtime_error("plan: condition_dsp must be a WaveNet for the device path");
+      cond = wavenet(wn.condition_dsp->wavenet, in_rows);
+      cond_dim = wn.condition_dsp->wavenet.out_channels();
+    }
+
+    int prev_layer_out = -1, prev_head_out = -1;
+    for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+    {
+      const LayerArraySpec& A = wn.arrays[ai];
+      if (A.condition_size != cond_dim)
+        throw std::runtime_error("plan: condition_size does not match the condition signal");
+      const int C = A.channels, B = A.bottleneck, HO = A.head_output_size();
+      // persistent rows for this array
+      const int head_acc = rows.alloc(HO);
+      const int xa = rows.alloc(C), xb = rows.alloc(C);
+      const int head_out = rows.alloc(A.head_size);
+      // head accumulator init — model.cpp:463-486
+      if (ai == 0)
+        simple(OP_ZERO, head_acc, 0, 0, HO);
+      else
+        simple(OP_COPY, head_acc, prev_head_out, 0, HO);
+      // rechannel — model.cpp:492
+      const int layer_in = (ai == 0) ? in_rows : prev_layer_out;
+      conv(w, xa, layer_in, A.input_size, C, 1, 1, 1, false);
+      int x = xa, xn = xb;
+      for (int l = 0; l < A.num_layers(); l++)
+      {
+        const int m = rows.mark();
+        const int gm = A.gating_modes[l];
+        const int zc = gm != GATING_NONE ? 2 * B : B;
+        // The flat stream order is conv, mixin, layer1x1, head1x1, then the 8 FiLMs (model.cpp:152-181),
+        // which differs from execution order. Resolve the per-module stream positions first.
+        const float* w_conv = w;
+        const float* p = w_conv + ((long)A.kernel_sizes[l] * C * zc / A.groups_input + zc);
+        const float* w_mix = p;
+        p += (long)A.condition_size * zc / A.groups_input_mixin;
+        const float* w_l1 = p;
+        if (A.layer1x1_active)
+          p += (long)B * C / A.layer1x1_groups + C;
+        const float* w_h1 = p;
+        if (A.head1x1_active)
+          p += (long)B * A.head1x1_out / A.head1x1_groups + A.head1x1_out;
+        const int dims[FILM_COUNT] = {C, zc, A.condition_size, zc, zc, B, C, A.head1x1_out};
+        const float* w_film[FILM_COUNT];
+        bool film_on[FILM_COUNT];
+        for (int k = 0; k < FILM_COUNT; k++)
+        {
+          film_on[k] = A.film[k].active;
+          if (k == FILM_LAYER1X1_POST && !A.layer1x1_active)
+            film_on[k] = false;
+          if (k == FILM_HEAD1X1_POST && !A.head1x1_active)
+            film_on[k] = false;
+          w_film[k] = p;
+          if (film_on[k])
+          {
+            const int outc = (A.film[k].shift ? 2 : 1) * dims[k];
+            p += (long)A.condition_size * outc / A.film[k].groups + outc;
+          }
+        }
+        w = p; // next layer
+
+        // conv (+ pre/post FiLM) — model.cpp:189-203
+        const int conv_out = rows.alloc(zc);
+        int conv_in = x;
+        if (film_on[FILM_CONV_PRE])
+        {
+          conv_in = rows.alloc(C);
+          film(w_film[FILM_CONV_PRE], A.film[FILM_CONV_PRE], conv_in, x, cond, cond_dim, C);
+        }
+        conv(w_conv, conv_out, conv_in, C, zc, A.kernel_sizes[l], A.dilations[l], A.groups_input, true);
+        if (film_on[FILM_CONV_POST])
+          film(w_film[FILM_CONV_POST], A.film[FILM_CONV_POST], conv_out, conv_out, cond, cond_dim, zc);
+        // input mixin (+ pre/post FiLM) — model.cpp:205-219
+        int mix_in = cond;
+        if (film_on[FILM_MIXIN_PRE])
+        {
+          mix_in = rows.alloc(cond_dim);
+          film(w_film[FILM_MIXIN_PRE], A.film[FILM_MIXIN_PRE], mix_in, cond, cond, cond_dim, cond_dim);
+        }
+        const int mix_out = rows.alloc(zc);
+        conv(w_mix, mix_out, mix_in, cond_dim, zc, 1, 1, A.groups_input_mixin, false);
+        if (film_on[FILM_MIXIN_POST])
+          film(w_film[FILM_MIXIN_POST], A.film[FILM_MIXIN_POST], mix_out, mix_out, cond, cond_dim, zc);
+        // z = conv + mixin — model.cpp:220 (z aliases conv_out)
+        const int z = conv_out;
+        simple(OP_ADD, z, conv_out, mix_out, zc);
+        if (film_on[FILM_ACT_PRE])
+          film(w_film[FILM_ACT_PRE], A.film[FILM_ACT_PRE], z, z, cond, cond_dim, zc);
+        // activation + 1x1 — model.cpp:234-288
+        int l1 = -1;
+        if (gm == GATING_NONE)
+          act(A.activations[l], z, zc);
+        else
+        {
+          NamOp& op = push(OP_GATE);
+          op.dst = z;
+          op.cout = B;
+          op.flag = gm;
+          op.k = A.activations[l].type;
+          op.dil = A.secondary_activations[l].type;
+          op.ring = (int)A.activations[l].slopes.size();
+          op.ring_id = (int)A.secondary_activations[l].slopes.size();
+          const int o1 = act_params(A.activations[l]);
+          const int o2 = act_params(A.secondary_activations[l]);
+          plan.ops.back().w = o1;
+          plan.ops.back().b = o2;
+        }
+        if (film_on[FILM_ACT_POST])
+          film(w_film[FILM_ACT_POST], A.film[FILM_ACT_POST], z, z, cond, cond_dim, B);
+        if (A.layer1x1_active)
+        {
+          l1 = rows.alloc(C);
+          conv(w_l1, l1, z, B, C, 1, 1, A.layer1x1_groups, true);
+          // quirk: layer1x1_post_film is applied in the BLENDED branch only — model.cpp:282-286
+          if (gm == GATING_BLENDED && film_on[FILM_LAYER1X1_POST])
+            film(w_film[FILM_LAYER1X1_POST], A.film[FILM_LAYER1X1_POST], l1, l1, cond, cond_dim, C);
+        }
+        // head contribution — model.cpp:290-352, accumulated at :513-531
+        int head_src = z;
+        if (A.head1x1_active)
+        {
+          head_src = rows.alloc(A.head1x1_out);
+          conv(w_h1, head_src, z, B, A.head1x1_out, 1, 1, A.head1x1_groups, true);
+          if (film_on[FILM_HEAD1X1_POST])
+            film(w_film[FILM_HEAD1X1_POST], A.film[FILM_HEAD1X1_POST], head_src, head_src, cond, cond_dim,
+                 A.head1x1_out);
+        }
+        simple(OP_ADD, head_acc, head_acc, head_src, HO);
+        // residual — model.cpp:354-392
+        if (A.layer1x1_active)
+        {
+          simple(OP_ADD, xn, x, l1, C);
+          std::swap(x, xn);
+        }
+        rows.release(m);
+      }
+      // head rechannel (causal Conv1D) — model.cpp:547-548
+      conv(w, head_out, head_acc, HO, A.head_size, A.head_kernel_size, A.head_dilation, 1, A.head_bias);
+      prev_layer_out = x;
+      prev_head_out = head_out;
+    }
+
+    const int hs = wn.arrays.back().head_size;
+    int result;
+    if (wn.with_head)
+    {
+      // model.cpp:854-883 + Head::process :86-103. head_scale itself is the last weight, after the head convs.
+      const PostHeadSpec& H = wn.head;
+      long head_w = 0;
+      {
+        int cin = H.in_channels;
+        for (size_t i = 0; i < H.kernel_sizes.size(); i++)
+        {
+          const int cout = (i + 1 == H.kernel_sizes.size()) ? H.out_channels : H.channels;
+          head_w += (long)H.kernel_sizes[i] * cin * cout + cout;
+          cin = cout;
+        }
+      }
+      const float head_scale = w[head_w];
+      int work = rows.alloc(hs);
+      const int so = blob_reserve(1, 1);
+      plan.blob[(size_t)so] = head_scale;
+      {
+        NamOp& op = push(OP_SCALE);
+        op.dst = work;
+        op.src = prev_head_out;
+        op.cout = hs;
+        plan.ops.back().w = so;
+      }
+      int cin = H.in_channels;
+      for (size_t i = 0; i < H.kernel_sizes.size(); i++)
+      {
+        const int cout = (i + 1 == H.kernel_sizes.size()) ? H.out_channels : H.channels;
+        act(H.activation, work, cin);
+        const int o = rows.alloc(cout);
+        conv(w, o, work, cin, cout, H.kernel_sizes[i], 1, 1, true);
+        work = o;
+        cin = cout;
+      }
+      w++; // head_scale
+      result = work;
+    }
+    else
+    {
+      const float head_scale = *(w++); // model.cpp:670 — last weight overrides the JSON head_scale
+      const int so = blob_reserve(1, 1);
+      plan.blob[(size_t)so] = head_scale;
+      result = rows.alloc(hs);
+      NamOp& op = push(OP_SCALE);
+      op.dst = result;
+      op.src = prev_head_out;
+      op.cout = hs;
+      plan.ops.back().w = so;
+    }
+    if (w != wn.weights.data() + wn.weights.size())
+      throw std::runtime_error("plan: internal error, weight stream not fully consumed");
+    return result;
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// A1-family fast path eligibility + packing
+// --------------------------------------------------------------------------------------------
+bool a1_channel_supported(int c)
+{
+  return c == 1 || c == 2 || c == 3 || c == 4 || c == 6 || c == 8 || c == 12 || c == 16;
+}
+
+void build_a1(const WaveNetSpec& wn, Plan& plan)
+{
+  A1Plan& a1 = plan.a1;
+  a1.valid = 0;
+  if (wn.condition_dsp || wn.with_head || wn.in_channels != 1)
+    return;
+  if (wn.arrays.empty() || (int)wn.arrays.size() > kA1MaxArrays)
+    return;
+  if (wn.arrays.back().head_size != 1)
+    return;
+  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    if (A.condition_size != 1 || A.groups_input != 1 || A.groups_input_mixin != 1 || !A.layer1x1_active
+        || A.layer1x1_groups != 1 || A.head1x1_active || A.bottleneck != A.channels || A.head_kernel_size != 1)
+      return;
+    if (!a1_channel_supported(A.channels) || A.num_layers() < 1 || A.num_layers() > kA1MaxLayers)
+      return;
+    if (ai + 1 < wn.arrays.size() && !a1_channel_supported(A.head_size))
+      return;
+    for (int k = 0; k < FILM_COUNT; k++)
+      if (A.film[k].active)
+        return;
+    for (int l = 0; l < A.num_layers(); l++)
+    {
+      if (A.gating_modes[l] != GATING_NONE || A.kernel_sizes[l] != A.kernel_sizes[0] || A.kernel_sizes[l] < 1
+          || A.kernel_sizes[l] > 8)
+        return;
+      const ActSpec& a = A.activations[l];
+      const ActSpec& a0 = A.activations[0];
+      if (a.type != a0.type || a.type == ACT_PRELU || a.type == ACT_LEAKYHARDTANH || a.p[0] != a0.p[0])
+        return;
+    }
+  }
+  // The fast kernel shares the generic plan's state layout: ring r of the generic program is the
+  // r-th dilated conv in execution order, i.e. (array, layer) order here (head rechannel has K = 1).
+  const float* w = wn.weights.data();
+  int ring_id = 0;
+  int state_off = 0;
+  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    A1Array& out = a1.arr[ai];
+    std::memset(&out, 0, sizeof(out));
+    const int C = A.channels, K = A.kernel_sizes[0], H = A.head_size;
+    out.in_size = A.input_size;
+    out.channels = C;
+    out.kernel = K;
+    out.n_layers = A.num_layers();
+    out.head_size = H;
+    out.act = A.activations[0].type;
+    out.layer_stride = K * C * C + C + C + C * C + C;
+    const size_t total = (size_t)A.input_size * C + (size_t)out.n_layers * out.layer_stride + (size_t)C * H + H + 1;
+    while (plan.blob.size() % 16)
+      plan.blob.push_back(0.0f);
+    out.w_base = (int)plan.blob.size();
+    plan.blob.resize(plan.blob.size() + total + 16, 0.0f);
+    float* dst = plan.blob.data() + out.w_base;
+    // rechannel: stream [co][ci] -> packed [ci][co]
+    for (int co = 0; co < C; co++)
+      for (int ci = 0; ci < A.input_size; ci++)
+        dst[(size_t)ci * C + co] = *(w++);
+    dst += (size_t)A.input_size * C;
+    for (int l = 0; l < out.n_layers; l++)
+    {
+      float* cw = dst;
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < C; ci++)
+          for (int k = 0; k < K; k++)
+            cw[((size_t)k * C + ci) * C + co] = *(w++);
+      float* cb = cw + (size_t)K * C * C;
+      for (int co = 0; co < C; co++)
+        cb[co] = *(w++);
+      float* mx = cb + C;
+      for (int co = 0; co < C; co++)
+        mx[co] = *(w++);
+      float* w1 = mx + C;
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < C; ci++)
+          w1[(size_t)ci * C + co] = *(w++);
+      float* b1 = w1 + (size_t)C * C;
+      for (int co = 0; co < C; co++)
+        b1[co] = *(w++);
+      dst += out.layer_stride;
+      out.dil[l] = A.dilations[l];
+      const int lookback = (K - 1) * A.dilations[l];
+      if (lookback > 0)
+      {
+        out.ring_len[l] = lookback + kBlock;
+        out.ring_off[l] = state_off;
+        out.ring_id[l] = ring_id;
+        if (ring_id < 64)
+          a1.ring_len_by_id[ring_id] = out.ring_len[l];
+        ring_id++;
+        state_off += C * out.ring_len[l];
+      }
+      else
+      {
+        out.ring_len[l] = 0;
+        out.ring_off[l] = 0;
+        out.ring_id[l] = -1;
+      }
+    }
+    // head rechannel: stream [h][c] (+ bias[h]) -> packed [c][h], bias[h]
+    for (int h = 0; h < H; h++)
+      for (int c = 0; c < C; c++)
+        dst[(size_t)c * H + h] = *(w++);
+    float* hb = dst + (size_t)C * H;
+    for (int h = 0; h < H; h++)
+      hb[h] = A.head_bias ? *(w++) : 0.0f;
+  }
+  a1.n_arrays = (int)wn.arrays.size();
+  a1.n_rings = ring_id;
+  a1.head_scale_off = (int)plan.blob.size();
+  plan.blob.push_back(*(w++));
+  if (w != wn.weights.data() + wn.weights.size() || ring_id != plan.n_rings || ring_id > 64)
+  {
+    a1.valid = 0; // layouts disagree: keep the generic path only
+    return;
+  }
+  a1.valid = 1;
+}
+
+} // namespace
+
+Plan build_wavenet_plan(const WaveNetSpec& wn)
+{
+  Plan plan;
+  plan.arch = ARCH_WAVENET;
+  plan.in_channels = wn.in_channels;
+  plan.out_channels = wn.out_channels();
+  plan.prewarm_samples = wn.prewarm_samples();
+  Builder b(plan);
+  const int in_rows = b.rows.alloc(wn.in_channels);
+  {
+    NamOp& op = b.push(OP_LOAD_IN);
+    op.dst = in_rows;
+    op.cout = wn.in_channels;
+  }
+  const int out_rows = b.wavenet(wn, in_rows);
+  {
+    NamOp& op = b.push(OP_STORE_OUT);
+    op.src = out_rows;
+    op.cin = plan.out_channels;
+  }
+  b.push(OP_END);
+  plan.lds_rows = b.rows.high;
+  // per-stream state: [write positions: n_rings ints, padded to 64 words][rings...]
+  const int table = (plan.n_rings + kBlock - 1) / kBlock * kBlock;
+  for (auto& op : plan.ops)
+    if (op.type == OP_CONV && op.state >= 0)
+      op.state += table;
+  plan.state_floats = (table + b.state_floats + kBlock - 1) / kBlock * kBlock;
+  if (plan.state_floats == 0)
+    plan.state_floats = kBlock;
+  build_a1(wn, plan);
+  if (plan.a1.valid)
+    for (int a = 0; a < plan.a1.n_arrays; a++)
+      for (int l = 0; l < plan.a1.arr[a].n_layers; l++)
+        if (plan.a1.arr[a].ring_id[l] >= 0)
+          plan.a1.arr[a].ring_off[l] += table;
+  return plan;
+}
+
+static Plan build_lstm_plan(const ModelSpec& model)
+{
+  const LSTMSpec& c = model.lstm;
+  Plan plan;
+  plan.arch = ARCH_LSTM;
+  plan.in_channels = c.in_channels;
+  plan.out_channels = c.out_channels;
+  plan.prewarm_samples = model.prewarm_samples();
+  LSTMPlan& L = plan.lstm;
+  if (c.num_layers > 16)
+    throw std::runtime_error("plan: LSTM with more than 16 layers is not supported on the device path");
+  if (c.num_layers < 1)
+    throw std::runtime_error("plan: LSTM with zero layers is not supported on the device path");
+  if (c.in_channels != c.input_size)
+    throw std::runtime_error("plan: LSTM in_channels must equal input_size");
+  L.n_layers = c.num_layers;
+  L.input_size = c.input_size;
+  L.hidden = c.hidden_size;
+  L.in_ch = c.in_channels;
+  L.out_ch = c.out_channels;
+  L.fast = model.fast_tanh ? 1 : 0;
+  const float* w = c.weights.data();
+  const int H = c.hidden_size;
+  for (int l = 0; l < c.num_layers; l++)
+  {
+    const int I = l == 0 ? c.input_size : H;
+    while (plan.blob.size() % 16)
+      plan.blob.push_back(0.0f);
+    L.layer_w[l] = (int)plan.blob.size();
+    plan.blob.insert(plan.blob.end(), w, w + (size_t)4 * H * (I + H));
+    w += (size_t)4 * H * (I + H);
+    L.layer_b[l] = (int)plan.blob.size();
+    plan.blob.insert(plan.blob.end(), w, w + 4 * H);
+    w += 4 * H;
+    // h0 then c0 (lstm.cpp:24-28)
+    L.init_state.insert(L.init_state.end(), w, w + 2 * H);
+    w += 2 * H;
+  }
+  L.head_w = (int)plan.blob.size();
+  plan.blob.insert(plan.blob.end(), w, w + (size_t)c.out_channels * H);
+  w += (size_t)c.out_channels * H;
+  L.head_b = (int)plan.blob.size();
+  plan.blob.insert(plan.blob.end(), w, w + c.out_channels);
+  w += c.out_channels;
+  if (w != c.weights.data() + c.weights.size())
+    throw std::runtime_error("plan: LSTM weight stream not fully consumed");
+  L.valid = 1;
+  plan.state_floats = (c.num_layers * 2 * H + kBlock - 1) / kBlock * kBlock;
+  return plan;
+}
+
+Plan build_plan(const ModelSpec& model)
+{
+  if (model.arch == ARCH_WAVENET)
+  {
+    if (model.wavenet.slimmable)
+      return build_wavenet_plan(slim_wavenet(model.wavenet, channels_for_ratio(model.wavenet, 1.0)));
+    return build_wavenet_plan(model.wavenet);
+  }
+  if (model.arch == ARCH_LSTM)
+    return build_lstm_plan(model);
+  throw std::runtime_error("plan: unknown architecture");
+}
+
+std::string Plan::describe() const
+{
+  std::stringstream ss;
+  ss << "arch=" << arch << " in=" << in_channels << " out=" << out_channels << " ops=" << ops.size()
+     << " blob=" << blob.size() << " lds_rows=" << lds_rows << " rings=" << n_rings
+     << " state_floats=" << state_floats << " a1=" << a1.valid << " lstm=" << lstm.valid
+     << " prewarm=" << prewarm_samples;
+  return ss.str();
+}
+
+} // namespace namhip

@@ -188,12 +188,121 @@ static void orc_arena_free(orc_arena* ar)
 }
 
 /* ------------------------------------------------------------------------- */
+/* Y[:, f] (op)= Wt^T X[:, f] for a block of frames: y[o][f] = sum_i wt[i][o] x[i][f], */
+/* each output summed in input order i = 0..in-1 (the rounding of a plain dot        */
+/* product). Frames are handled four at a time and the fixed-N variants exist only   */
+/* so the compiler keeps the accumulators in vector registers: every variant does    */
+/* exactly the same floating-point operations in the same order per output element.  */
+/* accumulate != 0 adds the finished product to Y (per-tap "out += W[k] * in").       */
+/* ------------------------------------------------------------------------- */
+#define ORC_GEMM_FIXED(N)                                                                                   \
+  static void orc_gemm_##N(const float* restrict wt, const float* restrict x, int x_stride, int in_ch,       \
+                           int n_frames, float* restrict y, int accumulate)                                 \
+  {                                                                                                         \
+    int f = 0;                                                                                              \
+    for (; f + 4 <= n_frames; f += 4)                                                                       \
+    {                                                                                                       \
+      float a0[N], a1[N], a2[N], a3[N];                                                                     \
+      for (int o = 0; o < N; o++)                                                                           \
+        a0[o] = a1[o] = a2[o] = a3[o] = 0.0f;                                                               \
+      const float* x0 = x + (size_t)f * x_stride;                                                           \
+      const float* x1 = x0 + x_stride;                                                                      \
+      const float* x2 = x1 + x_stride;                                                                      \
+      const float* x3 = x2 + x_stride;                                                                      \
+      for (int i = 0; i < in_ch; i++)                                                                       \
+      {                                                                                                     \
+        const float* restrict wc = wt + (size_t)i * N;                                                      \
+        const float v0 = x0[i], v1 = x1[i], v2 = x2[i], v3 = x3[i];                                         \
+        for (int o = 0; o < N; o++)                                                                         \
+        {                                                                                                   \
+          a0[o] += wc[o] * v0;                                                                              \
+          a1[o] += wc[o] * v1;                                                                              \
+          a2[o] += wc[o] * v2;                                                                              \
+          a3[o] += wc[o] * v3;                                                                              \
+        }                                                                                                   \
+      }                                                                                                     \
+      float* y0 = y + (size_t)f * N;                                                                        \
+      if (accumulate)                                                                                       \
+        for (int o = 0; o < N; o++)                                                                         \
+        {                                                                                                   \
+          y0[o] += a0[o];                                                                                   \
+          y0[N + o] += a1[o];                                                                               \
+          y0[2 * N + o] += a2[o];                                                                           \
+          y0[3 * N + o] += a3[o];                                                                           \
+        }                                                                                                   \
+      else                                                                                                  \
+        for (int o = 0; o < N; o++)                                                                         \
+        {                                                                                                   \
+          y0[o] = a0[o];                                                                                    \
+          y0[N + o] = a1[o];                                                                                \
+          y0[2 * N + o] = a2[o];                                                                            \
+          y0[3 * N + o] = a3[o];                                                                            \
+        }                                                                                                   \
+    }                                                                                                       \
+    for (; f < n_frames; f++)                                                                               \
+    {                                                                                                       \
+      float a0[N];                                                                                          \
+      for (int o = 0; o < N; o++)                                                                           \
+        a0[o] = 0.0f;                                                                                       \
+      const float* x0 = x + (size_t)f * x_stride;                                                           \
+      for (int i = 0; i < in_ch; i++)                                                                       \
+      {                                                                                                     \
+        const float* restrict wc = wt + (size_t)i * N;                                                      \
+        const float v0 = x0[i];                                                                             \
+        for (int o = 0; o < N; o++)                                                                         \
+          a0[o] += wc[o] * v0;                                                                              \
+      }                                                                                                     \
+      float* y0 = y + (size_t)f * N;                                                                        \
+      for (int o = 0; o < N; o++)                                                                           \
+        y0[o] = accumulate ? y0[o] + a0[o] : a0[o];                                                         \
+    }                                                                                                       \
+  }
+ORC_GEMM_FIXED(1)
+ORC_GEMM_FIXED(2)
+ORC_GEMM_FIXED(3)
+ORC_GEMM_FIXED(4)
+ORC_GEMM_FIXED(6)
+ORC_GEMM_FIXED(8)
+ORC_GEMM_FIXED(12)
+ORC_GEMM_FIXED(16)
+
+static void orc_gemm(const float* restrict wt, const float* restrict x, int x_stride, int in_ch, int oc, int n_frames,
+                     float* restrict y, int accumulate)
+{
+  switch (oc)
+  {
+    case 1: orc_gemm_1(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 2: orc_gemm_2(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 3: orc_gemm_3(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 4: orc_gemm_4(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 6: orc_gemm_6(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 8: orc_gemm_8(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 12: orc_gemm_12(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    case 16: orc_gemm_16(wt, x, x_stride, in_ch, n_frames, y, accumulate); return;
+    default: break;
+  }
+  for (int f = 0; f < n_frames; f++)
+  {
+    const float* x0 = x + (size_t)f * x_stride;
+    float* y0 = y + (size_t)f * oc;
+    for (int o = 0; o < oc; o++)
+    {
+      float sum = 0.0f;
+      for (int i = 0; i < in_ch; i++)
+        sum += wt[(size_t)i * oc + o] * x0[i];
+      y0[o] = accumulate ? y0[o] + sum : sum;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Conv1x1 — NAM/dsp.cpp:311-355 (ctor), :363-398 (set_weights_), :436-836     */
 /* ------------------------------------------------------------------------- */
 typedef struct
 {
   int in_ch, out_ch, groups, has_bias;
   float* w; /* dense [out][in] row-major; block-diagonal for grouped */
+  float* wt; /* the same matrix stored [in][out] (so the per-frame update vectorises over outputs) */
   float* bias;
   float* out; /* [out_ch x max_buf] column-major */
 } orc_conv1x1;
@@ -205,6 +314,7 @@ static void orc_conv1x1_init(orc_arena* ar, orc_conv1x1* c, int in_ch, int out_c
   c->groups = groups;
   c->has_bias = has_bias;
   c->w = (float*)orc_alloc(ar, sizeof(float) * (size_t)in_ch * out_ch);
+  c->wt = (float*)orc_alloc(ar, sizeof(float) * (size_t)in_ch * out_ch);
   c->bias = has_bias ? (float*)orc_alloc(ar, sizeof(float) * out_ch) : NULL;
   c->out = NULL;
 }
@@ -224,6 +334,9 @@ static const float* orc_conv1x1_set_weights(orc_conv1x1* c, const float* w)
     for (int i = 0; i < opg; i++)
       for (int j = 0; j < ipg; j++)
         c->w[(size_t)(g * opg + i) * c->in_ch + (g * ipg + j)] = *(w++);
+  for (int o = 0; o < c->out_ch; o++)
+    for (int i = 0; i < c->in_ch; i++)
+      c->wt[(size_t)i * c->out_ch + o] = c->w[(size_t)o * c->in_ch + i];
   if (c->has_bias)
     for (int i = 0; i < c->out_ch; i++)
       c->bias[i] = *(w++);
@@ -239,19 +352,14 @@ static void orc_conv1x1_set_max_buffer(orc_arena* ar, orc_conv1x1* c, int max_bu
  * `in` is column-major with column stride in_stride (>= in_ch). */
 static void orc_conv1x1_process(orc_conv1x1* c, const float* in, int in_stride, int num_frames)
 {
-  for (int f = 0; f < num_frames; f++)
-  {
-    const float* x = in + (size_t)f * in_stride;
-    float* y = c->out + (size_t)f * c->out_ch;
-    for (int o = 0; o < c->out_ch; o++)
+  orc_gemm(c->wt, in, in_stride, c->in_ch, c->out_ch, num_frames, c->out, 0);
+  if (c->has_bias)
+    for (int f = 0; f < num_frames; f++)
     {
-      const float* wr = c->w + (size_t)o * c->in_ch;
-      float sum = 0.0f;
-      for (int i = 0; i < c->in_ch; i++)
-        sum += wr[i] * x[i];
-      y[o] = c->has_bias ? sum + c->bias[o] : sum;
+      float* y = c->out + (size_t)f * c->out_ch;
+      for (int o = 0; o < c->out_ch; o++)
+        y[o] += c->bias[o];
     }
-  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -297,9 +405,12 @@ static void orc_ring_write(orc_ring* r, const float* in, int in_stride, int num_
 {
   if (r->write_pos + num_frames > r->cols)
     orc_ring_rewind(r);
-  for (int f = 0; f < num_frames; f++)
-    memcpy(r->storage + (size_t)(r->write_pos + f) * r->channels, in + (size_t)f * in_stride,
-           sizeof(float) * r->channels);
+  if (in_stride == r->channels)
+    memcpy(r->storage + (size_t)r->write_pos * r->channels, in, sizeof(float) * (size_t)num_frames * r->channels);
+  else
+    for (int f = 0; f < num_frames; f++)
+      memcpy(r->storage + (size_t)(r->write_pos + f) * r->channels, in + (size_t)f * in_stride,
+             sizeof(float) * r->channels);
 }
 
 /* ring_buffer.cpp:44-57 */
@@ -316,6 +427,7 @@ typedef struct
 {
   int in_ch, out_ch, K, dilation, groups, has_bias;
   float* w; /* dense [K][out][in] */
+  float* wt; /* dense [K][in][out] */
   float* bias;
   orc_ring ring;
   float* out; /* [out_ch x max_buf] */
@@ -334,6 +446,7 @@ static void orc_conv1d_init(orc_arena* ar, orc_conv1d* c, int in_ch, int out_ch,
   c->groups = groups;
   c->has_bias = has_bias;
   c->w = (float*)orc_alloc(ar, sizeof(float) * (size_t)K * in_ch * out_ch);
+  c->wt = (float*)orc_alloc(ar, sizeof(float) * (size_t)K * in_ch * out_ch);
   c->bias = has_bias ? (float*)orc_alloc(ar, sizeof(float) * out_ch) : NULL;
   c->cached_col = (float*)orc_alloc(ar, sizeof(float) * in_ch);
 }
@@ -354,6 +467,10 @@ static const float* orc_conv1d_set_weights(orc_conv1d* c, const float* w)
       for (int j = 0; j < ipg; j++)
         for (int k = 0; k < c->K; k++)
           c->w[((size_t)k * c->out_ch + (g * opg + i)) * c->in_ch + (g * ipg + j)] = *(w++);
+  for (int k = 0; k < c->K; k++)
+    for (int o = 0; o < c->out_ch; o++)
+      for (int i = 0; i < c->in_ch; i++)
+        c->wt[((size_t)k * c->in_ch + i) * c->out_ch + o] = c->w[((size_t)k * c->out_ch + o) * c->in_ch + i];
   if (c->has_bias)
     for (int i = 0; i < c->out_ch; i++)
       c->bias[i] = *(w++);
@@ -372,31 +489,22 @@ static void orc_conv1d_set_max_buffer(orc_arena* ar, orc_conv1d* c, int max_buf)
 static void orc_conv1d_process(orc_conv1d* c, const float* in, int in_stride, int num_frames)
 {
   orc_ring_write(&c->ring, in, in_stride, num_frames);
-  for (int f = 0; f < num_frames; f++)
-  {
-    float* y = c->out + (size_t)f * c->out_ch;
-    for (int o = 0; o < c->out_ch; o++)
-      y[o] = 0.0f;
-  }
+  /* out = 0; for each tap k: out += W[k] * ring.Read(n, lookback_k) — conv1d.cpp:672-682 */
   for (int k = 0; k < c->K; k++)
   {
     const long lookback = (long)c->dilation * (c->K - 1 - k);
     const float* blk = orc_ring_read(&c->ring, lookback);
-    const float* wk = c->w + (size_t)k * c->out_ch * c->in_ch;
-    for (int f = 0; f < num_frames; f++)
+    const float* wk = c->wt + (size_t)k * c->out_ch * c->in_ch;
+    if (k == 0)
     {
-      const float* x = blk + (size_t)f * c->in_ch;
-      float* y = c->out + (size_t)f * c->out_ch;
-      for (int o = 0; o < c->out_ch; o++)
-      {
-        const float* wr = wk + (size_t)o * c->in_ch;
-        float sum = 0.0f;
-        for (int i = 0; i < c->in_ch; i++)
-          sum += wr[i] * x[i];
-        y[o] += sum;
-      }
+      /* 0 + (W[0] x) == W[0] x exactly, so the first tap can store instead of accumulate */
+      orc_gemm(wk, blk, c->in_ch, c->in_ch, c->out_ch, num_frames, c->out, 0);
     }
+    else
+      orc_gemm(wk, blk, c->in_ch, c->in_ch, c->out_ch, num_frames, c->out, 1);
   }
+  if (c->K == 0)
+    memset(c->out, 0, sizeof(float) * (size_t)c->out_ch * num_frames);
   if (c->has_bias)
     for (int f = 0; f < num_frames; f++)
     {
@@ -1073,6 +1181,27 @@ ORC_API void orc_wavenet_process(void* h, const float* in, float* out, int n)
       out[(size_t)ch * n + s] = wn->head_scale * fh[(size_t)s * hs + ch];
 }
 
+/* A long signal fed in `block`-frame process() calls, as tools/benchmodel.cpp:129-132 and
+ * tools/render.cpp:146-197 do; the loop lives in C so timing it excludes any Python overhead. */
+ORC_API void orc_wavenet_process_blocks(void* h, const float* in, float* out, long n_total, int block)
+{
+  orc_wavenet* wn = (orc_wavenet*)h;
+  const int ic = wn->in_channels, oc = wn->out_channels;
+  float* tin = (float*)malloc(sizeof(float) * (size_t)ic * block);
+  float* tout = (float*)malloc(sizeof(float) * (size_t)oc * block);
+  for (long s = 0; s < n_total; s += block)
+  {
+    const int n = (int)((n_total - s) < block ? (n_total - s) : block);
+    for (int c = 0; c < ic; c++)
+      memcpy(tin + (size_t)c * n, in + (size_t)c * n_total + s, sizeof(float) * n);
+    orc_wavenet_process(wn, tin, tout, n);
+    for (int c = 0; c < oc; c++)
+      memcpy(out + (size_t)c * n_total + s, tout + (size_t)c * n, sizeof(float) * n);
+  }
+  free(tin);
+  free(tout);
+}
+
 static int orc_wavenet_has_cache(const orc_wavenet* wn)
 {
   /* model.cpp:749-757 */
@@ -1308,6 +1437,25 @@ ORC_API void orc_lstm_process(void* h, const float* in, float* out, int n)
     for (int ch = 0; ch < m->out_ch; ch++)
       out[(size_t)ch * n + f] = m->output[ch];
   }
+}
+
+ORC_API void orc_lstm_process_blocks(void* h, const float* in, float* out, long n_total, int block)
+{
+  orc_lstm* m = (orc_lstm*)h;
+  const int ic = m->in_ch, oc = m->out_ch;
+  float* tin = (float*)malloc(sizeof(float) * (size_t)ic * block);
+  float* tout = (float*)malloc(sizeof(float) * (size_t)oc * block);
+  for (long s = 0; s < n_total; s += block)
+  {
+    const int n = (int)((n_total - s) < block ? (n_total - s) : block);
+    for (int c = 0; c < ic; c++)
+      memcpy(tin + (size_t)c * n, in + (size_t)c * n_total + s, sizeof(float) * n);
+    orc_lstm_process(m, tin, tout, n);
+    for (int c = 0; c < oc; c++)
+      memcpy(out + (size_t)c * n_total + s, tout + (size_t)c * n, sizeof(float) * n);
+  }
+  free(tin);
+  free(tout);
 }
 
 /* lstm.cpp:127-134 */

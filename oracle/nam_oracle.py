@@ -71,19 +71,38 @@ def build(force: bool = False) -> str:
     """Compile nam_oracle.c -> libnam_oracle.so (gcc, no FMA contraction)."""
     src = os.path.join(_HERE, "nam_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c99",
-               "-o", _LIB_PATH, src, "-lm"]
+        # -ffp-contract=off: every multiply/add individually rounded; -O3 vectorises across output
+        # channels only (no -ffast-math), so results do not depend on the host's SIMD width.
+        cmd = ["gcc", "-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
+               "-std=c99", "-o", _LIB_PATH, src, "-lm"]
         subprocess.check_call(cmd)
     return _LIB_PATH
+
+
+def build_fast(out_path: str) -> str:
+    """Timing-only build for bench.py's cpu_baseline: same source with the reference's Release flags
+    (-Ofast, tools/CMakeLists.txt:176) and -march=native. Built on the machine that runs it."""
+    src = os.path.join(_HERE, "nam_oracle.c")
+    subprocess.check_call(["gcc", "-Ofast", "-march=native", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c99",
+                           "-o", out_path, src, "-lm"])
+    return out_path
 
 
 _lib = None
 
 
+def use_library(path: str) -> None:
+    """Point the module at another build of the same C source (bench.py's -Ofast timing build)."""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path
+    _lib = None
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if _LIB_PATH == os.path.join(_HERE, "libnam_oracle.so"):
+            build()
         L = ctypes.CDLL(_LIB_PATH)
         vp, ci, cf, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
         fp = ctypes.POINTER(ctypes.c_float)
@@ -110,6 +129,10 @@ def lib():
         L.orc_wavenet_head_scale.argtypes = [vp]
         L.orc_wavenet_process.restype = None
         L.orc_wavenet_process.argtypes = [vp, fp, fp, ci]
+        L.orc_wavenet_process_blocks.restype = None
+        L.orc_wavenet_process_blocks.argtypes = [vp, fp, fp, cl, ci]
+        L.orc_lstm_process_blocks.restype = None
+        L.orc_lstm_process_blocks.argtypes = [vp, fp, fp, cl, ci]
         L.orc_wavenet_reset.restype = None
         L.orc_wavenet_reset.argtypes = [vp, ci, ci]
         L.orc_wavenet_free.restype = None
@@ -665,6 +688,13 @@ class OracleWaveNet(OracleDSP):
         self._L.orc_wavenet_process(self._h, _fptr(x), _fptr(out), n)
         return out
 
+    def process_stream(self, x, block):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float32)
+        assert x.shape[0] == self.NumInputChannels() and block <= self.max_buffer_size
+        out = np.zeros((self.NumOutputChannels(), x.shape[1]), dtype=np.float32)
+        self._L.orc_wavenet_process_blocks(self._h, _fptr(x), _fptr(out), x.shape[1], block)
+        return out
+
 
 class OracleSlimmableWaveNet(OracleDSP):
     """slimmable.cpp:352-530 — rebuilds a plain WaveNet of the selected width."""
@@ -753,6 +783,9 @@ class OracleSlimmableWaveNet(OracleDSP):
     def process(self, x):
         return self._active.process(x)
 
+    def process_stream(self, x, block):
+        return self._active.process_stream(x, block)
+
 
 class OracleLSTM(OracleDSP):
     def __init__(self, config: dict, weights: np.ndarray, sample_rate: float, fast_tanh: bool):
@@ -793,6 +826,12 @@ class OracleLSTM(OracleDSP):
         n = x.shape[1]
         out = np.zeros((self.out_channels, n), dtype=np.float32)
         self._L.orc_lstm_process(self._h, _fptr(x), _fptr(out), n)
+        return out
+
+    def process_stream(self, x, block):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float32)
+        out = np.zeros((self.out_channels, x.shape[1]), dtype=np.float32)
+        self._L.orc_lstm_process_blocks(self._h, _fptr(x), _fptr(out), x.shape[1], block)
         return out
 
 

@@ -1,0 +1,167 @@
+"""-m gpu parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs. Tolerances follow the reference's own alt-implementation precedent
+(tools/test/test_a2_fast.cpp:296-298: max-abs 5e-5) — 5e-5 with fast_tanh (a pure rational
+function), 1e-4 with libm tanh / expf (device vs host transcendental ulp differences)."""
+import numpy as np
+import pytest
+
+from conftest import model_path
+from signals import stream_bank, two_tone
+
+pytestmark = pytest.mark.gpu
+
+WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet"]
+
+
+def _oracle_run(oracle, name, x, block, fast_tanh, ratio=None):
+    ref = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    if ratio is not None:
+        ref.SetSlimmableSize(ratio)
+    ref.Reset(48000.0, block)
+    return ref.process_stream(x, block)
+
+
+def _tol(fast_tanh):
+    return 5e-5 if fast_tanh else 1e-4
+
+
+@pytest.mark.parametrize("name", WAVENETS)
+@pytest.mark.parametrize("fast_tanh", [True, False])
+@pytest.mark.parametrize("kernel", ["generic", "auto"])
+def test_wavenet_matches_oracle(nam_lib, oracle, name, fast_tanh, kernel):
+    nam = nam_lib
+    n_streams, block, n = 5, 64, 64 * 6
+    x = stream_bank(n_streams, n, seed=3)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    batch = model.batch(n_streams, block)
+    if kernel == "generic":
+        batch.set_kernel(nam.KERNEL_GENERIC)
+    batch.Reset(prewarm=True)
+    y = batch.process_stream(x, block)
+    assert y.shape == (n_streams, model.NumOutputChannels(), n)
+    for s in range(n_streams):
+        r = _oracle_run(oracle, name, x[s], block, fast_tanh)
+        scale = max(1.0, float(np.max(np.abs(r))))
+        err = float(np.max(np.abs(r - y[s])))
+        assert err <= _tol(fast_tanh) * scale, (name, s, err, scale)
+    batch.close()
+
+
+def test_lstm_matches_oracle(nam_lib, oracle):
+    nam = nam_lib
+    for fast_tanh in (True, False):
+        n_streams, block, n = 70, 64, 64 * 4  # 70: exercises a partial 64-stream wavefront
+        rng = np.random.default_rng(0)
+        x = rng.uniform(-0.5, 0.5, size=(n_streams, n)).astype(np.float32)
+        model = nam.get_dsp(model_path("lstm"), fast_tanh=fast_tanh)
+        assert model.GetPrewarmSamples() == 24000
+        batch = model.batch(n_streams, block)
+        batch.Reset(prewarm=True)
+        y = batch.process_stream(x, block)
+        for s in (0, 1, 63, 64, 69):
+            r = _oracle_run(oracle, "lstm", x[s], block, fast_tanh)
+            err = float(np.max(np.abs(r - y[s])))
+            assert err <= _tol(fast_tanh), (s, err)
+        batch.close()
+
+
+def test_block_partition_independence(nam_lib):
+    """process(n) in one call == the same audio in ragged calls (state carried in HBM rings)."""
+    nam = nam_lib
+    x = stream_bank(3, 500, seed=5)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1):
+        b1 = model.batch(3, 512)
+        b1.set_kernel(kernel)
+        b1.Reset(prewarm=False)
+        y1 = b1.process(x)
+        b2 = model.batch(3, 512)
+        b2.set_kernel(kernel)
+        b2.Reset(prewarm=False)
+        parts, pos = [], 0
+        for n in (1, 63, 64, 65, 7, 200, 100):
+            parts.append(b2.process(x[:, pos:pos + n]))
+            pos += n
+        y2 = np.concatenate(parts, axis=2)
+        assert pos == 500
+        np.testing.assert_array_equal(y1, y2)
+        b1.close()
+        b2.close()
+
+
+def test_generic_and_a1_kernels_agree(nam_lib):
+    nam = nam_lib
+    x = stream_bank(4, 64 * 5, seed=9)
+    for name in ("wavenet", "wavenet_a1_standard", "slimmable_wavenet"):
+        model = nam.get_dsp(model_path(name), fast_tanh=True)
+        assert model.info.has_a1_kernel == 1
+        ys = []
+        for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1):
+            b = model.batch(4, 64)
+            b.set_kernel(kernel)
+            b.Reset(prewarm=True)
+            ys.append(b.process_stream(x, 64))
+            b.close()
+        assert float(np.max(np.abs(ys[0] - ys[1]))) < 1e-5 * max(1.0, float(np.max(np.abs(ys[0]))))
+
+
+def test_double_api_matches_float(nam_lib):
+    nam = nam_lib
+    x = stream_bank(2, 128, seed=1)
+    model = nam.get_dsp(model_path("wavenet"), fast_tanh=False)
+    b = model.batch(2, 64)
+    b.Reset()
+    yf = b.process_stream(x, 64)
+    b.Reset()
+    yd = b.process_stream(x.astype(np.float64), 64)
+    assert yd.dtype == np.float64
+    np.testing.assert_array_equal(yf.astype(np.float64), yd)
+    b.close()
+
+
+def test_too_many_frames_is_an_error(nam_lib):
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet"))
+    b = model.batch(1, 64)
+    with pytest.raises(nam.NamHipError):
+        b.process(np.zeros((1, 1, 65), dtype=np.float32))
+    b.close()
+
+
+def test_slimmable_mixed_width_batch(nam_lib, oracle):
+    """Config 5: streams of one batch run at different widths; each matches the oracle's slimmed model."""
+    nam = nam_lib
+    n_streams, block, n = 8, 64, 64 * 5
+    x = stream_bank(n_streams, n, seed=11)
+    ratios = [0.0, 0.34, 0.67, 1.0]
+    model = nam.get_dsp(model_path("slimmable_wavenet"), fast_tanh=False)
+    assert model.is_slimmable and model.GetSlimmableSizeBreakpoints() == pytest.approx([1 / 3, 2 / 3])
+    b = model.batch(n_streams, block)
+    b.Reset(prewarm=True)
+    for i, r in enumerate(ratios):
+        b.SetSlimmableSize(r, [s for s in range(n_streams) if s % len(ratios) == i])
+    y = b.process_stream(x, block)
+    for s in range(n_streams):
+        r = _oracle_run(oracle, "slimmable_wavenet", x[s], block, False, ratio=ratios[s % len(ratios)])
+        scale = max(1.0, float(np.max(np.abs(r))))
+        assert float(np.max(np.abs(r - y[s]))) <= 1e-4 * scale, s
+    b.close()
+
+
+def test_device_pointer_long_render(nam_lib, oracle):
+    """Offline re-amp form: whole signal resident in HBM, one launch walks it in 64-frame blocks."""
+    torch = pytest.importorskip("torch")
+    nam = nam_lib
+    n_streams, n = 6, 64 * 20 + 17
+    x = stream_bank(n_streams, n, seed=4)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    b = model.batch(n_streams, 64)
+    b.Reset(prewarm=True)
+    xd = torch.from_numpy(x[:, None, :]).cuda()
+    yd = b.process_tensor(xd)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    for s in (0, n_streams - 1):
+        r = _oracle_run(oracle, "wavenet_a1_standard", x[s], 64, True)
+        assert float(np.max(np.abs(r - y[s]))) <= 5e-5
+    b.close()
