@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark: real-time audio streams (xRT) at 48 kHz through
+wavenet_a1_standard.nam on MI355X (BASELINE.json metric / configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: every stream of the batch advances by one
+64-frame buffer (`DSP::process(in, out, 64)` for all streams at once). Inputs are resident in HBM
+before the timed region; K steps are timed between barrier + torch.cuda.synchronize() pairs and the
+MAX over ranks is used. Weak scaling: every GPU owns `--streams` independent streams (no data-path
+collective; RCCL only scatters the input bank before and gathers checksums after the timed region).
+
+Launch modes (the kernel is the same):
+  --launch block     one kernel launch per 64-frame step, K launches enqueued back to back
+                     (the real-time serving shape: buffer = 64 samples)            [default]
+  --launch resident  ONE launch walks all K steps of the resident signal (offline re-amp shape)
+
+Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel's algorithmic FLOPs
+(2 x MAC per stream-sample, SURVEY.md §8d: 26,640 for wavenet_a1_standard) against the fp32 peak
+of MI355X (157.3 TFLOP/s — the fp32 MFMA peak equals the fp32 vector peak on gfx950);
+`cpu_baseline` times the CPU oracle (oracle/, -Ofast build made on this box) on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SR = 48000.0
+FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 vector == FP32 (f32-in) MFMA
+
+
+def wavenet_macs_per_sample(cfg: dict) -> int:
+    """Algorithmic MACs per stream-sample of a WaveNet config (dense, grouped convs counted per group).
+    wavenet_a1_standard -> 13,320."""
+    macs = 0
+    if cfg.get("condition_dsp"):
+        macs += wavenet_macs_per_sample(cfg["condition_dsp"]["config"])
+    for lc in cfg["layers"]:
+        C = lc["channels"]
+        B = lc.get("bottleneck", C)
+        cs = lc["condition_size"]
+        n = len(lc["dilations"])
+        ks = lc.get("kernel_sizes") or [lc["kernel_size"]] * n
+        gm = lc.get("gating_mode")
+        if gm is None:
+            gm = ["gated" if lc.get("gated") else "none"] * n
+        elif isinstance(gm, str):
+            gm = [gm] * n
+        macs += lc["input_size"] * C
+        l1 = lc.get("layer1x1", {"active": True, "groups": 1})
+        h1 = lc.get("head1x1", {"active": False})
+        for l in range(n):
+            zc = 2 * B if gm[l] != "none" else B
+            macs += ks[l] * C * zc // lc.get("groups_input", 1)
+            macs += cs * zc // lc.get("groups_input_mixin", 1)
+            if l1.get("active", True):
+                macs += B * C // l1.get("groups", 1)
+            if h1.get("active"):
+                macs += B * h1["out_channels"] // h1.get("groups", 1)
+            dims = {"conv_pre_film": C, "conv_post_film": zc, "input_mixin_pre_film": cs, "input_mixin_post_film": zc,
+                    "activation_pre_film": zc, "activation_post_film": B, "layer1x1_post_film": C,
+                    "head1x1_post_film": h1.get("out_channels", 0)}
+            for key, d in dims.items():
+                f = lc.get(key)
+                if f and f.get("active", True):
+                    macs += cs * (2 if f.get("shift", True) else 1) * d // f.get("groups", 1)
+        head_in = h1["out_channels"] if h1.get("active") else B
+        if lc.get("head"):
+            macs += head_in * lc["head"]["out_channels"] * lc["head"]["kernel_size"]
+        else:
+            macs += head_in * lc["head_size"]
+    return macs
+
+
+def model_macs(path: str) -> int:
+    with open(path) as f:
+        j = json.load(f)
+    if j["architecture"] == "WaveNet":
+        return wavenet_macs_per_sample(j["config"])
+    c = j["config"]
+    H, I, L = c["hidden_size"], c["input_size"], c["num_layers"]
+    return sum(4 * H * ((I if l == 0 else H) + H) for l in range(L)) + H * c.get("out_channels", 1)
+
+
+def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: float = 12.0):
+    """CPU oracle ("port": our Eigen-free restatement of the reference path; the reference's own
+    Eigen binary cannot be built here) on ONE host core, benchmodel protocol (64-frame blocks,
+    Reset + prewarm first), on a bounded sample of the same workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nam_oracle
+    from signals import two_tone
+    fast_so = os.path.join("/tmp", f"libnam_oracle_fast_{os.getpid()}.so")
+    kind_flags = "-Ofast -march=native"
+    try:
+        nam_oracle.build_fast(fast_so)
+        nam_oracle.use_library(fast_so)
+    except Exception:
+        kind_flags = "-O3 -march=x86-64-v3 -ffp-contract=off"
+    m = nam_oracle.get_dsp(model_path, fast_tanh=fast_tanh)
+    m.Reset(SR, block)
+    probe = two_tone(int(SR))  # 1 s
+    t0 = time.perf_counter()
+    m.process_stream(probe, block)
+    dt = time.perf_counter() - t0
+    secs_audio = max(2.0, min(120.0, target_seconds / max(dt, 1e-6)))
+    x = two_tone(int(secs_audio * SR))
+    t0 = time.perf_counter()
+    m.process_stream(x, block)
+    dt = time.perf_counter() - t0
+    try:
+        os.remove(fast_so)
+    except OSError:
+        pass
+    return {
+        "value": round(len(x) / SR / dt, 3), "unit": "xRT (48 kHz real-time streams)", "cores": 1, "kind": "port",
+        "sample": f"1 stream x {secs_audio:.1f} s of two-tone audio in {block}-frame blocks after Reset+prewarm, "
+                  f"oracle/nam_oracle.c built {kind_flags}, {dt:.2f} s of CPU",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--streams", type=int, default=256, help="streams per GPU (weak scaling)")
+    ap.add_argument("--block", type=int, default=64)
+    ap.add_argument("--model", default="wavenet_a1_standard")
+    ap.add_argument("--fast-tanh", type=int, default=1, help="benchmodel default: fast tanh ON (tools/benchmodel.cpp:27)")
+    ap.add_argument("--launch", choices=["block", "resident"], default="block")
+    ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=1, help="verify stream 0 of rank 0 against the oracle after timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import neuralampmodelercore_amd as nam
+    from signals import stream_bank
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not distributed and args.gpus != 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    model_path = os.path.join(ROOT, "tests", "golden", "models", args.model + ".nam")
+    model = nam.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
+    ic, oc = model.NumInputChannels(), model.NumOutputChannels()
+    n_streams, block, K, W = args.streams, args.block, args.steps, args.warmup
+    total_steps = K + W
+    T = total_steps * block
+
+    # ---- synthetic input bank: generated on rank 0, scattered to the ranks over RCCL ----
+    if rank == 0:
+        bank = stream_bank(n_streams * world, T, seed=0)  # [world*n_streams, T]
+        bank_t = torch.from_numpy(bank).to(dev).view(world, n_streams, ic, T)
+    x = torch.empty((n_streams, ic, T), dtype=torch.float32, device=dev)
+    if distributed:
+        dist.scatter(x, scatter_list=[bank_t[r].contiguous() for r in range(world)] if rank == 0 else None, src=0)
+    else:
+        x.copy_(bank_t[0])
+    y = torch.zeros((n_streams, oc, T), dtype=torch.float32, device=dev)
+
+    batch = model.batch(n_streams, block, device=local_rank)
+    if args.kernel != "auto":
+        batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[args.kernel])
+    batch.Reset(prewarm=True)
+    # a dedicated (non-null) HIP stream: the kernels are launched on it through the C ABI and the
+    # HIP events that time them are recorded on the same stream
+    stream = torch.cuda.Stream(dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    sh = stream.cuda_stream
+    assert sh != 0
+    xp, yp = x.data_ptr(), y.data_ptr()
+
+    def run_steps(first, count):
+        if args.launch == "block":
+            for s in range(first, first + count):
+                off = s * block * 4
+                batch.process_device(xp + off, yp + off, block, T, sh)
+        else:
+            off = first * block * 4
+            batch.process_device(xp + off, yp + off, count * block, T, sh)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    run_steps(0, W)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run_steps(W, K)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+
+    tmax = torch.tensor([wall, gpu_ms / 1e3], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_max, gpu_s_max = float(tmax[0]), float(tmax[1])
+
+    # gather a per-rank checksum of the produced audio (RCCL gather of stream batches' digests)
+    digest = y.double().abs().sum().reshape(1)
+    if distributed:
+        digests = [torch.zeros_like(digest) for _ in range(world)] if rank == 0 else None
+        dist.gather(digest, gather_list=digests, dst=0)
+    finite = bool(torch.isfinite(y).all())
+
+    parity = None
+    if rank == 0 and args.check:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import nam_oracle
+        n_chk = min(T, 64 * 40)
+        ref = nam_oracle.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
+        ref.Reset(SR, block)
+        r = ref.process_stream(bank[0, :n_chk], block)[0]
+        got = y[0, 0, :n_chk].cpu().numpy()
+        parity = float(np.max(np.abs(r - got)))
+
+    if rank == 0:
+        macs = model_macs(model_path)
+        flops_per_sample = 2 * macs
+        samples_per_step_gpu = n_streams * block
+        total_samples = samples_per_step_gpu * K * world
+        xrt = total_samples / SR / wall_max
+        launches = K if args.launch == "block" else 1
+        avg_launch_s = gpu_s_max / launches
+        flops_per_launch = flops_per_sample * samples_per_step_gpu * (1 if args.launch == "block" else K)
+        achieved = flops_per_launch / avg_launch_s / 1e12
+        out = {
+            "metric": "real-time audio streams (xRT) at 48 kHz, wavenet_a1_standard" if args.model == "wavenet_a1_standard"
+            else f"real-time audio streams (xRT) at 48 kHz, {args.model}",
+            "value": round(xrt, 1),
+            "unit": "xRT (48 kHz real-time streams sustained)",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(wall_max * 1e3 / K, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.model}.nam, {n_streams} concurrent streams per GPU, buffer={block} samples, "
+                            f"fast_tanh={'on' if args.fast_tanh else 'off'} (BASELINE.json configs[1])",
+                "streams_per_gpu": n_streams, "block": block, "launch": args.launch,
+                "kernel": {1: "generic", 2: "a1_valu", 3: "a1_mfma"}.get(batch.get_kernel(), "?"),
+                "sharding": f"streams x{world} (no data-path collective)",
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "note": f"algorithmic {flops_per_sample} FLOP/stream-sample x {samples_per_step_gpu} stream-samples per "
+                        f"launch-step; avg launch {avg_launch_s * 1e6:.2f} us from HIP events on the launch stream; "
+                        "peak = fp32 vector == fp32-input MFMA peak (the kernel uses VALU FMA with SGPR weights)",
+            },
+            "gpu_ms_total": round(gpu_s_max * 1e3, 3),
+            "finite": finite,
+            "max_abs_err_vs_oracle": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_path, bool(args.fast_tanh), block)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

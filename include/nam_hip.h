@@ -51,7 +51,8 @@ extern "C" {
 /* kernel selection for nam_hip_batch_set_kernel */
 #define NAM_HIP_KERNEL_AUTO 0
 #define NAM_HIP_KERNEL_GENERIC 1 /* op-program interpreter (every WaveNet feature) */
-#define NAM_HIP_KERNEL_A1 2 /* register-resident kernel for the plain A1 family */
+#define NAM_HIP_KERNEL_A1 2 /* register-resident VALU kernel for the plain A1 family (1 wave per stream) */
+#define NAM_HIP_KERNEL_A1_MFMA 3 /* fp32-MFMA kernel for the A1 family (4 waves per stream-block) */
 
 typedef struct nam_hip_model nam_hip_model;
 typedef struct nam_hip_batch nam_hip_batch;
@@ -73,7 +74,7 @@ typedef struct nam_hip_model_info
   double output_level; /* DSP::GetOutputLevel dsp.h:133 */
   int64_t num_weights;
   int32_t fast_tanh; /* load-time switch replacing the global Activation::enable_fast_tanh (activations.cpp:168) */
-  int32_t has_a1_kernel; /* the specialised kernel can run this model */
+  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: the A1 MFMA kernel can */
   int64_t state_bytes_per_stream; /* HBM history per stream */
   char version[32]; /* .nam "version" */
 } nam_hip_model_info;
@@ -137,10 +138,15 @@ NAM_HIP_API int nam_hip_batch_process_device(nam_hip_batch* batch, const float* 
 /* Wait for everything enqueued on the batch's own stream. */
 NAM_HIP_API int nam_hip_batch_synchronize(nam_hip_batch* batch);
 
-/* Choose the kernel (NAM_HIP_KERNEL_*); AUTO picks the A1 kernel when the model allows it. */
+/* Choose the kernel (NAM_HIP_KERNEL_*); AUTO picks the fastest kernel the model allows
+ * (A1_MFMA > A1 > GENERIC). */
 NAM_HIP_API int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel);
 NAM_HIP_API int nam_hip_batch_get_kernel(const nam_hip_batch* batch);
 NAM_HIP_API int nam_hip_batch_n_streams(const nam_hip_batch* batch);
+
+/* Developer tool, not part of the drop-in surface: runs n_frames of silence with the MFMA kernel's
+ * per-job phase timestamps enabled; out_stamps receives 96 x 8 int64 shader-clock stamps. */
+NAM_HIP_API int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* out_stamps);
 
 /* Library identification: "nam_hip <version> gfx950". */
 NAM_HIP_API const char* nam_hip_version(void);

@@ -18,12 +18,12 @@ import numpy as np
 
 __all__ = [
     "NamHipError", "NamFileValidationError", "Model", "Batch", "get_dsp", "get_dsp_json", "lib_path", "load_library",
-    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_A1", "ABI_SYMBOLS",
+    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_A1", "KERNEL_A1_MFMA", "ABI_SYMBOLS",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_A1 = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_A1, KERNEL_A1_MFMA = 0, 1, 2, 3
 
 ERR_INVALID_ARGUMENT, ERR_FILE, ERR_MODEL, ERR_UNSUPPORTED, ERR_DEVICE, ERR_TOO_MANY_FRAMES = -1, -2, -3, -4, -5, -6
 
@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
     "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_synchronize",
     "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams",
+    "nam_hip_batch_debug_timeline",
 ]
 
 
@@ -67,6 +68,28 @@ def lib_path() -> str:
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process. The PyTorch-ROCm wheel ships its own libamdhip64.so /
+    libhsa-runtime64.so (same SONAME as /opt/rocm's). If libnam_hip.so pulled in /opt/rocm's copy
+    first and torch then loaded its own, the second HSA runtime would find no GPU. So when torch is
+    installed, make ITS runtime the resident one before libnam_hip.so is dlopen'ed; our DT_NEEDED
+    libamdhip64.so.7 then binds to it. Stand-alone C/C++ callers simply get /opt/rocm's runtime.
+    Set NAM_HIP_SYSTEM_RUNTIME=1 to skip this."""
+    import sys
+    if os.environ.get("NAM_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """Load libnam_hip.so. Raises (loudly) if the HIP extension has not been built."""
     global _lib
@@ -78,6 +101,7 @@ def load_library():
             f"neuralampmodelercore_amd: {path} is missing — build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C neuralampmodelercore_amd/csrc`. "
             "There is no CPU fallback.")
+    _share_torch_hip_runtime()
     L = ctypes.CDLL(path)
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     L.nam_hip_last_error.restype = ctypes.c_char_p
@@ -100,6 +124,7 @@ def load_library():
     L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
     L.nam_hip_batch_get_kernel.argtypes = [vp]
     L.nam_hip_batch_n_streams.argtypes = [vp]
+    L.nam_hip_batch_debug_timeline.argtypes = [vp, ci, vp]
     _lib = L
     return L
 
@@ -228,6 +253,12 @@ class Batch:
 
     def synchronize(self):
         _check(self._L.nam_hip_batch_synchronize(self._h))
+
+    def debug_timeline(self, n_frames: int) -> np.ndarray:
+        """Developer tool: [96, 8] shader-clock stamps of workgroup 0's first 96 jobs (MFMA kernel)."""
+        out = np.zeros((96, 8), dtype=np.int64)
+        _check(self._L.nam_hip_batch_debug_timeline(self._h, int(n_frames), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def process(self, x: np.ndarray) -> np.ndarray:
         """x: host array [n_streams, in_channels, n_frames] (or [n_streams, n_frames] for mono),

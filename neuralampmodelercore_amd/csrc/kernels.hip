@@ -162,7 +162,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
           idx += R;
         for (int ci = 0; ci < cin; ci++)
         {
-          const float x = ring[(size_t)ci * R + idx];
+          const float x = ring[(size_t)idx * cin + ci];
 #pragma unroll
           for (int j = 0; j < CB; j++)
             acc[j] = fmaf(wk[(size_t)ci * cpad + j], x, acc[j]);
@@ -181,7 +181,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
         for (int ci = 0; ci < cin; ci++)
         {
           const float xl = src[ci * kBlock + lidx];
-          const float xr = ring[(size_t)ci * R + idx];
+          const float xr = ring[(size_t)idx * cin + ci];
           const float x = in_block ? xl : xr;
 #pragma unroll
           for (int j = 0; j < CB; j++)
@@ -208,7 +208,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
       widx -= R;
     if (lane < nvalid)
       for (int ci = 0; ci < cin; ci++)
-        ring[(size_t)ci * R + widx] = src[ci * kBlock + lane];
+        ring[(size_t)widx * cin + ci] = src[ci * kBlock + lane];
     int nwp = wp + nvalid;
     if (nwp >= R)
       nwp -= R;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
       {
 #pragma unroll
         for (int c = 0; c < C; c++)
-          ring[(size_t)c * R + widx] = x[c];
+          ring[(size_t)widx * C + c] = x[c];
       }
     }
     __syncthreads();
@@ -442,7 +442,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
           idx += R;
 #pragma unroll
         for (int c = 0; c < C; c++)
-          xt[c] = ring[(size_t)c * R + idx];
+          xt[c] = ring[(size_t)idx * C + c];
       }
       else
       {
@@ -458,7 +458,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
         for (int c = 0; c < C; c++)
         {
           const float xl = win[c * kBlock + lidx];
-          const float xr = ring[(size_t)c * R + idx];
+          const float xr = ring[(size_t)idx * C + c];
           xt[c] = in_block ? xl : xr;
         }
       }
@@ -571,6 +571,437 @@ __global__ __launch_bounds__(64) void nam_a1_kernel(const A1Plan* __restrict__ P
       wpos_tbl[lane] = v;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1-family MFMA kernel: one workgroup (4 wavefronts) per stream, 64-frame blocks, job pipeline
+// ------------------------------------------------------------------------------------------------
+// Every matrix product of the model is (C x Kdim) * (Kdim x 64 frames); wave w owns frames
+// [16w, 16w+16) and issues v_mfma_f32_16x16x4_f32 (exact fp32: bitwise an ordered fmaf chain).
+// Lane l = (g = l >> 4, j = l & 15) of wave w:
+//   D (4 VGPR)  out channels 4g + r, r = 0..3, of frame 16w + j          (residual x, head, z live here)
+//   B operand   k-step s feeds row k = g with channel 4g + s of frame 16w + j — THE LANE'S OWN D VALUES,
+//               so the current tap, the 1x1, the rechannel and the head need no data movement at all
+//   A operand   tile value W[out = j][in = 4g + s] (plan.h: tiles are packed for exactly this mapping)
+// Only the time-shifted taps leave the registers: each lane fetches its 4 channels of frame
+// (16w + j - L) with ONE 16-byte LDS read from a frame-major window (lookback L <= 64:
+// [previous 64 | current 64] frames) or tap buffer (L > 64), both filled from the stream's
+// frame-major history ring in HBM with 16-byte accesses.
+//
+// The model is flattened into a job table (plan.h MJob: rechannel / layer / head). This path is
+// bound by the latency and bandwidth of the history reads (3,840 B per stream-sample stream through
+// HBM / Infinity Cache; they cannot live in LDS), so every global load a job needs — its quarter of
+// the 4 KB weight tile area and three 64-frame history sets — is issued kPrefetch jobs ahead into
+// a rotating set of VGPR slots and dropped into LDS one job early; raw s_barrier (no vmcnt drain)
+// keeps the loads in flight across jobs and the compiler's counted s_waitcnt vmcnt(N) retires
+// exactly the oldest slot.
+namespace mf
+{
+constexpr int kOldTaps = 2; // K == 3
+constexpr int kPrefetch = 4; // jobs in flight
+constexpr int SCMAX = 20; // window row pitch for C = 16 (floats): C + 4 keeps 16-B alignment, spreads banks
+constexpr int XW_FLOATS = 2 * kBlock * SCMAX; // [frame -64..63][C + 4]
+constexpr int TB_FLOATS = kBlock * SCMAX; // [frame 0..63][C + 4]
+constexpr int TL_PITCH = 20; // tile area row pitch (floats): lane-major [64][16 + 4]
+constexpr int TL_FLOATS = 64 * TL_PITCH;
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+struct Slot // one job's worth of prefetched data, per lane
+{
+  f4 tile; // this lane's 16 bytes of the job's 4 KB tile area
+  f4 h[1 + kOldTaps]; // history: [0] = previous 64 frames (window), [1 + k] = tap k
+  float inp; // RECH1 jobs (first job of a block): this lane's input sample of that block
+};
+
+__device__ __forceinline__ float rcp(float x)
+{
+  return __builtin_amdgcn_rcpf(x);
+}
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units (abs error ~1e-7)
+__device__ __forceinline__ float tanh_hw(float x)
+{
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f); // exp(2x) = 2^(2x*log2(e))
+  return 1.0f - 2.0f * rcp(e + 1.0f);
+}
+__device__ __forceinline__ float fast_tanh_hw(const float x)
+{
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  const float num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+  const float den = 2.44506634652299f + (2.44506634652299f + x2) * fabsf(x + 0.814642734961073f * x * ax);
+  return num * rcp(den);
+}
+__device__ __forceinline__ float sigmoid_hw(float x)
+{
+  return rcp(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float act_hw(int type, float x, float p0)
+{
+  switch (type)
+  {
+    case ACT_TANH: return tanh_hw(x);
+    case ACT_FASTTANH: return fast_tanh_hw(x);
+    case ACT_HARDTANH: return fminf(fmaxf(x, -1.0f), 1.0f);
+    case ACT_RELU: return x > 0.0f ? x : 0.0f;
+    case ACT_LEAKYRELU: return x > 0.0f ? x : p0 * x;
+    case ACT_SIGMOID: return sigmoid_hw(x);
+    case ACT_SILU: return x * sigmoid_hw(x);
+    case ACT_HARDSWISH:
+    {
+      const float t = fminf(fmaxf(x + 3.0f, 0.0f), 6.0f);
+      return x * t * (1.0f / 6.0f);
+    }
+    case ACT_SOFTSIGN: return x * rcp(1.0f + fabsf(x));
+    default: return x;
+  }
+}
+// whole-vector activation: ONE wave-uniform dispatch per job (a per-element switch costs a branch
+// cascade per element), most likely types first
+template <int TYPE>
+__device__ __forceinline__ f4 act4_t(const f4& v, float p0)
+{
+  f4 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+  {
+    if constexpr (TYPE == ACT_FASTTANH)
+      r[i] = fast_tanh_hw(v[i]);
+    else if constexpr (TYPE == ACT_TANH)
+      r[i] = tanh_hw(v[i]);
+    else
+      r[i] = act_hw(TYPE, v[i], p0);
+  }
+  return r;
+}
+__device__ __forceinline__ f4 act4(int type, const f4& v, float p0)
+{
+  if (type == ACT_FASTTANH)
+    return act4_t<ACT_FASTTANH>(v, p0);
+  if (type == ACT_TANH)
+    return act4_t<ACT_TANH>(v, p0);
+  if (type == ACT_RELU)
+    return act4_t<ACT_RELU>(v, p0);
+  if (type == ACT_LEAKYRELU)
+    return act4_t<ACT_LEAKYRELU>(v, p0);
+  if (type == ACT_SIGMOID)
+    return act4_t<ACT_SIGMOID>(v, p0);
+  if (type == ACT_SILU)
+    return act4_t<ACT_SILU>(v, p0);
+  if (type == ACT_HARDTANH)
+    return act4_t<ACT_HARDTANH>(v, p0);
+  if (type == ACT_HARDSWISH)
+    return act4_t<ACT_HARDSWISH>(v, p0);
+  if (type == ACT_SOFTSIGN)
+    return act4_t<ACT_SOFTSIGN>(v, p0);
+  return v;
+}
+// workgroup barrier that orders LDS traffic only: outstanding global loads stay in flight
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ f4 mfma4(const f4& a, const f4& b, f4 acc)
+{
+  // four k-steps: step s multiplies tile value a[s] with the lane's channel-s value b[s]
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+  return acc;
+}
+} // namespace mf
+
+__global__ __launch_bounds__(256) void nam_a1_mfma_kernel(const A1Plan* __restrict__ P,
+                                                          const float* __restrict__ blob, const A1Args a)
+{
+  using namespace mf;
+  // one LDS array (a single __shared__ object keeps every access a plain ds_* instruction):
+  //   window  [2][128][SC]     [buf][frame -64..63][channel]: previous 64 | current 64 frames of a layer input
+  //   taps    [2][2][64][SC]   [buf][tap][frame 0..63][channel]: far taps (lookback > 64)
+  //   tiles   [2][64][20]      the running / the next job's tile area, lane-major
+  //   consts  [jobs][48]
+  constexpr int XW_OFF = 0, TB_OFF = XW_OFF + 2 * XW_FLOATS, TL_OFF = TB_OFF + 2 * kOldTaps * TB_FLOATS,
+                CONSTS_OFF = TL_OFF + 2 * TL_FLOATS, LDS_FLOATS = CONSTS_OFF + kMJobMax * 48;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  auto xw_off = [](int buf) { return XW_OFF + buf * XW_FLOATS; };
+  auto tb_off = [](int buf, int tap) { return TB_OFF + (buf * kOldTaps + tap) * TB_FLOATS; };
+  auto tl_off = [](int tb) { return TL_OFF + tb * TL_FLOATS; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = uni(tid >> 6); // wave id = 16-frame tile
+  const int g = lane >> 4; // channel quad: this lane owns channels 4g..4g+3
+  const int j = lane & 15;
+  const int frame = 16 * w + j; // this lane's frame inside the 64-frame block
+  const int hfr = 16 * w + (lane >> 2); // history mover: frame inside a 64-frame set
+  const int hch = lane & 3; // history mover: channel quad
+  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  float* st = a.state + (size_t)stream * a.state_stride;
+  const char* stb = reinterpret_cast<const char*>(st);
+  int* wpos_tbl = reinterpret_cast<int*>(st);
+  const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
+  float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
+  const int n_rings = P->n_rings;
+  const int NJ = P->n_mjobs;
+  const float head_scale = blob[P->head_scale_off];
+  const float act_p0 = a.act_p0;
+  const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
+  const int total = n_blocks * NJ;
+
+  int wposv = lane < n_rings ? wpos_tbl[lane] : 0; // every wave keeps its own copy of all ring positions
+  const int ring_len_v = lane < n_rings ? P->ring_len_by_id[lane] : 1;
+  for (int i = tid; i < NJ * 48; i += 256)
+    lds[CONSTS_OFF + i] = blob[P->mconsts_off + i];
+  const unsigned tile_lane_off = (unsigned)tid * 16u; // this thread's 16 B of a job's 4 KB tile area
+  const int tile_stash_off = (tid >> 2) * TL_PITCH + (tid & 3) * 4; // same 16 B inside the padded LDS copy
+
+  // ---- prefetch: issue the 5 global loads of job J (of block jblk) into slot s. Every load is
+  // unconditional (selects act on the ADDRESS) so the compiler's vmcnt bookkeeping stays exact; all
+  // addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset. ----
+  auto fetch = [&](Slot& s, const MJob& J, bool next_block, int jblk) {
+    s.tile = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(blob + J.tiles) + tile_lane_off);
+    const int rid = J.ring_id;
+    const bool has = J.type == MJ_LAYER && rid >= 0;
+    const int R = has ? J.R : 64;
+    const int d = J.d, CS = J.CS;
+    int wp = has ? __builtin_amdgcn_readlane(wposv, rid) : 0;
+    if (next_block)
+    {
+      wp += kBlock;
+      if (wp >= R)
+        wp -= R;
+    }
+    // one base (the stream's state) + a selected 32-bit byte offset: jobs without a ring read a
+    // harmless dummy (the first 256 B of the state)
+    const unsigned rbase = has ? (unsigned)J.ring_off * 4u : 0u;
+    const unsigned cmul = has ? (unsigned)J.C * 4u : 0u; // bytes per ring frame
+    const unsigned cq = has ? (unsigned)(hch < CS ? hch : CS - 1) * 16u : (unsigned)(lane & 15) * 16u;
+#pragma unroll
+    for (int t = 0; t <= kOldTaps; t++)
+    {
+      const int L = (t == 0) ? kBlock : (3 - t) * d; // window, then tap k = t-1 -> (K-1-k)*d with K = 3
+      int idx = wp + hfr - L;
+      if (idx < 0)
+        idx += R;
+      const unsigned off = rbase + __umul24((unsigned)idx, cmul) + cq;
+      s.h[t] = *reinterpret_cast<const f4*>(stb + off);
+    }
+    int fi = jblk * kBlock + frame;
+    if (fi >= a.n_frames)
+      fi = a.n_frames - 1;
+    const bool use_in = in && J.type == MJ_RECH1;
+    const char* ibase = use_in ? reinterpret_cast<const char*>(in) : stb;
+    s.inp = *reinterpret_cast<const float*>(ibase + (use_in ? (unsigned)fi * 4u : 0u));
+  };
+  // ---- drop a slot into LDS for the job that will read buffer `buf` / tile buffer `tb`: 4 x 16-byte writes ----
+  auto stash = [&](const Slot& s, int C, int CS, int buf, int tb) {
+    *reinterpret_cast<f4*>(&lds[tl_off(tb) + tile_stash_off]) = s.tile;
+    if (hch < CS)
+    {
+      const int SC = C + 4;
+      *reinterpret_cast<f4*>(&lds[xw_off(buf) + hfr * SC + 4 * hch]) = s.h[0];
+#pragma unroll
+      for (int t = 0; t < kOldTaps; t++)
+        *reinterpret_cast<f4*>(&lds[tb_off(buf, t) + hfr * SC + 4 * hch]) = s.h[1 + t];
+    }
+  };
+
+  Slot slot[kPrefetch];
+#pragma unroll
+  for (int u = 0; u < kPrefetch; u++)
+  {
+    const MJob J = P->mjobs[u < total ? u % NJ : 0];
+    fetch(slot[u], J, u >= NJ, u / NJ);
+  }
+
+  // running state
+  f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f}, hprev = {0.f, 0.f, 0.f, 0.f};
+  int ji = 0, blk = 0, tb = 0;
+  int jf = kPrefetch % NJ; // job index of the next fetch
+  int fblk = kPrefetch / NJ; // its block
+  int nvalid = min(kBlock, a.n_frames);
+  // job descriptors are fetched (scalar loads) ahead of their use: Jcur runs now, Jnext is stashed now
+  MJob Jcur = P->mjobs[0];
+  MJob Jnext = P->mjobs[1 % NJ];
+  MJob Jfnext = P->mjobs[jf];
+  float cond = (in && frame < nvalid) ? slot[0].inp : 0.0f; // job 0 is always a RECH1
+  // job 0's data goes to LDS now; afterwards every job stashes its SUCCESSOR while it computes
+  stash(slot[0], Jcur.C, Jcur.CS, Jcur.buf, 0);
+  {
+    const bool valid = fblk < n_blocks;
+    fetch(slot[0], Jfnext, valid && fblk > 0, fblk);
+    if (++jf == NJ)
+    {
+      jf = 0;
+      fblk++;
+    }
+    Jfnext = P->mjobs[jf];
+  }
+  __syncthreads(); // CONSTS + job 0 visible
+
+  // Software pipeline, one barrier per job. In job i (slot index u = i % kPrefetch):
+  //   barrier                      -> job i's LDS data (stashed during job i-1) and x published by job i-1 are visible
+  //   issue job i's LDS operand reads (tile values, shifted taps, constants)
+  //   stash job i+1 (slot u+1) into the OTHER halves of the double buffers, refill that slot with job i+1+kPrefetch
+  //   MFMA chain, activation, 1x1, publish x
+  for (int q0 = 0; q0 < total; q0 += kPrefetch)
+  {
+#pragma unroll
+    for (int u = 0; u < kPrefetch; u++)
+    {
+      // NOTE: no branch around a whole job: past the end it degenerates to type -1 (barrier, stash and
+      // dummy prefetch only), which keeps the number of loads in flight statically known.
+      const bool active = q0 + u < total;
+      const MJob J = Jcur;
+      const MJob Jn = Jnext;
+      Jcur = Jnext;
+      {
+        int jn2 = ji + 2;
+        if (jn2 >= NJ)
+          jn2 -= NJ;
+        Jnext = P->mjobs[jn2];
+      }
+      const int type = active ? J.type : -1, C = J.C, CS = J.CS, buf = J.buf;
+      const int SC = C + 4;
+      const bool own = g < CS;
+      const int un = (u + 1) % kPrefetch; // constant after unrolling: slot[] stays in registers
+      long long* dbg = (a.dbg && blockIdx.x == 0 && tid == 0 && q0 + u < 96) ? a.dbg + (q0 + u) * 8 : nullptr;
+      if (dbg)
+        dbg[0] = __builtin_readcyclecounter();
+      lds_barrier();
+      if (dbg)
+        dbg[1] = __builtin_readcyclecounter();
+
+      const int d = J.d, R = J.R, rid = J.ring_id, act = J.act;
+      // 1. operand reads of this job first (their latency starts now): 4 + 2 + 3 sixteen-byte LDS reads.
+      //    Straight-line for every job type (non-LAYER jobs have d = 0 and read valid, unused words) so
+      //    that the prefetch below is never inside a branch.
+      // lanes whose channel quad does not exist (g >= C/4) read quad 0: finite data that only ever meets zero weights
+      const int gq = own ? g : 0;
+      const float* __restrict__ tl = &lds[tl_off(tb) + lane * TL_PITCH];
+      const f4 a0 = *reinterpret_cast<const f4*>(tl), a1 = *reinterpret_cast<const f4*>(tl + 4),
+               a2 = *reinterpret_cast<const f4*>(tl + 8), a3 = *reinterpret_cast<const f4*>(tl + 12);
+      f4 bt[kOldTaps];
+#pragma unroll
+      for (int k = 0; k < kOldTaps; k++)
+      {
+        const int L = (2 - k) * d;
+        const int o = (L <= kBlock) ? xw_off(buf) + (kBlock + frame - L) * SC : tb_off(buf, k) + frame * SC;
+        bt[k] = *reinterpret_cast<const f4*>(&lds[o + 4 * gq]);
+      }
+      const float* __restrict__ cst = &lds[CONSTS_OFF + J.consts + 4 * g];
+      const f4 bv4 = *reinterpret_cast<const f4*>(cst);
+      const f4 mv = *reinterpret_cast<const f4*>(cst + 16);
+      const f4 b1v = *reinterpret_cast<const f4*>(cst + 32);
+      if (dbg)
+      {
+        asm volatile("" ::"v"(bv4), "v"(mv), "v"(b1v), "v"(a3), "v"(bt[0]), "v"(bt[1]));
+        dbg[6] = __builtin_readcyclecounter();
+      }
+      // 2. LAYER: append this layer's INPUT to its history ring (frame-major: 16 B per lane)
+      if (type == MJ_LAYER && rid >= 0 && own && frame < nvalid)
+      {
+        int widx = __builtin_amdgcn_readlane(wposv, rid) + frame;
+        if (widx >= R)
+          widx -= R;
+        *reinterpret_cast<f4*>(reinterpret_cast<char*>(st) + (size_t)J.ring_off * 4
+                               + (__umul24((unsigned)widx, (unsigned)C * 4u) + (unsigned)g * 16u)) = x;
+      }
+      // 3. successor: stash slot u+1 into the other halves of the double buffers and refill it with
+      //    the job kPrefetch ahead (LDS writes / VMEM issue overlap the MFMA chain below)
+      const float inp_next = slot[un].inp;
+      stash(slot[un], Jn.C, Jn.CS, Jn.buf, tb ^ 1);
+      if (dbg)
+        dbg[7] = __builtin_readcyclecounter();
+      {
+        const bool valid = fblk < n_blocks;
+        fetch(slot[un], Jfnext, valid && (fblk > blk), fblk);
+        if (++jf == NJ)
+        {
+          jf = 0;
+          fblk++;
+        }
+        Jfnext = P->mjobs[jf];
+      }
+      if (dbg)
+        dbg[2] = __builtin_readcyclecounter();
+
+      // 4. dilated conv, 3 taps x 4 k-steps; tap 2 (the current frame) multiplies the lane's own x.
+      //    Two accumulators shorten the dependent chain. Issued for EVERY job type (non-LAYER jobs just
+      //    discard the result) so that the MFMAs share a basic block with the stash / prefetch code
+      //    above and the scheduler can interleave that VALU / LDS / VMEM work into the MFMA shadow.
+      f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      acc0 = mfma4(a0, bt[0], acc0);
+      acc1 = mfma4(a1, bt[1], acc1);
+      acc0 = mfma4(a2, x, acc0);
+      const f4 acc = acc0 + acc1;
+      if (type == MJ_LAYER)
+      {
+        if (dbg)
+        {
+          asm volatile("" ::"v"(acc));
+          dbg[3] = __builtin_readcyclecounter();
+        }
+        // 5. bias + input mixin + activation; head accumulate
+        f4 pre;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          pre[r] = fmaf(mv[r], cond, acc[r] + bv4[r]);
+        const f4 z = act4(act, pre, act_p0);
+        head += z;
+        // 6. layer1x1: z is already this lane's B operand
+        const f4 y = mfma4(a3, z, f4{0.f, 0.f, 0.f, 0.f});
+        x = x + (y + b1v);
+        if (dbg)
+        {
+          asm volatile("" ::"v"(x));
+          dbg[4] = __builtin_readcyclecounter();
+        }
+        // 7. publish x (the next layer's input) into the other window buffer: one 16-byte write
+        if (own)
+          *reinterpret_cast<f4*>(&lds[xw_off(buf ^ 1) + (kBlock + frame) * SC + 4 * g]) = x;
+      }
+      else if (type == MJ_RECH1)
+      {
+        x = bv4 * cond; // consts[0..15] = rechannel column (in_size == 1)
+        head = f4{0.f, 0.f, 0.f, 0.f};
+        if (own)
+          *reinterpret_cast<f4*>(&lds[xw_off(buf) + (kBlock + frame) * SC + 4 * g]) = x;
+      }
+      else if (type == MJ_RECH)
+      {
+        // the previous array's last-layer output is still in x (this lane's own channels)
+        x = mfma4(a0, x, f4{0.f, 0.f, 0.f, 0.f});
+        head = J.first ? f4{0.f, 0.f, 0.f, 0.f} : hprev;
+        if (own)
+          *reinterpret_cast<f4*>(&lds[xw_off(buf ^ 1) + (kBlock + frame) * SC + 4 * g]) = x;
+      }
+      else if (type == MJ_HEAD) // hout[h] = bh[h] + sum_c Wh[h][c] * head[c]
+      {
+        hprev = mfma4(a0, head, f4{0.f, 0.f, 0.f, 0.f}) + bv4;
+        if (J.last && out && g == 0 && frame < nvalid)
+          out[(size_t)blk * kBlock + frame] = head_scale * hprev[0];
+      }
+      if (dbg)
+        dbg[5] = __builtin_readcyclecounter();
+
+      tb ^= 1;
+      if (active && ++ji == NJ)
+      {
+        // block finished: advance every ring's write position, take the next block's input sample
+        ji = 0;
+        wposv += nvalid;
+        if (wposv >= ring_len_v)
+          wposv -= ring_len_v;
+        blk++;
+        nvalid = min(kBlock, a.n_frames - blk * kBlock);
+        cond = (in && frame < nvalid) ? inp_next : 0.0f;
+      }
+    }
+  }
+  if (w == 0 && lane < n_rings)
+    wpos_tbl[lane] = wposv;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -716,6 +1147,12 @@ hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hip
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
 {
   hipLaunchKernelGGL(nam_a1_kernel, dim3(n_blocks), dim3(64), 0, stream, a.plan, a.blob, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  hipLaunchKernelGGL(nam_a1_mfma_kernel, dim3(n_blocks), dim3(256), 0, stream, a.plan, a.blob, a);
   return hipGetLastError();
 }
 

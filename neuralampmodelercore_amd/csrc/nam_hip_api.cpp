@@ -109,6 +109,7 @@ struct nam_hip_batch
   float* d_out = nullptr;
   float* h_stage = nullptr; // pinned, used by the f64 path
   int kernel = NAM_HIP_KERNEL_AUTO;
+  long long* dbg = nullptr; // device buffer for kernel phase timestamps (nam_hip_batch_debug_timeline)
   bool was_reset = false;
   bool reset_with_prewarm = true; // thread_local gPrewarmOnResetDefault = true (NAM/dsp.cpp:20)
 };
@@ -171,11 +172,18 @@ int refresh_map(nam_hip_batch* b, WidthGroup& g)
   return NAM_HIP_OK;
 }
 
-bool use_a1(const nam_hip_batch* b, const WidthGroup& g)
+// Which kernel a WaveNet group runs: explicit choice if possible, otherwise the fastest available.
+int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 {
-  if (!g.plan->a1.valid || !g.d_a1)
-    return false;
-  return b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1;
+  const bool a1 = g.plan->a1.valid && g.d_a1;
+  const bool mfma = a1 && g.plan->a1.mfma_ok;
+  switch (b->kernel)
+  {
+    case NAM_HIP_KERNEL_GENERIC: return NAM_HIP_KERNEL_GENERIC;
+    case NAM_HIP_KERNEL_A1: return a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
+    case NAM_HIP_KERNEL_A1_MFMA: return mfma ? NAM_HIP_KERNEL_A1_MFMA : (a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC);
+    default: return mfma ? NAM_HIP_KERNEL_A1_MFMA : (a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC);
+  }
 }
 
 // Launch one group's kernel over `n` streams given by `d_map` (nullptr = streams 0..n-1).
@@ -187,7 +195,8 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
   const Plan& p = *g.plan;
   if (p.arch == ARCH_WAVENET)
   {
-    if (use_a1(b, g))
+    const int kernel = pick_kernel(b, g);
+    if (kernel != NAM_HIP_KERNEL_GENERIC)
     {
       A1Args a;
       a.plan = g.d_a1;
@@ -200,10 +209,14 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.io_stride = io_stride;
       a.n_frames = n_frames;
       a.act_p0 = 0.01f;
+      a.dbg = b->dbg;
       for (const auto& arr : b->model->spec->wavenet.arrays)
         if (!arr.activations.empty() && arr.activations[0].type == ACT_LEAKYRELU)
           a.act_p0 = arr.activations[0].p[0];
-      NAM_HIP_CHECK(launch_a1(a, n, s));
+      if (kernel == NAM_HIP_KERNEL_A1_MFMA)
+        NAM_HIP_CHECK(launch_a1_mfma(a, n, s));
+      else
+        NAM_HIP_CHECK(launch_a1(a, n, s));
     }
     else
     {
@@ -393,7 +406,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
   info->output_level = s.output_level;
   info->num_weights = s.arch == ARCH_WAVENET ? (int64_t)s.wavenet.weights.size() : (int64_t)s.lstm.weights.size();
   info->fast_tanh = s.fast_tanh ? 1 : 0;
-  info->has_a1_kernel = p.a1.valid;
+  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && p.a1.mfma_ok) ? 2 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -640,12 +653,16 @@ int nam_hip_batch_synchronize(nam_hip_batch* batch)
 
 int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
-  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1)
+  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_MFMA)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
-  if (kernel == NAM_HIP_KERNEL_A1)
+  if (kernel == NAM_HIP_KERNEL_A1 || kernel == NAM_HIP_KERNEL_A1_MFMA)
     for (const auto& g : batch->groups)
+    {
       if (g.plan->arch != ARCH_WAVENET || !g.plan->a1.valid)
-        return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 kernel cannot run this model");
+        return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 kernels cannot run this model");
+      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !g.plan->a1.mfma_ok)
+        return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 MFMA kernel cannot run this model");
+    }
   batch->kernel = kernel;
   return NAM_HIP_OK;
 }
@@ -654,10 +671,36 @@ int nam_hip_batch_get_kernel(const nam_hip_batch* batch)
 {
   if (!batch)
     return NAM_HIP_ERR_INVALID_ARGUMENT;
-  if (batch->kernel != NAM_HIP_KERNEL_AUTO)
-    return batch->kernel;
   const WidthGroup& g = batch->groups[batch->model->full_width];
-  return (g.plan->arch == ARCH_WAVENET && g.plan->a1.valid) ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
+  if (g.plan->arch != ARCH_WAVENET)
+    return NAM_HIP_KERNEL_GENERIC;
+  return pick_kernel(batch, g);
+}
+
+// Developer tool (not part of the drop-in surface): run `n_frames` of silence through the batch with
+// the MFMA kernel's phase timestamps enabled and copy out 96 jobs x 8 cycle-counter stamps of
+// workgroup 0 / lane 0.
+int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* out_stamps)
+{
+  if (!batch || !out_stamps)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_debug_timeline: bad argument");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  const size_t bytes = 96 * 8 * sizeof(long long);
+  NAM_HIP_CHECK(hipMalloc(&batch->dbg, bytes));
+  NAM_HIP_CHECK(hipMemset(batch->dbg, 0, bytes));
+  int rc = NAM_HIP_OK;
+  for (auto& g : batch->groups)
+    if (!g.streams.empty() && rc == NAM_HIP_OK)
+      rc = launch_group(batch, g, g.d_map, (int)g.streams.size(), nullptr, nullptr, n_frames, 0, batch->stream);
+  hipError_t e = hipStreamSynchronize(batch->stream);
+  if (e == hipSuccess)
+    e = hipMemcpy(out_stamps, batch->dbg, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(batch->dbg);
+  batch->dbg = nullptr;
+  if (rc != NAM_HIP_OK)
+    return rc;
+  NAM_HIP_CHECK(e);
+  return NAM_HIP_OK;
 }
 
 int nam_hip_batch_n_streams(const nam_hip_batch* batch)

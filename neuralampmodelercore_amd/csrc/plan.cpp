@@ -496,6 +496,121 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
     return;
   }
   a1.valid = 1;
+
+  // ---- MFMA job table (v_mfma_f32_16x16x4_f32 A-operand tiles) ----
+  int n_jobs = 0;
+  bool mfma_ok = true;
+  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    if (A.channels % 4 != 0 || A.channels > 16 || A.kernel_sizes[0] != 3)
+      mfma_ok = false;
+    if (ai > 0 && (A.input_size % 4 != 0 || A.input_size > 16))
+      mfma_ok = false;
+    if (A.head_size > 16)
+      mfma_ok = false;
+    n_jobs += 2 + A.num_layers();
+  }
+  if (!mfma_ok || n_jobs > kMJobMax)
+    return;
+  while (plan.blob.size() % 64)
+    plan.blob.push_back(0.0f);
+  const size_t tiles_base = plan.blob.size();
+  plan.blob.resize(tiles_base + (size_t)n_jobs * 1024 + (size_t)n_jobs * 48 + 64, 0.0f);
+  a1.mconsts_off = (int)(tiles_base + (size_t)n_jobs * 1024);
+  a1.n_mjobs = n_jobs;
+  auto tile_at = [&](int job, int tile, int o, int in_idx) -> float& {
+    // A-operand element W[o][in_idx]: input channel c = 4g + s is fed by lane group g in k-step s, so it
+    // lives in lane (g, o) of tile `tile` (the caller passes tile = tile_base + s with s = in_idx % 4).
+    // The tile area is stored lane-major, [lane][16 tiles], so one lane's 16 operands are 64 contiguous bytes.
+    const int g = in_idx / 4;
+    return plan.blob[tiles_base + (size_t)job * 1024 + (size_t)(g * 16 + o) * 16 + tile];
+  };
+  auto const_at = [&](int job, int vec, int i) -> float& { return plan.blob[(size_t)a1.mconsts_off + (size_t)job * 48 + vec * 16 + i]; };
+  w = wn.weights.data();
+  int ji = 0;
+  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    const A1Array& arr = a1.arr[ai];
+    const int C = A.channels, K = A.kernel_sizes[0], H = A.head_size, CS = C / 4, IN = A.input_size;
+    auto base_job = [&](int type) -> MJob& {
+      MJob& J = a1.mjobs[ji];
+      std::memset(&J, 0, sizeof(J));
+      J.type = type;
+      J.C = C;
+      J.CS = CS;
+      J.K = K;
+      J.ring_id = -1;
+      J.tiles = (int)(tiles_base + (size_t)ji * 1024);
+      J.consts = ji * 48;
+      J.act = A.activations[0].type;
+      return J;
+    };
+    {
+      MJob& J = base_job(IN == 1 ? MJ_RECH1 : MJ_RECH);
+      J.steps = IN == 1 ? 0 : 4;
+      J.first = ai == 0 ? 1 : 0;
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < IN; ci++)
+        {
+          const float v = *(w++);
+          if (IN == 1)
+            const_at(ji, 0, co) = v;
+          else
+            tile_at(ji, ci % 4, co, ci) = v;
+        }
+      ji++;
+    }
+    for (int l = 0; l < A.num_layers(); l++)
+    {
+      MJob& J = base_job(MJ_LAYER);
+      J.d = A.dilations[l];
+      J.R = arr.ring_len[l];
+      J.ring_off = arr.ring_off[l];
+      J.ring_id = arr.ring_id[l];
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < C; ci++)
+          for (int k = 0; k < K; k++)
+            tile_at(ji, k * 4 + ci % 4, co, ci) = *(w++);
+      for (int co = 0; co < C; co++)
+        const_at(ji, 0, co) = *(w++);
+      for (int co = 0; co < C; co++)
+        const_at(ji, 1, co) = *(w++);
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < C; ci++)
+          tile_at(ji, 12 + ci % 4, co, ci) = *(w++);
+      for (int co = 0; co < C; co++)
+        const_at(ji, 2, co) = *(w++);
+      ji++;
+    }
+    {
+      MJob& J = base_job(MJ_HEAD);
+      J.steps = 4;
+      J.last = (ai + 1 == wn.arrays.size()) ? 1 : 0;
+      for (int h = 0; h < H; h++)
+        for (int c = 0; c < C; c++)
+          tile_at(ji, c % 4, h, c) = *(w++);
+      for (int h = 0; h < H; h++)
+        const_at(ji, 0, h) = A.head_bias ? *(w++) : 0.0f;
+      ji++;
+    }
+  }
+  // static double-buffer parity: RECH1 publishes into the buffer the next job reads; LAYER / RECH read
+  // `buf` and publish into `buf ^ 1`.
+  {
+    int b = 0;
+    for (int j = 0; j < n_jobs; j++)
+    {
+      a1.mjobs[j].buf = b;
+      if (a1.mjobs[j].type == MJ_LAYER || a1.mjobs[j].type == MJ_RECH)
+        b ^= 1;
+    }
+    // the sequence repeats every block: the first job of the next block must not publish into a buffer
+    // that a late wave could still be reading; every block ends with HEAD jobs (no window traffic), so
+    // any parity is safe there.
+  }
+  a1.mfma_ok = 1;
 }
 
 } // namespace
@@ -532,10 +647,15 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
     plan.state_floats = kBlock;
   build_a1(wn, plan);
   if (plan.a1.valid)
+  {
     for (int a = 0; a < plan.a1.n_arrays; a++)
       for (int l = 0; l < plan.a1.arr[a].n_layers; l++)
         if (plan.a1.arr[a].ring_id[l] >= 0)
           plan.a1.arr[a].ring_off[l] += table;
+    for (int j = 0; j < plan.a1.n_mjobs; j++)
+      if (plan.a1.mjobs[j].ring_id >= 0)
+        plan.a1.mjobs[j].ring_off += table;
+  }
   return plan;
 }
 

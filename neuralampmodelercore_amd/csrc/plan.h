@@ -8,8 +8,9 @@
 //               from the reference's flat weight stream (order: NAM/wavenet/model.cpp:152-181,
 //               563-569, 661-683; conv layouts NAM/conv1d.cpp:40-55, NAM/dsp.cpp:384-397).
 //   * state     per-stream persistent state layout in HBM: for every dilated conv a history ring
-//               `[cin][R]` (time contiguous => a tap read is 64 consecutive floats) plus its write
-//               position. This replaces nam::RingBuffer (NAM/ring_buffer.cpp:7-109).
+//               `[R][cin]` (frame-major: one frame's channels are contiguous, so a lane that owns a
+//               frame moves its channels with 16-byte accesses) plus its write position.
+//               This replaces nam::RingBuffer (NAM/ring_buffer.cpp:7-109).
 //   * `a1`      (optional) description for the specialised register-resident kernel used for the
 //               plain "A1" WaveNet family (ungated, no FiLM, groups=1): wavenet_a1_standard.nam.
 //   * `lstm`    (optional) description for the LSTM kernel (NAM/lstm.cpp:31-168).
@@ -88,14 +89,58 @@ struct A1Array
   int32_t ring_id[kA1MaxLayers];
 };
 
+// Job table of the MFMA kernel (nam_a1_mfma_kernel): the model flattened into a straight sequence
+// of jobs, each a handful of v_mfma_f32_16x16x4_f32 k-steps, so that weights and history can be
+// prefetched a fixed number of JOBS ahead regardless of array boundaries.
+//   tiles: 1024 floats per job, lane-major [lane 0..63][16 tiles]. Tile t is the A operand of one k-step:
+//          lane (g = lane >> 4, o = lane & 15) holds W[out = o][in = 4*g + s] where s = t & 3 is the k-step,
+//          i.e. lane group g always feeds ITS OWN channels 4g..4g+3 (the D-layout rows it holds).
+//          LAYER: tile 4*k + s = conv tap k, k-step s; tiles 12..15 = layer1x1. RECH / HEAD: tiles 0..3.
+//   consts: 48 floats per job, padded to 16 per vector — LAYER: conv bias, mixin, b1x1; RECH1: rechannel
+//          column (in_size == 1); HEAD: head bias
+enum MJobType : int32_t
+{
+  MJ_RECH1 = 0, // x = w * input sample            (first array, in_size == 1)
+  MJ_RECH = 1, // x = Wre * previous array output  (MFMA)
+  MJ_LAYER = 2,
+  MJ_HEAD = 3 // head rechannel (K = 1)
+};
+
+struct MJob // 16 x int32
+{
+  int32_t type;
+  int32_t C; // channels of the array
+  int32_t CS; // C / 4
+  int32_t K; // LAYER: kernel size
+  int32_t d; // LAYER: dilation
+  int32_t R; // LAYER: ring length (frames), 0 = no ring
+  int32_t ring_off; // float offset of the ring inside the per-stream state
+  int32_t ring_id; // -1 = none
+  int32_t tiles; // blob offset of this job's 1024-float tile area
+  int32_t consts; // float offset inside the consts table
+  int32_t act; // LAYER: activation type
+  int32_t steps; // RECH / HEAD: number of k-steps (4)
+  int32_t first; // RECH1/RECH of the first array: head accumulator starts at zero
+  int32_t last; // HEAD of the last array: produces the output sample
+  int32_t buf; // which half of the double-buffered LDS window / tap buffers this job READS (see kernel)
+  int32_t pad1;
+};
+static_assert(sizeof(MJob) == 64, "MJob must stay 64 bytes");
+constexpr int kMJobMax = 40;
+
 struct A1Plan
 {
   int32_t valid = 0;
   int32_t n_arrays = 0;
   int32_t head_scale_off = 0; // blob offset
   int32_t n_rings = 0;
+  int32_t mfma_ok = 0; // nam_a1_mfma_kernel can run this model (channels % 4 == 0, K == 3)
+  int32_t n_mjobs = 0;
+  int32_t mconsts_off = 0; // blob offset of the consts table (n_mjobs * 48 floats)
+  int32_t pad = 0;
   int32_t ring_len_by_id[64]; // R of ring r (for the per-block write-position update)
   A1Array arr[kA1MaxArrays];
+  MJob mjobs[kMJobMax];
 };
 
 // ---- LSTM ------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def _tol(fast_tanh):
 
 @pytest.mark.parametrize("name", WAVENETS)
 @pytest.mark.parametrize("fast_tanh", [True, False])
-@pytest.mark.parametrize("kernel", ["generic", "auto"])
+@pytest.mark.parametrize("kernel", ["generic", "a1", "auto"])
 def test_wavenet_matches_oracle(nam_lib, oracle, name, fast_tanh, kernel):
     nam = nam_lib
     n_streams, block, n = 5, 64, 64 * 6
@@ -36,6 +36,10 @@ def test_wavenet_matches_oracle(nam_lib, oracle, name, fast_tanh, kernel):
     batch = model.batch(n_streams, block)
     if kernel == "generic":
         batch.set_kernel(nam.KERNEL_GENERIC)
+    elif kernel == "a1":
+        if not (model.info.has_a1_kernel & 1):
+            pytest.skip("model is outside the A1 family")
+        batch.set_kernel(nam.KERNEL_A1)
     batch.Reset(prewarm=True)
     y = batch.process_stream(x, block)
     assert y.shape == (n_streams, model.NumOutputChannels(), n)
@@ -70,7 +74,7 @@ def test_block_partition_independence(nam_lib):
     nam = nam_lib
     x = stream_bank(3, 500, seed=5)
     model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
-    for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1):
+    for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1, nam.KERNEL_A1_MFMA):
         b1 = model.batch(3, 512)
         b1.set_kernel(kernel)
         b1.Reset(prewarm=False)
@@ -94,15 +98,17 @@ def test_generic_and_a1_kernels_agree(nam_lib):
     x = stream_bank(4, 64 * 5, seed=9)
     for name in ("wavenet", "wavenet_a1_standard", "slimmable_wavenet"):
         model = nam.get_dsp(model_path(name), fast_tanh=True)
-        assert model.info.has_a1_kernel == 1
+        assert model.info.has_a1_kernel & 1
         ys = []
-        for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1):
+        kernels = [nam.KERNEL_GENERIC, nam.KERNEL_A1] + ([nam.KERNEL_A1_MFMA] if model.info.has_a1_kernel & 2 else [])
+        for kernel in kernels:
             b = model.batch(4, 64)
             b.set_kernel(kernel)
             b.Reset(prewarm=True)
             ys.append(b.process_stream(x, 64))
             b.close()
-        assert float(np.max(np.abs(ys[0] - ys[1]))) < 1e-5 * max(1.0, float(np.max(np.abs(ys[0]))))
+        for y in ys[1:]:
+            assert float(np.max(np.abs(ys[0] - y))) < 1e-5 * max(1.0, float(np.max(np.abs(ys[0]))))
 
 
 def test_double_api_matches_float(nam_lib):
