@@ -168,14 +168,18 @@ def main():
     T = total_steps * block
 
     # ---- synthetic input bank: generated on rank 0, scattered to the ranks over RCCL ----
+    from neuralampmodelercore_amd import sharding
+    n_total = n_streams * world
+    bank = None
     if rank == 0:
-        bank = stream_bank(n_streams * world, T, seed=0)  # [world*n_streams, T]
-        bank_t = torch.from_numpy(bank).to(dev).view(world, n_streams, ic, T)
-    x = torch.empty((n_streams, ic, T), dtype=torch.float32, device=dev)
+        bank = stream_bank(n_total, T, seed=0)  # [world*n_streams, T]
     if distributed:
-        dist.scatter(x, scatter_list=[bank_t[r].contiguous() for r in range(world)] if rank == 0 else None, src=0)
+        full = torch.from_numpy(bank[:, None, :]).to(dev) if rank == 0 else None
+        x = sharding.scatter_streams(full, n_total, src=0, device=dev)  # RCCL send/recv of stream batches
+        del full
     else:
-        x.copy_(bank_t[0])
+        x = torch.from_numpy(bank[:, None, :]).to(dev)
+    assert tuple(x.shape) == (n_streams, ic, T)
     y = torch.zeros((n_streams, oc, T), dtype=torch.float32, device=dev)
 
     batch = model.batch(n_streams, block, device=local_rank)
@@ -224,12 +228,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall_max, gpu_s_max = float(tmax[0]), float(tmax[1])
 
-    # gather a per-rank checksum of the produced audio (RCCL gather of stream batches' digests)
-    digest = y.double().abs().sum().reshape(1)
-    if distributed:
-        digests = [torch.zeros_like(digest) for _ in range(world)] if rank == 0 else None
-        dist.gather(digest, gather_list=digests, dst=0)
-    finite = bool(torch.isfinite(y).all())
+    # after the timed region: gather the last rendered block of every stream back to rank 0 over RCCL
+    tail = y[:, :, (total_steps - 1) * block:].contiguous()
+    gathered = sharding.gather_streams(tail, n_total, dst=0) if distributed else tail
+    finite = bool(torch.isfinite(y).all()) and (gathered is None or bool(torch.isfinite(gathered).all()))
 
     parity = None
     if rank == 0 and args.check:

@@ -171,3 +171,78 @@ def test_device_pointer_long_render(nam_lib, oracle):
         r = _oracle_run(oracle, "wavenet_a1_standard", x[s], 64, True)
         assert float(np.max(np.abs(r - y[s]))) <= 5e-5
     b.close()
+
+
+def test_hip_matches_committed_golden_vectors(nam_lib):
+    """HIP path vs the committed fixtures (tests/golden/outputs.npz), all kernels that can run each model."""
+    import os
+    from conftest import ROOT
+    nam = nam_lib
+    G = np.load(os.path.join(ROOT, "tests", "golden", "outputs.npz"))
+    x = G["input"]
+    for key in [k for k in G.files if "__ft" in k]:
+        name, ft = key.split("__ft")
+        model = nam.get_dsp(model_path(name), fast_tanh=bool(int(ft)))
+        kernels = [nam.KERNEL_GENERIC]
+        if model.architecture == "WaveNet" and model.info.has_a1_kernel & 1:
+            kernels.append(nam.KERNEL_A1)
+        if model.architecture == "WaveNet" and model.info.has_a1_kernel & 2:
+            kernels.append(nam.KERNEL_A1_MFMA)
+        for kernel in kernels:
+            b = model.batch(3, 64)
+            if model.architecture == "WaveNet":
+                b.set_kernel(kernel)
+            b.Reset(prewarm=True)
+            y = b.process_stream(np.stack([x, x, x]), 64)
+            scale = max(1.0, float(np.max(np.abs(G[key]))))
+            tol = (5e-5 if int(ft) else 1e-4) * scale
+            for s in range(3):
+                assert float(np.max(np.abs(y[s] - G[key]))) <= tol, (key, kernel, s)
+            b.close()
+
+
+@pytest.mark.parametrize("kernel", ["generic", "a1", "a1_mfma"])
+def test_long_resident_render_wraps_every_ring(nam_lib, oracle, kernel):
+    """One launch over 150 blocks: the d = 512 ring (1088 frames) wraps ~9 times; frames written by one
+    wavefront are read back by others many blocks later (same-CU L1 coherence of global memory)."""
+    torch = pytest.importorskip("torch")
+    nam = nam_lib
+    n_streams, n = 3, 64 * 150 + 5
+    x = stream_bank(n_streams, n, seed=21)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    b = model.batch(n_streams, 64)
+    b.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[kernel])
+    b.Reset(prewarm=True)
+    xd = torch.from_numpy(x[:, None, :]).cuda()
+    y = b.process_tensor(xd)
+    torch.cuda.synchronize()
+    y = y.cpu().numpy()
+    r = _oracle_run(oracle, "wavenet_a1_standard", x[1], 64, True)
+    assert float(np.max(np.abs(r - y[1]))) <= 5e-5
+    # and the state left behind continues correctly in block mode
+    x2 = stream_bank(n_streams, 128, seed=22)
+    y2 = b.process_stream(x2, 64)
+    ref = oracle.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    ref.Reset(48000.0, 64)
+    ref.process_stream(x[1], 64)
+    r2 = ref.process_stream(x2[1], 64)
+    assert float(np.max(np.abs(r2 - y2[1]))) <= 5e-5
+    b.close()
+
+
+def test_cpp_adapter_benchmodel_runs(nam_lib):
+    """The C++ adapter (cpp/NAM/dsp.h: nam::get_dsp / nam::DSP::process over the C ABI) as a stand-alone
+    binary, the way tools/benchmodel.cpp drives the reference."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cpp", "tools", "benchmodel")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cpp")])
+    for args in ([model_path("wavenet")], [model_path("lstm")], [model_path("slimmable_wavenet"), "--slim", "0.5"],
+                 [model_path("wavenet_a1_standard"), "--streams", "64"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "ms" in out.stdout
+    bad = subprocess.run([exe, "/nonexistent.nam"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "does not exist" in bad.stderr

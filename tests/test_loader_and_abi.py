@@ -1,0 +1,141 @@
+"""Host logic without a GPU: the product's .nam loader / plan compiler against the oracle's
+independent (Python) reading of the same files, reference error behaviour, and the C ABI surface."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, ROOT, model_path
+
+ALL = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable_wavenet", "wavenet_condition_dsp"]
+EXPECTED_WEIGHTS = {"wavenet": 131, "wavenet_a1_standard": 13802, "lstm": 70, "wavenet_a2_max": 818,
+                    "slimmable_wavenet": 457, "wavenet_condition_dsp": 147}
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_loader_agrees_with_oracle(nam_lib, oracle, name):
+    m = nam_lib.get_dsp(model_path(name))
+    o = oracle.get_dsp(model_path(name))
+    assert m.num_weights == EXPECTED_WEIGHTS[name]
+    assert m.NumInputChannels() == o.NumInputChannels() and m.NumOutputChannels() == o.NumOutputChannels()
+    assert m.GetPrewarmSamples() == o.GetPrewarmSamples()
+    assert m.GetExpectedSampleRate() == o.expected_sample_rate
+    assert m.HasLoudness() == (o.loudness is not None)
+    if m.HasLoudness():
+        assert m.GetLoudness() == pytest.approx(o.loudness)
+
+
+def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
+    m = nam_lib.get_dsp(model_path("wavenet_a1_standard"))
+    assert m.GetExpectedSampleRate() == -1.0 and not m.HasLoudness()  # get_dsp.cpp:275-281
+    assert m.GetPrewarmSamples() == 4093  # model.cpp:653-658
+    assert m.info.has_a1_kernel == 3  # VALU + MFMA specialisations
+    # write-position table (64 words) + one ring of (K-1)*d + 64 frames per layer, rounded up to 64 floats
+    floats = 64 + sum(c * (2 * d + 64) for c in (16, 8) for d in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512))
+    assert m.info.state_bytes_per_stream == 4 * ((floats + 63) // 64 * 64)
+    with pytest.raises(RuntimeError):
+        m.GetLoudness()  # dsp.cpp:121-128
+
+
+def test_missing_file_is_validation_error(nam_lib):
+    with pytest.raises(nam_lib.NamFileValidationError):
+        nam_lib.get_dsp(os.path.join(MODELS, "does_not_exist.nam"))
+
+
+def _variant(name, mutate):
+    j = json.load(open(model_path(name)))
+    mutate(j)
+    return json.dumps(j)
+
+
+def test_reference_error_behaviour(nam_lib, tmp_path):
+    nam = nam_lib
+    # missing required key -> NamFileValidationError (nam_file.cpp:31-37)
+    p = tmp_path / "nokey.nam"
+    p.write_text(_variant("wavenet", lambda j: j.pop("weights")))
+    with pytest.raises(nam.NamFileValidationError):
+        nam.get_dsp(str(p))
+    p = tmp_path / "garbage.nam"
+    p.write_text("{ not json")
+    with pytest.raises(nam.NamFileValidationError):
+        nam.get_dsp(str(p))
+    # unsupported versions (get_dsp.cpp:18-39): too old, minor too new, non-semver
+    for v in ("0.4.9", "0.8.0", "1.0.0", "0.5"):
+        with pytest.raises(nam.NamHipError, match="unsupported version"):
+            nam.get_dsp_json(_variant("wavenet", lambda j, v=v: j.__setitem__("version", v)))
+    nam.get_dsp_json(_variant("wavenet", lambda j: j.__setitem__("version", "0.7.3")))  # partial support: loads
+    # weight count mismatch (model.cpp:671-682)
+    with pytest.raises(nam.NamHipError, match="Weight mismatch"):
+        nam.get_dsp_json(_variant("wavenet", lambda j: j["weights"].append(0.0)))
+    with pytest.raises(nam.NamHipError, match="Weight mismatch"):
+        nam.get_dsp_json(_variant("wavenet", lambda j: j["weights"].pop()))
+    # unknown architecture (model_config.h:84-87)
+    with pytest.raises(nam.NamHipError, match="No config parser registered"):
+        nam.get_dsp_json(_variant("wavenet", lambda j: j.__setitem__("architecture", "ConvNet")))
+    # kernel_size and kernel_sizes together (model.cpp:1004-1008)
+    def both(j):
+        j["config"]["layers"][0]["kernel_sizes"] = [3, 3]
+    with pytest.raises(nam.NamHipError, match="only one of kernel_size"):
+        nam.get_dsp_json(_variant("wavenet", both))
+    with pytest.raises(nam.NamHipError, match="Unknown activation"):
+        nam.get_dsp_json(_variant("wavenet", lambda j: j["config"]["layers"][0].__setitem__("activation", "Nope")))
+
+
+def test_legacy_and_new_schema_forms_load_identically(nam_lib, oracle):
+    """`gated: false` == gating_mode none; kernel_size == kernel_sizes; head_size/head_bias == nested head."""
+    def modern(j):
+        for lc in j["config"]["layers"]:
+            n = len(lc["dilations"])
+            lc["kernel_sizes"] = [lc.pop("kernel_size")] * n
+            lc["gating_mode"] = "none"
+            lc.pop("gated")
+            lc["head"] = {"out_channels": lc.pop("head_size"), "kernel_size": 1, "bias": lc.pop("head_bias")}
+            lc["activation"] = {"type": lc["activation"]}
+    a = nam_lib.get_dsp(model_path("wavenet"))
+    b = nam_lib.get_dsp_json(_variant("wavenet", modern))
+    assert (a.num_weights, a.GetPrewarmSamples(), a.info.state_bytes_per_stream) == (
+        b.num_weights, b.GetPrewarmSamples(), b.info.state_bytes_per_stream)
+    x = (0.2 * np.sin(0.05 * np.arange(256))).astype(np.float32)
+    oa = oracle.get_dsp(model_path("wavenet"))
+    ob = oracle.load_nam_json(json.loads(_variant("wavenet", modern)))
+    oa.Reset(48000, 64)
+    ob.Reset(48000, 64)
+    np.testing.assert_array_equal(oa.process_stream(x, 64), ob.process_stream(x, 64))
+
+
+def test_slimmable_breakpoints_and_ratio_mapping(nam_lib, oracle):
+    m = nam_lib.get_dsp(model_path("slimmable_wavenet"))
+    assert m.is_slimmable and m.GetSlimmableSizeBreakpoints() == pytest.approx([1 / 3, 2 / 3])
+    o = oracle.get_dsp(model_path("slimmable_wavenet"))
+    assert o.GetSlimmableSizeBreakpoints() == pytest.approx([1 / 3, 2 / 3])
+    # idx = min(floor(ratio * len), len - 1) (slimmable.cpp:102-106)
+    assert [o.channels_for(r)[0] for r in (0.0, 0.33, 0.34, 0.66, 0.67, 1.0)] == [1, 1, 2, 2, 3, 3]
+    assert not nam_lib.get_dsp(model_path("wavenet")).is_slimmable
+
+
+def test_library_exports_exactly_the_header_abi(nam_lib):
+    """Every symbol include/nam_hip.h declares is exported by the built library, and nothing else is."""
+    header = open(os.path.join(ROOT, "include", "nam_hip.h")).read()
+    declared = sorted(set(re.findall(r"NAM_HIP_API\s+[\w\s\*]*?\b(nam_hip_\w+)\s*\(", header)))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", nam_lib.lib_path()], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "nam_hip_" in l)
+    assert declared == exported == sorted(nam_lib.ABI_SYMBOLS)
+    assert nam_lib.load_library().nam_hip_version().decode().endswith("gfx950")
+
+
+def test_library_carries_gfx950_code_objects(nam_lib):
+    """The shared library embeds device code for gfx950 only (no CUDA / multi-arch fat binary)."""
+    data = open(nam_lib.lib_path(), "rb").read()
+    assert b"gfx950" in data
+    assert b"gfx942" not in data and b"sm_" not in data
+
+
+def test_no_cpu_fallback_without_library(monkeypatch, nam_lib):
+    import neuralampmodelercore_amd as nam
+    monkeypatch.setattr(nam, "_lib", None)
+    monkeypatch.setattr(nam, "lib_path", lambda: os.path.join(ROOT, "no_such_dir", "libnam_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        nam.get_dsp(model_path("wavenet"))
