@@ -33,6 +33,35 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 SR = 48000.0
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 vector == FP32 (f32-in) MFMA
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def wavenet_history_bytes_per_sample(cfg: dict) -> int:
+    """Algorithmic history traffic per stream-sample, SURVEY.md §8d-ii's figure: per dilated layer
+    (K tap reads + 1 write) x C channels x 4 B. wavenet_a1_standard -> 3,840. (The kernels never re-read
+    the current tap, so what must actually move is (K-1) reads + 1 write = 2,880 B; the contract
+    figure is kept so numbers stay comparable with SURVEY.md / BASELINE.md.)"""
+    total = 0
+    if cfg.get("condition_dsp"):
+        total += wavenet_history_bytes_per_sample(cfg["condition_dsp"]["config"])
+    for lc in cfg["layers"]:
+        n = len(lc["dilations"])
+        ks = lc.get("kernel_sizes") or [lc["kernel_size"]] * n
+        total += sum((k + 1) * lc["channels"] * 4 for k in ks if k > 1)
+    return total
+
+
+def measured_traffic(kernel: str, streams: int, block: int, launch: str):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), if the
+    profiled configuration matches this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if (e["kernel"], e["streams"], e["block"], e["launch"]) == (kernel, streams, block, launch):
+                    return e
+    except Exception:
+        pass
+    return None
 
 
 def wavenet_macs_per_sample(cfg: dict) -> int:
@@ -252,8 +281,16 @@ def main():
         xrt = total_samples / SR / wall_max
         launches = K if args.launch == "block" else 1
         avg_launch_s = gpu_s_max / launches
-        flops_per_launch = flops_per_sample * samples_per_step_gpu * (1 if args.launch == "block" else K)
-        achieved = flops_per_launch / avg_launch_s / 1e12
+        samples_per_launch = samples_per_step_gpu * (1 if args.launch == "block" else K)
+        flops_per_launch = flops_per_sample * samples_per_launch
+        achieved_tf = flops_per_launch / avg_launch_s / 1e12
+        with open(model_path) as f:
+            mj = json.load(f)
+        hist = wavenet_history_bytes_per_sample(mj["config"]) if mj["architecture"] == "WaveNet" else 0
+        bytes_per_sample = hist + 4 * (ic + oc)
+        achieved_gbs = bytes_per_sample * samples_per_launch / avg_launch_s / 1e9
+        kname = {1: "generic", 2: "a1_valu", 3: "a1_mfma"}.get(batch.get_kernel(), "?")
+        tr = measured_traffic(kname, n_streams, block, args.launch)
         out = {
             "metric": "real-time audio streams (xRT) at 48 kHz, wavenet_a1_standard" if args.model == "wavenet_a1_standard"
             else f"real-time audio streams (xRT) at 48 kHz, {args.model}",
@@ -272,15 +309,23 @@ def main():
                 "workload": f"{args.model}.nam, {n_streams} concurrent streams per GPU, buffer={block} samples, "
                             f"fast_tanh={'on' if args.fast_tanh else 'off'} (BASELINE.json configs[1])",
                 "streams_per_gpu": n_streams, "block": block, "launch": args.launch,
-                "kernel": {1: "generic", 2: "a1_valu", 3: "a1_mfma"}.get(batch.get_kernel(), "?"),
+                "kernel": kname,
                 "sharding": f"streams x{world} (no data-path collective)",
             },
+            # The path is bound by history traffic through HBM / Infinity Cache (191.8 KB of state per
+            # stream cannot stay in LDS): 8 TB/s / 3,848 B / 48 kHz = 43 k xRT, below the fp32 ceiling of
+            # 157.3 TF / 26,640 FLOP / 48 kHz = 123 k xRT. Both fractions are reported.
             "roofline": {
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                "note": f"algorithmic {flops_per_sample} FLOP/stream-sample x {samples_per_step_gpu} stream-samples per "
-                        f"launch-step; avg launch {avg_launch_s * 1e6:.2f} us from HIP events on the launch stream; "
-                        "peak = fp32 vector == fp32-input MFMA peak (the kernel uses VALU FMA with SGPR weights)",
+                "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "traffic": (tr["hbm_bytes_per_launch"] if tr else None),
+                "traffic_note": (tr["note"] if tr else "no PMC pass committed for this exact configuration"),
+                "note": f"algorithmic {bytes_per_sample} B/stream-sample ({hist} history + {4 * (ic + oc)} I/O) x "
+                        f"{samples_per_launch} stream-samples per launch; avg launch {avg_launch_s * 1e6:.2f} us from HIP "
+                        "events on the launch stream",
+                "compute": {"achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
+                            "note": f"{flops_per_sample} FLOP/stream-sample; fp32 MFMA peak == fp32 vector peak"},
             },
             "gpu_ms_total": round(gpu_s_max * 1e3, 3),
             "finite": finite,
