@@ -588,29 +588,28 @@ __global__ __launch_bounds__(64) void nam_a1_kernel(const A1Plan* __restrict__ P
 // [previous 64 | current 64] frames) or tap buffer (L > 64), both filled from the stream's
 // frame-major history ring in HBM with 16-byte accesses.
 //
-// The model is flattened into a job table (plan.h MJob: rechannel / layer / head). This path is
-// bound by the latency and bandwidth of the history reads (3,840 B per stream-sample stream through
-// HBM / Infinity Cache; they cannot live in LDS), so every global load a job needs — its quarter of
-// the 4 KB weight tile area and three 64-frame history sets — is issued kPrefetch jobs ahead into
-// a rotating set of VGPR slots and dropped into LDS one job early; raw s_barrier (no vmcnt drain)
-// keeps the loads in flight across jobs and the compiler's counted s_waitcnt vmcnt(N) retires
-// exactly the oldest slot.
+// The model is flattened into a job table (plan.h: rechannel / layer / head; MDesc holds every
+// host-decidable quantity as a ready byte offset). With one workgroup per CU (the 256-stream
+// headline shape) a wavefront has its SIMD to itself and issues at most ~1 instruction per 4 clocks,
+// so the kernel is written for INSTRUCTION COUNT: 16-byte LDS / VMEM operations only, scalar ring
+// arithmetic, one descriptor load per job, activation resolved at compile time.
+// The path is also bound by the latency of the history reads (3,840 B per stream-sample stream
+// through HBM / Infinity Cache; they cannot live in LDS), so every global load a job needs — its
+// 64 B of weight-tile values per lane, three 64-frame history sets, the input sample — is issued
+// kMfPrefetch jobs ahead into rotating VGPR slots; history is dropped into LDS one job early. A raw
+// s_barrier (no vmcnt drain) keeps the loads in flight and, because every load is unconditional
+// (selects act on the ADDRESS, no branch surrounds a load), the compiler's counted
+// s_waitcnt vmcnt(N) retires exactly the oldest slot.
 namespace mf
 {
-constexpr int kOldTaps = 2; // K == 3
-constexpr int kPrefetch = 4; // jobs in flight
-constexpr int SCMAX = 20; // window row pitch for C = 16 (floats): C + 4 keeps 16-B alignment, spreads banks
-constexpr int XW_FLOATS = 2 * kBlock * SCMAX; // [frame -64..63][C + 4]
-constexpr int TB_FLOATS = kBlock * SCMAX; // [frame 0..63][C + 4]
-constexpr int TL_PITCH = 20; // tile area row pitch (floats): lane-major [64][16 + 4]
-constexpr int TL_FLOATS = 64 * TL_PITCH;
 using f4 = __attribute__((ext_vector_type(4))) float;
+constexpr int SC = kMfSC;
+constexpr int D = kMfPrefetch;
 
-struct Slot // one job's worth of prefetched data, per lane
+struct Slot // one job's worth of prefetched history, per lane
 {
-  f4 tile; // this lane's 16 bytes of the job's 4 KB tile area
-  f4 h[1 + kOldTaps]; // history: [0] = previous 64 frames (window), [1 + k] = tap k
-  float inp; // RECH1 jobs (first job of a block): this lane's input sample of that block
+  f4 h[3]; // [0] = previous 64 frames (window), [1] = tap 0 (lookback 2d), [2] = tap 1 (lookback d)
+  float inp; // the lane's input sample of the block the job belongs to (used by the block's first job)
 };
 
 __device__ __forceinline__ float rcp(float x)
@@ -655,45 +654,40 @@ __device__ __forceinline__ float act_hw(int type, float x, float p0)
     default: return x;
   }
 }
-// whole-vector activation: ONE wave-uniform dispatch per job (a per-element switch costs a branch
-// cascade per element), most likely types first
-template <int TYPE>
-__device__ __forceinline__ f4 act4_t(const f4& v, float p0)
-{
-  f4 r;
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-  {
-    if constexpr (TYPE == ACT_FASTTANH)
-      r[i] = fast_tanh_hw(v[i]);
-    else if constexpr (TYPE == ACT_TANH)
-      r[i] = tanh_hw(v[i]);
-    else
-      r[i] = act_hw(TYPE, v[i], p0);
-  }
-  return r;
-}
+// whole-vector activation; ACT_T >= 0 resolves the type at compile time (the two kernels that matter:
+// Fasttanh = benchmodel default, Tanh), ACT_T < 0 dispatches once per job on the run-time type
+template <int ACT_T>
 __device__ __forceinline__ f4 act4(int type, const f4& v, float p0)
 {
-  if (type == ACT_FASTTANH)
-    return act4_t<ACT_FASTTANH>(v, p0);
-  if (type == ACT_TANH)
-    return act4_t<ACT_TANH>(v, p0);
-  if (type == ACT_RELU)
-    return act4_t<ACT_RELU>(v, p0);
-  if (type == ACT_LEAKYRELU)
-    return act4_t<ACT_LEAKYRELU>(v, p0);
-  if (type == ACT_SIGMOID)
-    return act4_t<ACT_SIGMOID>(v, p0);
-  if (type == ACT_SILU)
-    return act4_t<ACT_SILU>(v, p0);
-  if (type == ACT_HARDTANH)
-    return act4_t<ACT_HARDTANH>(v, p0);
-  if (type == ACT_HARDSWISH)
-    return act4_t<ACT_HARDSWISH>(v, p0);
-  if (type == ACT_SOFTSIGN)
-    return act4_t<ACT_SOFTSIGN>(v, p0);
-  return v;
+  f4 r;
+  if constexpr (ACT_T == ACT_FASTTANH)
+  {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      r[i] = fast_tanh_hw(v[i]);
+  }
+  else if constexpr (ACT_T == ACT_TANH)
+  {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      r[i] = tanh_hw(v[i]);
+  }
+  else
+  {
+    if (type == ACT_RELU)
+    {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        r[i] = fmaxf(v[i], 0.0f);
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        r[i] = act_hw(type, v[i], p0);
+    }
+  }
+  return r;
 }
 // workgroup barrier that orders LDS traffic only: outstanding global loads stay in flight
 __device__ __forceinline__ void lds_barrier()
@@ -710,283 +704,301 @@ __device__ __forceinline__ f4 mfma4(const f4& a, const f4& b, f4 acc)
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
   return acc;
 }
+__device__ __forceinline__ f4 lds_ld4(const char* lds, unsigned byte_off)
+{
+  return *reinterpret_cast<const f4*>(lds + byte_off);
+}
+__device__ __forceinline__ void lds_st4(char* lds, unsigned byte_off, const f4& v)
+{
+  *reinterpret_cast<f4*>(lds + byte_off) = v;
+}
 } // namespace mf
 
+// Ring append: 16 B at (wave-uniform base + per-lane byte offset). WT = write-through (sc0 sc1): a launch that
+// covers only a block or two would otherwise leave every ring line dirty in L2 and pay for the write-back
+// when the kernel retires (measured 3 us of a 28 us launch at 256 streams); long launches keep the default
+// write-back policy, which is ~3% faster in steady state.
+template <bool WT>
+__device__ __forceinline__ void ring_store(char* base, unsigned off, mf::f4 v)
+{
+  if constexpr (WT)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v),
+                                           __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000),
+                                           (int)off, 0, /*sc0 sc1*/ 17);
+  else
+    *reinterpret_cast<mf::f4*>(base + off) = v;
+}
+
+template <int ACT_T, bool DBG, bool WT>
 __global__ __launch_bounds__(256) void nam_a1_mfma_kernel(const A1Plan* __restrict__ P,
                                                           const float* __restrict__ blob, const A1Args a)
 {
   using namespace mf;
-  // one LDS array (a single __shared__ object keeps every access a plain ds_* instruction):
+  // one LDS array (a single __shared__ object keeps every access a plain ds_* instruction); plan.h kMf*:
   //   window  [2][128][SC]     [buf][frame -64..63][channel]: previous 64 | current 64 frames of a layer input
   //   taps    [2][2][64][SC]   [buf][tap][frame 0..63][channel]: far taps (lookback > 64)
-  //   tiles   [2][64][20]      the running / the next job's tile area, lane-major
   //   consts  [jobs][48]
-  constexpr int XW_OFF = 0, TB_OFF = XW_OFF + 2 * XW_FLOATS, TL_OFF = TB_OFF + 2 * kOldTaps * TB_FLOATS,
-                CONSTS_OFF = TL_OFF + 2 * TL_FLOATS, LDS_FLOATS = CONSTS_OFF + kMJobMax * 48;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  auto xw_off = [](int buf) { return XW_OFF + buf * XW_FLOATS; };
-  auto tb_off = [](int buf, int tap) { return TB_OFF + (buf * kOldTaps + tap) * TB_FLOATS; };
-  auto tl_off = [](int tb) { return TL_OFF + tb * TL_FLOATS; };
+  // (weight tiles never touch LDS: each wave loads its own copy straight into VGPRs, L1 serves the repeats)
+  __shared__ __attribute__((aligned(16))) float lds_f[kMfLdsFloats];
+  char* const lds = reinterpret_cast<char*>(lds_f);
 
   const int tid = threadIdx.x;
+  long long* wall = nullptr; // DBG: wall-clock (100 MHz) stamps of the first / last workgroup: rows 95 / 94
+  if constexpr (DBG)
+  {
+    if (a.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+      wall = a.dbg + (blockIdx.x == 0 ? 95 : 94) * 8;
+    if (wall)
+      wall[0] = wall_clock64();
+  }
   const int lane = tid & 63;
   const int w = uni(tid >> 6); // wave id = 16-frame tile
   const int g = lane >> 4; // channel quad: this lane owns channels 4g..4g+3
-  const int j = lane & 15;
-  const int frame = 16 * w + j; // this lane's frame inside the 64-frame block
+  const int frame = 16 * w + (lane & 15); // this lane's frame inside the 64-frame block
   const int hfr = 16 * w + (lane >> 2); // history mover: frame inside a 64-frame set
-  const int hch = lane & 3; // history mover: channel quad
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
   float* st = a.state + (size_t)stream * a.state_stride;
-  const char* stb = reinterpret_cast<const char*>(st);
+  char* stb = reinterpret_cast<char*>(st);
   int* wpos_tbl = reinterpret_cast<int*>(st);
   const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
   float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
-  const int n_rings = P->n_rings;
-  const int NJ = P->n_mjobs;
-  const float head_scale = blob[P->head_scale_off];
+  const char* ibase = in ? reinterpret_cast<const char*>(in) : stb; // silence: any valid word, masked to 0 later
+  const int n_rings = a.n_rings;
+  const int NJ = a.n_mjobs;
+  const float head_scale = a.head_scale;
   const float act_p0 = a.act_p0;
   const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
   const int total = n_blocks * NJ;
 
-  int wposv = lane < n_rings ? wpos_tbl[lane] : 0; // every wave keeps its own copy of all ring positions
-  const int ring_len_v = lane < n_rings ? P->ring_len_by_id[lane] : 1;
-  for (int i = tid; i < NJ * 48; i += 256)
-    lds[CONSTS_OFF + i] = blob[P->mconsts_off + i];
-  const unsigned tile_lane_off = (unsigned)tid * 16u; // this thread's 16 B of a job's 4 KB tile area
-  const int tile_stash_off = (tid >> 2) * TL_PITCH + (tid & 3) * 4; // same 16 B inside the padded LDS copy
+  // per-lane byte offsets that never change
+  const unsigned v_g16 = (unsigned)g * 16u; // this lane's channel quad inside a frame row
+  const unsigned v_tap = (unsigned)(frame * SC) * 4u; // row of this lane's frame in a 64-frame operand set
+  const unsigned v_hist = (unsigned)(hfr * SC + 4 * (lane & 3)) * 4u; // where this lane drops its 16 B of history
+  const unsigned v_hq16 = (unsigned)(lane & 3) * 16u; // history mover: channel quad
+  const unsigned v_tile = (unsigned)lane * 64u; // this lane's 16 tile values inside a job's 4 KB tile area
 
-  // ---- prefetch: issue the 5 global loads of job J (of block jblk) into slot s. Every load is
-  // unconditional (selects act on the ADDRESS) so the compiler's vmcnt bookkeeping stays exact; all
-  // addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset. ----
-  auto fetch = [&](Slot& s, const MJob& J, bool next_block, int jblk) {
-    s.tile = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(blob + J.tiles) + tile_lane_off);
-    const int rid = J.ring_id;
-    const bool has = J.type == MJ_LAYER && rid >= 0;
-    const int R = has ? J.R : 64;
-    const int d = J.d, CS = J.CS;
-    int wp = has ? __builtin_amdgcn_readlane(wposv, rid) : 0;
+  // prologue: everything below is an independent load off kernel arguments (no load depends on another)
+  int wposv = wpos_tbl[lane]; // the table is 64 words: every wave keeps its own copy of all ring positions
+  const int ring_len_v = P->ring_len_by_id[lane];
+  {
+    const float* __restrict__ csrc = blob + a.consts_off;
+    float cv[(kMJobMax * 48 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (kMJobMax * 48 + 255) / 256; i++)
+      cv[i] = (tid + 256 * i < NJ * 48) ? csrc[tid + 256 * i] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < (kMJobMax * 48 + 255) / 256; i++)
+      if (tid + 256 * i < kMJobMax * 48)
+        lds_f[kMfConstsOff + tid + 256 * i] = cv[i];
+  }
+
+  // ---- history prefetch of the job described by (rbase, cmul, R, L0, L1, ring_id, q16max): 4 loads ----
+  auto fetch = [&](Slot& s, int f_rbase, int f_cmul, int f_R, int f_L0, int f_L1, int f_ring_id, int f_q16max,
+                   bool next_block, int jblk) {
+    int wp = __builtin_amdgcn_readlane(wposv, f_ring_id);
     if (next_block)
     {
       wp += kBlock;
-      if (wp >= R)
-        wp -= R;
+      if (wp >= f_R)
+        wp -= f_R;
     }
-    // one base (the stream's state) + a selected 32-bit byte offset: jobs without a ring read a
-    // harmless dummy (the first 256 B of the state)
-    const unsigned rbase = has ? (unsigned)J.ring_off * 4u : 0u;
-    const unsigned cmul = has ? (unsigned)J.C * 4u : 0u; // bytes per ring frame
-    const unsigned cq = has ? (unsigned)(hch < CS ? hch : CS - 1) * 16u : (unsigned)(lane & 15) * 16u;
+    const unsigned vq = min(v_hq16, (unsigned)f_q16max) + (unsigned)f_rbase;
+    const int Ls[3] = {kBlock, f_L0, f_L1};
 #pragma unroll
-    for (int t = 0; t <= kOldTaps; t++)
+    for (int t = 0; t < 3; t++)
     {
-      const int L = (t == 0) ? kBlock : (3 - t) * d; // window, then tap k = t-1 -> (K-1-k)*d with K = 3
-      int idx = wp + hfr - L;
-      if (idx < 0)
-        idx += R;
-      const unsigned off = rbase + __umul24((unsigned)idx, cmul) + cq;
-      s.h[t] = *reinterpret_cast<const f4*>(stb + off);
+      int sb = wp - Ls[t]; // scalar: ring index of the set's frame 0 (before the per-wave 16w offset)
+      if (sb < 0)
+        sb += f_R;
+      const unsigned v = (unsigned)(hfr + sb);
+      const unsigned idx = min(v, v - (unsigned)f_R); // v < 2R: wraps at most once
+      s.h[t] = *reinterpret_cast<const f4*>(stb + (__umul24(idx, (unsigned)f_cmul) + vq));
     }
     int fi = jblk * kBlock + frame;
-    if (fi >= a.n_frames)
-      fi = a.n_frames - 1;
-    const bool use_in = in && J.type == MJ_RECH1;
-    const char* ibase = use_in ? reinterpret_cast<const char*>(in) : stb;
-    s.inp = *reinterpret_cast<const float*>(ibase + (use_in ? (unsigned)fi * 4u : 0u));
+    fi = min(fi, a.n_frames - 1);
+    s.inp = *reinterpret_cast<const float*>(ibase + (in ? (unsigned)fi * 4u : 0u));
   };
-  // ---- drop a slot into LDS for the job that will read buffer `buf` / tile buffer `tb`: 4 x 16-byte writes ----
-  auto stash = [&](const Slot& s, int C, int CS, int buf, int tb) {
-    *reinterpret_cast<f4*>(&lds[tl_off(tb) + tile_stash_off]) = s.tile;
-    if (hch < CS)
-    {
-      const int SC = C + 4;
-      *reinterpret_cast<f4*>(&lds[xw_off(buf) + hfr * SC + 4 * hch]) = s.h[0];
+  // ---- weight-tile prefetch: this lane's 16 A-operand values (64 contiguous bytes) of job `job`; the tile
+  // areas of consecutive jobs are contiguous in the blob ----
+  const char* tiles0 = reinterpret_cast<const char*>(blob + a.tiles_off);
+  auto fetch_tiles = [&](f4 (&ta)[4], int job) {
+    const char* tp = tiles0 + (size_t)job * 4096;
 #pragma unroll
-      for (int t = 0; t < kOldTaps; t++)
-        *reinterpret_cast<f4*>(&lds[tb_off(buf, t) + hfr * SC + 4 * hch]) = s.h[1 + t];
-    }
+    for (int q = 0; q < 4; q++)
+      ta[q] = *reinterpret_cast<const f4*>(tp + (v_tile + 16u * q));
   };
 
-  Slot slot[kPrefetch];
+  Slot slot[D];
+  f4 ta[D][4];
 #pragma unroll
-  for (int u = 0; u < kPrefetch; u++)
+  for (int u = 0; u < D; u++)
   {
-    const MJob J = P->mjobs[u < total ? u % NJ : 0];
-    fetch(slot[u], J, u >= NJ, u / NJ);
+    // job u's history (u < NJ always: a model has at least 3 jobs... use the generic path otherwise)
+    const MJob J = P->mjobs[u % NJ];
+    const bool fr = J.type == MJ_LAYER && J.ring_id >= 0;
+    fetch(slot[u], fr ? J.ring_off * 4 : 0, fr ? J.C * 4 : 0, fr ? J.R : 64, fr ? 2 * J.d : 64, fr ? J.d : 64,
+          fr ? J.ring_id : 0, 16 * (J.CS - 1), u >= NJ, u / NJ);
+    fetch_tiles(ta[u], u % NJ);
   }
 
   // running state
   f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f}, hprev = {0.f, 0.f, 0.f, 0.f};
-  int ji = 0, blk = 0, tb = 0;
-  int jf = kPrefetch % NJ; // job index of the next fetch
-  int fblk = kPrefetch / NJ; // its block
+  int ji = 0, blk = 0;
+  int jt = D % NJ; // job whose tiles are fetched next
+  int fblk = (D + 1) / NJ; // block of the job whose history is fetched next (job ji + 1 + D)
+  int fj = (D + 1) % NJ;
   int nvalid = min(kBlock, a.n_frames);
-  // job descriptors are fetched (scalar loads) ahead of their use: Jcur runs now, Jnext is stashed now
-  MJob Jcur = P->mjobs[0];
-  MJob Jnext = P->mjobs[1 % NJ];
-  MJob Jfnext = P->mjobs[jf];
-  float cond = (in && frame < nvalid) ? slot[0].inp : 0.0f; // job 0 is always a RECH1
-  // job 0's data goes to LDS now; afterwards every job stashes its SUCCESSOR while it computes
-  stash(slot[0], Jcur.C, Jcur.CS, Jcur.buf, 0);
+  bool lane_live = frame < nvalid;
+  MDesc Dn = P->mdesc[0]; // descriptors are scalar-loaded one job ahead of their use
+  float cond = (in && lane_live) ? slot[0].inp : 0.0f; // job 0 is the block's first job
+  // job 0's history goes to LDS now (job 0 is never a LAYER, but keep the pipeline uniform); afterwards
+  // every job drops its SUCCESSOR's history while it computes. Slot 0 is then refilled with job D.
   {
-    const bool valid = fblk < n_blocks;
-    fetch(slot[0], Jfnext, valid && fblk > 0, fblk);
-    if (++jf == NJ)
-    {
-      jf = 0;
-      fblk++;
-    }
-    Jfnext = P->mjobs[jf];
+    const MJob J0 = P->mjobs[0];
+    lds_st4(lds, v_hist + (unsigned)(kMfXwOff + J0.buf * kMfXwFloats) * 4u, slot[0].h[0]);
+    const MJob J = P->mjobs[D % NJ];
+    const bool fr = J.type == MJ_LAYER && J.ring_id >= 0;
+    fetch(slot[0], fr ? J.ring_off * 4 : 0, fr ? J.C * 4 : 0, fr ? J.R : 64, fr ? 2 * J.d : 64, fr ? J.d : 64,
+          fr ? J.ring_id : 0, 16 * (J.CS - 1), D >= NJ, D / NJ);
   }
-  __syncthreads(); // CONSTS + job 0 visible
+  // (consts + job 0's history become visible at job 0's barrier; no vmcnt drain here)
+  if (DBG && wall)
+    wall[1] = wall_clock64();
 
-  // Software pipeline, one barrier per job. In job i (slot index u = i % kPrefetch):
-  //   barrier                      -> job i's LDS data (stashed during job i-1) and x published by job i-1 are visible
-  //   issue job i's LDS operand reads (tile values, shifted taps, constants)
-  //   stash job i+1 (slot u+1) into the OTHER halves of the double buffers, refill that slot with job i+1+kPrefetch
-  //   MFMA chain, activation, 1x1, publish x
-  for (int q0 = 0; q0 < total; q0 += kPrefetch)
+  // Software pipeline, one barrier per job. In job i (u = i % D):
+  //   barrier                 -> job i's history (dropped during job i-1) and x published by job i-1 are visible
+  //   issue job i's LDS operand reads (2 shifted taps + 3 constant vectors; weight tiles are in ta[u])
+  //   drop job i+1's history (slot u+1) into the OTHER halves of the double buffers, refill that slot with
+  //   job i+1+D; conv MFMAs; activation; 1x1; publish x; ring append; refill ta[u] with job i+D
+  for (int q0 = 0; q0 < total; q0 += D)
   {
 #pragma unroll
-    for (int u = 0; u < kPrefetch; u++)
+    for (int u = 0; u < D; u++)
     {
-      // NOTE: no branch around a whole job: past the end it degenerates to type -1 (barrier, stash and
-      // dummy prefetch only), which keeps the number of loads in flight statically known.
+      // NOTE: no branch around a whole job: past the end it degenerates to flags = 0 (barrier, history drop
+      // and dummy prefetch only), which keeps the number of loads in flight statically known.
       const bool active = q0 + u < total;
-      const MJob J = Jcur;
-      const MJob Jn = Jnext;
-      Jcur = Jnext;
-      {
-        int jn2 = ji + 2;
-        if (jn2 >= NJ)
-          jn2 -= NJ;
-        Jnext = P->mjobs[jn2];
-      }
-      const int type = active ? J.type : -1, C = J.C, CS = J.CS, buf = J.buf;
-      const int SC = C + 4;
-      const bool own = g < CS;
-      const int un = (u + 1) % kPrefetch; // constant after unrolling: slot[] stays in registers
-      long long* dbg = (a.dbg && blockIdx.x == 0 && tid == 0 && q0 + u < 96) ? a.dbg + (q0 + u) * 8 : nullptr;
-      if (dbg)
+      const MDesc J = Dn;
+      Dn = P->mdesc[ji + 1 == NJ ? 0 : ji + 1];
+      const int flags = active ? J.flags : 0;
+      const int un = (u + 1) % D; // constant after unrolling: slot[] stays in registers
+      long long* dbg = nullptr;
+      if constexpr (DBG)
+        dbg = (a.dbg && blockIdx.x == 0 && tid == 0 && q0 + u < 94) ? a.dbg + (q0 + u) * 8 : nullptr;
+      if (DBG && dbg)
         dbg[0] = __builtin_readcyclecounter();
       lds_barrier();
-      if (dbg)
+      if (DBG && dbg)
         dbg[1] = __builtin_readcyclecounter();
 
-      const int d = J.d, R = J.R, rid = J.ring_id, act = J.act;
-      // 1. operand reads of this job first (their latency starts now): 4 + 2 + 3 sixteen-byte LDS reads.
-      //    Straight-line for every job type (non-LAYER jobs have d = 0 and read valid, unused words) so
-      //    that the prefetch below is never inside a branch.
-      // lanes whose channel quad does not exist (g >= C/4) read quad 0: finite data that only ever meets zero weights
-      const int gq = own ? g : 0;
-      const float* __restrict__ tl = &lds[tl_off(tb) + lane * TL_PITCH];
-      const f4 a0 = *reinterpret_cast<const f4*>(tl), a1 = *reinterpret_cast<const f4*>(tl + 4),
-               a2 = *reinterpret_cast<const f4*>(tl + 8), a3 = *reinterpret_cast<const f4*>(tl + 12);
-      f4 bt[kOldTaps];
-#pragma unroll
-      for (int k = 0; k < kOldTaps; k++)
+      // 1. operand reads first (their latency starts now): 2 shifted taps + 3 constant vectors, 16 B each.
+      //    Lanes whose channel quad does not exist (g >= C/4) read the last real quad: finite data that
+      //    only ever meets zero weights.
+      const unsigned gq16 = min(v_g16, (unsigned)J.g16max);
+      const unsigned a_tap = v_tap + gq16;
+      const f4 bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
+      const f4 bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
+      const unsigned a_c = v_g16 + (unsigned)J.consts_b;
+      const f4 bv4 = lds_ld4(lds, a_c), mv = lds_ld4(lds, a_c + 64u), b1v = lds_ld4(lds, a_c + 128u);
+      if (DBG && dbg)
       {
-        const int L = (2 - k) * d;
-        const int o = (L <= kBlock) ? xw_off(buf) + (kBlock + frame - L) * SC : tb_off(buf, k) + frame * SC;
-        bt[k] = *reinterpret_cast<const f4*>(&lds[o + 4 * gq]);
-      }
-      const float* __restrict__ cst = &lds[CONSTS_OFF + J.consts + 4 * g];
-      const f4 bv4 = *reinterpret_cast<const f4*>(cst);
-      const f4 mv = *reinterpret_cast<const f4*>(cst + 16);
-      const f4 b1v = *reinterpret_cast<const f4*>(cst + 32);
-      if (dbg)
-      {
-        asm volatile("" ::"v"(bv4), "v"(mv), "v"(b1v), "v"(a3), "v"(bt[0]), "v"(bt[1]));
+        asm volatile("" ::"v"(bv4), "v"(mv), "v"(b1v), "v"(bt0), "v"(bt1));
         dbg[6] = __builtin_readcyclecounter();
       }
-      // 2. LAYER: append this layer's INPUT to its history ring (frame-major: 16 B per lane)
-      if (type == MJ_LAYER && rid >= 0 && own && frame < nvalid)
-      {
-        int widx = __builtin_amdgcn_readlane(wposv, rid) + frame;
-        if (widx >= R)
-          widx -= R;
-        *reinterpret_cast<f4*>(reinterpret_cast<char*>(st) + (size_t)J.ring_off * 4
-                               + (__umul24((unsigned)widx, (unsigned)C * 4u) + (unsigned)g * 16u)) = x;
-      }
-      // 3. successor: stash slot u+1 into the other halves of the double buffers and refill it with
-      //    the job kPrefetch ahead (LDS writes / VMEM issue overlap the MFMA chain below)
+      const f4 x_in = x; // the layer INPUT: appended to the history ring at the end of the job
+      // 2. successor: drop job i+1's history into LDS (3 x 16 B; quads beyond its C land in row padding),
+      //    then refill that slot with the history of job i+1+D
       const float inp_next = slot[un].inp;
-      stash(slot[un], Jn.C, Jn.CS, Jn.buf, tb ^ 1);
-      if (dbg)
+      lds_st4(lds, v_hist + (unsigned)J.st_win_b, slot[un].h[0]);
+      lds_st4(lds, v_hist + (unsigned)J.st_tb0_b, slot[un].h[1]);
+      lds_st4(lds, v_hist + (unsigned)J.st_tb1_b, slot[un].h[2]);
+      if (DBG && dbg)
         dbg[7] = __builtin_readcyclecounter();
       {
         const bool valid = fblk < n_blocks;
-        fetch(slot[un], Jfnext, valid && (fblk > blk), fblk);
-        if (++jf == NJ)
+        fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_cmul : 0, valid ? J.f_R : 64, valid ? J.f_L0 : 64,
+              valid ? J.f_L1 : 64, valid ? J.f_ring_id : 0, J.f_q16max, valid && (fblk > blk), valid ? fblk : blk);
+        if (++fj == NJ)
         {
-          jf = 0;
+          fj = 0;
           fblk++;
         }
-        Jfnext = P->mjobs[jf];
       }
-      if (dbg)
+      if (DBG && dbg)
         dbg[2] = __builtin_readcyclecounter();
 
-      // 4. dilated conv, 3 taps x 4 k-steps; tap 2 (the current frame) multiplies the lane's own x.
-      //    Two accumulators shorten the dependent chain. Issued for EVERY job type (non-LAYER jobs just
-      //    discard the result) so that the MFMAs share a basic block with the stash / prefetch code
-      //    above and the scheduler can interleave that VALU / LDS / VMEM work into the MFMA shadow.
+      // 3. dilated conv, 3 taps x 4 k-steps; tap 2 (the current frame) multiplies the lane's own x. Two
+      //    accumulators shorten the dependent chain. Issued for EVERY job type (others discard it) so the
+      //    MFMAs share a basic block with the code above.
       f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      acc0 = mfma4(a0, bt[0], acc0);
-      acc1 = mfma4(a1, bt[1], acc1);
-      acc0 = mfma4(a2, x, acc0);
+      acc0 = mfma4(ta[u][0], bt0, acc0);
+      acc1 = mfma4(ta[u][1], bt1, acc1);
+      acc0 = mfma4(ta[u][2], x, acc0);
       const f4 acc = acc0 + acc1;
-      if (type == MJ_LAYER)
+
+      if (flags & MD_LAYER)
       {
-        if (dbg)
+        if (DBG && dbg)
         {
           asm volatile("" ::"v"(acc));
           dbg[3] = __builtin_readcyclecounter();
         }
-        // 5. bias + input mixin + activation; head accumulate
+        // 4. bias + input mixin + activation; head accumulate
         f4 pre;
 #pragma unroll
         for (int r = 0; r < 4; r++)
           pre[r] = fmaf(mv[r], cond, acc[r] + bv4[r]);
-        const f4 z = act4(act, pre, act_p0);
+        const f4 z = act4<ACT_T>(J.act, pre, act_p0);
         head += z;
-        // 6. layer1x1: z is already this lane's B operand
-        const f4 y = mfma4(a3, z, f4{0.f, 0.f, 0.f, 0.f});
+        // 5. layer1x1: z is already this lane's B operand
+        const f4 y = mfma4(ta[u][3], z, f4{0.f, 0.f, 0.f, 0.f});
         x = x + (y + b1v);
-        if (dbg)
+        if (DBG && dbg)
         {
           asm volatile("" ::"v"(x));
           dbg[4] = __builtin_readcyclecounter();
         }
-        // 7. publish x (the next layer's input) into the other window buffer: one 16-byte write
-        if (own)
-          *reinterpret_cast<f4*>(&lds[xw_off(buf ^ 1) + (kBlock + frame) * SC + 4 * g]) = x;
+        // 6. publish x (the next layer's input) into the other window buffer; append the layer INPUT to its
+        //    history ring (frame-major: 16 B per lane). Lanes without real channels / frames stay out.
+        if (v_g16 <= (unsigned)J.g16max)
+        {
+          lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
+          if ((flags & MD_RING) && lane_live)
+          {
+            const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + frame);
+            const unsigned widx = min(v, v - (unsigned)J.R);
+            ring_store<WT>(stb, __umul24(widx, (unsigned)J.cmul) + v_g16 + (unsigned)J.ring_b, x_in);
+          }
+        }
       }
-      else if (type == MJ_RECH1)
+      else if (flags & MD_RECH1)
       {
         x = bv4 * cond; // consts[0..15] = rechannel column (in_size == 1)
         head = f4{0.f, 0.f, 0.f, 0.f};
-        if (own)
-          *reinterpret_cast<f4*>(&lds[xw_off(buf) + (kBlock + frame) * SC + 4 * g]) = x;
+        if (v_g16 <= (unsigned)J.g16max)
+          lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
       }
-      else if (type == MJ_RECH)
+      else if (flags & MD_RECH)
       {
         // the previous array's last-layer output is still in x (this lane's own channels)
-        x = mfma4(a0, x, f4{0.f, 0.f, 0.f, 0.f});
-        head = J.first ? f4{0.f, 0.f, 0.f, 0.f} : hprev;
-        if (own)
-          *reinterpret_cast<f4*>(&lds[xw_off(buf ^ 1) + (kBlock + frame) * SC + 4 * g]) = x;
+        x = mfma4(ta[u][0], x, f4{0.f, 0.f, 0.f, 0.f});
+        head = (flags & MD_FIRST) ? f4{0.f, 0.f, 0.f, 0.f} : hprev;
+        if (v_g16 <= (unsigned)J.g16max)
+          lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
       }
-      else if (type == MJ_HEAD) // hout[h] = bh[h] + sum_c Wh[h][c] * head[c]
+      else if (flags & MD_HEAD) // hout[h] = bh[h] + sum_c Wh[h][c] * head[c]
       {
-        hprev = mfma4(a0, head, f4{0.f, 0.f, 0.f, 0.f}) + bv4;
-        if (J.last && out && g == 0 && frame < nvalid)
+        hprev = mfma4(ta[u][0], head, f4{0.f, 0.f, 0.f, 0.f}) + bv4;
+        if ((flags & MD_LAST) && out && g == 0 && lane_live)
           out[(size_t)blk * kBlock + frame] = head_scale * hprev[0];
       }
-      if (dbg)
+      // 7. this job's weight tiles are consumed: refill the tile slot for the job D ahead
+      fetch_tiles(ta[u], jt);
+      if (++jt == NJ)
+        jt = 0;
+      if (DBG && dbg)
         dbg[5] = __builtin_readcyclecounter();
 
-      tb ^= 1;
       if (active && ++ji == NJ)
       {
         // block finished: advance every ring's write position, take the next block's input sample
@@ -996,12 +1008,15 @@ __global__ __launch_bounds__(256) void nam_a1_mfma_kernel(const A1Plan* __restri
           wposv -= ring_len_v;
         blk++;
         nvalid = min(kBlock, a.n_frames - blk * kBlock);
-        cond = (in && frame < nvalid) ? inp_next : 0.0f;
+        lane_live = frame < nvalid;
+        cond = (in && lane_live) ? inp_next : 0.0f;
       }
     }
   }
   if (w == 0 && lane < n_rings)
     wpos_tbl[lane] = wposv;
+  if (DBG && wall)
+    wall[2] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1150,9 +1165,30 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
   return hipGetLastError();
 }
 
-hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, hipStream_t stream)
+namespace
 {
-  hipLaunchKernelGGL(nam_a1_mfma_kernel, dim3(n_blocks), dim3(256), 0, stream, a.plan, a.blob, a);
+template <int ACT_T, bool DBG>
+void launch_a1_mfma_wt(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  // short launches write ring appends through (see ring_store)
+  if (a.n_frames <= 2 * kBlock)
+    hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, DBG, true>), dim3(n_blocks), dim3(256), 0, stream, a.plan, a.blob, a);
+  else
+    hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, DBG, false>), dim3(n_blocks), dim3(256), 0, stream, a.plan, a.blob, a);
+}
+} // namespace
+
+hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream)
+{
+  // activation resolved at compile time for the two types that matter; a timeline build for the developer tool
+  if (a.dbg)
+    launch_a1_mfma_wt<-1, true>(a, n_blocks, stream);
+  else if (act == ACT_FASTTANH)
+    launch_a1_mfma_wt<ACT_FASTTANH, false>(a, n_blocks, stream);
+  else if (act == ACT_TANH)
+    launch_a1_mfma_wt<ACT_TANH, false>(a, n_blocks, stream);
+  else
+    launch_a1_mfma_wt<-1, false>(a, n_blocks, stream);
   return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -210,11 +211,20 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.n_frames = n_frames;
       a.act_p0 = 0.01f;
       a.dbg = b->dbg;
-      for (const auto& arr : b->model->spec->wavenet.arrays)
-        if (!arr.activations.empty() && arr.activations[0].type == ACT_LEAKYRELU)
-          a.act_p0 = arr.activations[0].p[0];
+      a.n_rings = p.a1.n_rings;
+      a.n_mjobs = p.a1.n_mjobs;
+      a.tiles_off = p.a1.n_mjobs > 0 ? p.a1.mjobs[0].tiles : 0;
+      a.consts_off = p.a1.mconsts_off;
+      a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
       if (kernel == NAM_HIP_KERNEL_A1_MFMA)
-        NAM_HIP_CHECK(launch_a1_mfma(a, n, s));
+      {
+        // uniform activation across arrays -> compile-time specialised kernel, else run-time dispatch
+        int act = p.a1.arr[0].act;
+        for (int i = 1; i < p.a1.n_arrays; i++)
+          if (p.a1.arr[i].act != act)
+            act = -1;
+        NAM_HIP_CHECK(launch_a1_mfma(a, n, act, s));
+      }
       else
         NAM_HIP_CHECK(launch_a1(a, n, s));
     }

@@ -610,6 +610,48 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
     // that a late wave could still be reading; every block ends with HEAD jobs (no window traffic), so
     // any parity is safe there.
   }
+  // executable descriptors
+  for (int j = 0; j < n_jobs; j++)
+  {
+    const MJob& J = a1.mjobs[j];
+    const MJob& N = a1.mjobs[(j + 1) % n_jobs]; // successor: its history is dropped into LDS during job j
+    const int fj = (j + 1 + kMfPrefetch) % n_jobs; // job whose history is prefetched during job j
+    const MJob& F = a1.mjobs[fj];
+    MDesc& D = a1.mdesc[j];
+    std::memset(&D, 0, sizeof(D));
+    auto xw = [](int buf) { return kMfXwOff + buf * kMfXwFloats; };
+    auto tb = [](int buf, int tap) { return kMfTbOff + (buf * 2 + tap) * kMfTbFloats; };
+    D.flags = (J.type == MJ_LAYER ? MD_LAYER : 0) | (J.type == MJ_RECH1 ? MD_RECH1 : 0) | (J.type == MJ_RECH ? MD_RECH : 0)
+              | (J.type == MJ_HEAD ? MD_HEAD : 0) | (J.first ? MD_FIRST : 0) | (J.last ? MD_LAST : 0)
+              | ((J.type == MJ_LAYER && J.ring_id >= 0) ? MD_RING : 0) | ((F.type == MJ_LAYER && F.ring_id >= 0) ? MD_F_RING : 0)
+              | ((j + 1 + kMfPrefetch >= n_jobs) ? MD_F_NEXT : 0);
+    D.act = J.act;
+    D.g16max = 16 * (J.CS - 1);
+    D.consts_b = (kMfConstsOff + J.consts) * 4;
+    for (int k = 0; k < 2; k++)
+    {
+      const int L = (J.type == MJ_LAYER) ? (2 - k) * J.d : 0;
+      const int off = (L <= kBlock) ? xw(J.buf) + (kBlock - L) * kMfSC : tb(J.buf, k);
+      (k == 0 ? D.tap0_b : D.tap1_b) = off * 4;
+    }
+    const int pub_buf = (J.type == MJ_RECH1) ? J.buf : (J.buf ^ 1);
+    D.pub_b = (xw(pub_buf) + kBlock * kMfSC) * 4;
+    D.ring_b = J.ring_off * 4;
+    D.cmul = J.C * 4;
+    D.R = J.R > 0 ? J.R : 64;
+    D.ring_id = J.ring_id >= 0 ? J.ring_id : 0;
+    D.st_win_b = xw(N.buf) * 4;
+    D.st_tb0_b = tb(N.buf, 0) * 4;
+    D.st_tb1_b = tb(N.buf, 1) * 4;
+    const bool fr = F.type == MJ_LAYER && F.ring_id >= 0;
+    D.f_rbase = fr ? F.ring_off * 4 : 0;
+    D.f_cmul = fr ? F.C * 4 : 0;
+    D.f_R = fr ? F.R : 64;
+    D.f_L0 = fr ? 2 * F.d : 64;
+    D.f_L1 = fr ? F.d : 64;
+    D.f_ring_id = fr ? F.ring_id : 0;
+    D.f_q16max = 16 * (F.CS - 1);
+  }
   a1.mfma_ok = 1;
 }
 
@@ -653,8 +695,14 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
         if (plan.a1.arr[a].ring_id[l] >= 0)
           plan.a1.arr[a].ring_off[l] += table;
     for (int j = 0; j < plan.a1.n_mjobs; j++)
+    {
       if (plan.a1.mjobs[j].ring_id >= 0)
         plan.a1.mjobs[j].ring_off += table;
+      if (plan.a1.mdesc[j].flags & MD_RING)
+        plan.a1.mdesc[j].ring_b += table * 4;
+      if (plan.a1.mdesc[j].flags & MD_F_RING)
+        plan.a1.mdesc[j].f_rbase += table * 4;
+    }
   }
   return plan;
 }

@@ -128,6 +128,50 @@ struct MJob // 16 x int32
 static_assert(sizeof(MJob) == 64, "MJob must stay 64 bytes");
 constexpr int kMJobMax = 40;
 
+// LDS geometry of nam_a1_mfma_kernel (shared by the host, which precomputes every per-job LDS offset)
+constexpr int kMfSC = 24; // floats per frame row: 6 sixteen-byte slots => conflict-free ds_read_b128 for lane (g, j)
+constexpr int kMfPrefetch = 4; // jobs of global loads in flight
+constexpr int kMfXwFloats = 2 * kBlock * kMfSC; // one window: [previous 64 | current 64] frames
+constexpr int kMfTbFloats = kBlock * kMfSC; // one tap buffer: 64 frames
+constexpr int kMfXwOff = 0; // window [2 buffers]
+constexpr int kMfTbOff = kMfXwOff + 2 * kMfXwFloats; // tap buffers [2 buffers][2 taps]
+constexpr int kMfConstsOff = kMfTbOff + 4 * kMfTbFloats; // consts [jobs][48]
+constexpr int kMfLdsFloats = kMfConstsOff + kMJobMax * 48;
+
+// Per-job descriptor the kernel actually executes from: everything that can be decided on the host is —
+// LDS byte offsets, ring geometry of this job, where the SUCCESSOR's history is dropped, and the ring
+// geometry of the job whose history is prefetched now (kMfPrefetch + 1 jobs ahead).
+enum MDescFlags : int32_t
+{
+  MD_LAYER = 1,
+  MD_RECH1 = 2,
+  MD_RECH = 4,
+  MD_HEAD = 8,
+  MD_FIRST = 16, // head accumulator starts at zero
+  MD_LAST = 32, // produces the output sample
+  MD_RING = 64, // this job appends its input to a history ring
+  MD_F_RING = 256, // the prefetched job has a ring
+  MD_F_NEXT = 512 // the prefetched job belongs to the next block
+};
+
+struct MDesc // 24 x int32
+{
+  int32_t flags;
+  int32_t act;
+  int32_t g16max; // 16 * (C/4 - 1): clamp for the lane's channel-quad byte offset
+  int32_t consts_b; // LDS byte offset of this job's 48 constants
+  int32_t tap0_b, tap1_b; // LDS byte offset of frame 0 of tap k's operand rows (window: already shifted by 64 - L)
+  int32_t pub_b; // LDS byte offset of frame 0 of the window rows x is published to
+  int32_t ring_b; // byte offset of this job's ring inside the stream state
+  int32_t cmul; // bytes per ring frame (C * 4)
+  int32_t R; // ring length in frames
+  int32_t ring_id;
+  int32_t st_win_b, st_tb0_b, st_tb1_b; // LDS byte offsets where the SUCCESSOR's history sets are dropped
+  int32_t f_rbase, f_cmul, f_R, f_L0, f_L1, f_ring_id, f_q16max; // the prefetched job's ring geometry
+  int32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(MDesc) == 96, "MDesc must stay 96 bytes");
+
 struct A1Plan
 {
   int32_t valid = 0;
@@ -141,6 +185,7 @@ struct A1Plan
   int32_t ring_len_by_id[64]; // R of ring r (for the per-block write-position update)
   A1Array arr[kA1MaxArrays];
   MJob mjobs[kMJobMax];
+  MDesc mdesc[kMJobMax];
 };
 
 // ---- LSTM ------------------------------------------------------------------------------------
