@@ -1165,6 +1165,280 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
   return hipGetLastError();
 }
 
+// ================================================================================================
+// nam_a1_ws_kernel — wave-specialised version of the MFMA kernel: 8 wavefronts per stream.
+//   waves 0-3 (compute): per job one barrier, 7 LDS operand reads, 16-20 MFMAs, activation, publish x,
+//                        prefetch of the weight tiles kWsTilePrefetch jobs ahead. No history traffic.
+//   waves 4-7 (movers) : per job drop the successor's prefetched history (3 x 16 B per lane) into the LDS
+//                        double buffers, append the job's input rows (LDS window) to its HBM ring, and
+//                        issue the history loads of the job kWsPrefetch + 1 ahead. At block boundaries
+//                        they also materialise x0 = rechannel * input and the input samples in LDS.
+// Each SIMD hosts one compute and one mover wave, so address arithmetic / memory instructions of the mover
+// fill the issue slots the compute wave leaves between dependent MFMA / VALU instructions.
+// Jobs are LAYERS only (plan.h: CDesc / VDesc); rechannel and head steps ride on neighbouring layer jobs.
+// ================================================================================================
+namespace ws
+{
+using mf::f4;
+constexpr int SC = kMfSC;
+constexpr int D = kWsPrefetch;
+constexpr int DT = kWsTilePrefetch;
+struct HSlot
+{
+  f4 h[3]; // [0] previous 64 frames (window), [1] tap 0 (lookback 2d), [2] tap 1 (lookback d)
+  float inp; // input sample of frame hfr of the block the job belongs to
+};
+} // namespace ws
+
+template <int ACT_T, bool WT>
+__global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict__ P, const float* __restrict__ blob,
+                                                        const A1Args a)
+{
+  using namespace mf;
+  using ws::HSlot;
+  constexpr int SC = ws::SC;
+  __shared__ __attribute__((aligned(16))) float lds_f[kWsLdsFloats];
+  char* const lds = reinterpret_cast<char*>(lds_f);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = uni(tid >> 6);
+  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  float* st = a.state + (size_t)stream * a.state_stride;
+  char* stb = reinterpret_cast<char*>(st);
+  const int NJ = a.n_mjobs;
+  const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
+  const int total = n_blocks * NJ;
+  const int total_pad = (total + kWsUnroll - 1) / kWsUnroll * kWsUnroll; // both roles: same number of barriers
+
+  // constants table -> LDS (all 512 threads; visible at the first barrier)
+  {
+    const float* __restrict__ csrc = blob + a.consts_off;
+    constexpr int N = (kMJobMax * 64 + 511) / 512;
+    float cv[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      cv[i] = (tid + 512 * i < NJ * 64) ? csrc[tid + 512 * i] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (tid + 512 * i < kMJobMax * 64)
+        lds_f[kWsConstsOff + tid + 512 * i] = cv[i];
+  }
+
+  if (w < 4)
+  {
+    // ------------------------------------------------ compute role ------------------------------------
+    constexpr int DT = ws::DT;
+    const int g = lane >> 4; // channel quad: this lane owns channels 4g..4g+3
+    const int frame = 16 * w + (lane & 15);
+    float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
+    const float head_scale = a.head_scale;
+    const float act_p0 = a.act_p0;
+    const unsigned v_g16 = (unsigned)g * 16u;
+    const unsigned v_tap = (unsigned)(frame * SC) * 4u;
+    const unsigned v_cond = (unsigned)(kWsCondOff + frame) * 4u;
+    const char* tiles0 = reinterpret_cast<const char*>(blob + a.tiles_off);
+    const unsigned v_tile = (unsigned)lane * 80u;
+    auto fetch_tiles = [&](f4 (&t)[5], int job) {
+      const char* tp = tiles0 + (size_t)job * (kWsTileFloats * 4);
+#pragma unroll
+      for (int q = 0; q < 5; q++)
+        t[q] = *reinterpret_cast<const f4*>(tp + (v_tile + 16u * q));
+    };
+    f4 ta[DT][5];
+#pragma unroll
+    for (int u = 0; u < DT; u++)
+      fetch_tiles(ta[u], u); // NJ >= kWsPrefetch + 2 > DT
+    f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f};
+    int ji = 0, blk = 0, jt = DT;
+    int nvalid = min(kBlock, a.n_frames);
+    CDesc Dn = P->cdesc[0];
+    for (int q0 = 0; q0 < total_pad; q0 += DT)
+    {
+#pragma unroll
+      for (int u = 0; u < DT; u++)
+      {
+        const bool active = q0 + u < total;
+        const CDesc J = Dn;
+        Dn = P->cdesc[ji + 1 == NJ ? 0 : ji + 1];
+        const int flags = active ? J.flags : 0;
+        lds_barrier();
+        // operand reads: 2 shifted taps, 4 constant vectors, the frame's input sample
+        const unsigned gq16 = min(v_g16, (unsigned)J.g16max);
+        const unsigned a_tap = v_tap + gq16;
+        const f4 bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
+        const f4 bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
+        const unsigned a_c = v_g16 + (unsigned)J.consts_b;
+        const f4 bv4 = lds_ld4(lds, a_c), mv = lds_ld4(lds, a_c + 64u), b1v = lds_ld4(lds, a_c + 128u);
+        const f4 ev = lds_ld4(lds, a_c + 192u);
+        const float cond = *reinterpret_cast<const float*>(lds + (v_cond + (unsigned)(blk & 1) * (kBlock * 4u)));
+        if (flags & CD_X0)
+        {
+          x = ev * cond; // ev = first array's rechannel column (in_size == 1)
+          head = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        else if (flags & CD_PRE_HEAD)
+          head = mfma4(ta[u][4], head, f4{0.f, 0.f, 0.f, 0.f}) + ev; // previous array's head rechannel + bias
+        // dilated conv: 3 taps x 4 k-steps; tap 2 (current frame) multiplies the lane's own x
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        acc0 = mfma4(ta[u][0], bt0, acc0);
+        acc1 = mfma4(ta[u][1], bt1, acc1);
+        acc0 = mfma4(ta[u][2], x, acc0);
+        const f4 acc = acc0 + acc1;
+        if (flags & CD_LAYER)
+        {
+          f4 pre;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            pre[r] = fmaf(mv[r], cond, acc[r] + bv4[r]);
+          const f4 z = act4<ACT_T>(J.act, pre, act_p0);
+          head += z;
+          const f4 y = mfma4(ta[u][3], z, f4{0.f, 0.f, 0.f, 0.f});
+          x = x + (y + b1v);
+          if (flags & CD_POST_OUT)
+          {
+            const f4 hout = mfma4(ta[u][4], head, f4{0.f, 0.f, 0.f, 0.f}) + ev;
+            if (out && g == 0 && frame < nvalid)
+              out[(size_t)blk * kBlock + frame] = head_scale * hout[0];
+          }
+          else
+          {
+            if (flags & CD_POST_RECH)
+              x = mfma4(ta[u][4], x, f4{0.f, 0.f, 0.f, 0.f}); // next array's rechannel (no bias)
+            if (v_g16 <= (unsigned)J.pubmax)
+              lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
+          }
+        }
+        fetch_tiles(ta[u], jt);
+        if (++jt == NJ)
+          jt = 0;
+        if (active && ++ji == NJ)
+        {
+          ji = 0;
+          blk++;
+          nvalid = min(kBlock, a.n_frames - blk * kBlock);
+        }
+      }
+    }
+  }
+  else
+  {
+    // ------------------------------------------------ mover role --------------------------------------
+    constexpr int D = ws::D;
+    const int hfr = 16 * (w - 4) + (lane >> 2); // frame inside a 64-frame set
+    const unsigned v_hq16 = (unsigned)(lane & 3) * 16u; // channel quad
+    const unsigned v_hist = (unsigned)(hfr * SC + 4 * (lane & 3)) * 4u;
+    int* wpos_tbl = reinterpret_cast<int*>(st);
+    const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
+    const char* ibase = in ? reinterpret_cast<const char*>(in) : stb; // silence: any valid word, masked later
+    int wposv = wpos_tbl[lane]; // lane r = write position of ring r
+    const int ring_len_v = P->ring_len_by_id[lane];
+    const f4 r1q = *reinterpret_cast<const f4*>(blob + a.r1_off + 4 * (lane & 3));
+
+    auto fetch = [&](HSlot& s, int f_rbase, int f_R, int f_L1, int f_ring_id, int f_q16max, bool next_block, int jblk) {
+      int wp = __builtin_amdgcn_readlane(wposv, f_ring_id);
+      if (next_block)
+      {
+        wp += kBlock;
+        if (wp >= f_R)
+          wp -= f_R;
+      }
+      const unsigned vq = min(v_hq16, (unsigned)f_q16max) + (unsigned)f_rbase;
+      const unsigned cmul = (unsigned)f_q16max + 16u;
+      const int Ls[3] = {kBlock, 2 * f_L1, f_L1};
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+      {
+        int sb = wp - Ls[t];
+        if (sb < 0)
+          sb += f_R;
+        const unsigned v = (unsigned)(hfr + sb);
+        const unsigned idx = min(v, v - (unsigned)f_R);
+        s.h[t] = *reinterpret_cast<const f4*>(stb + (__umul24(idx, cmul) + vq));
+      }
+      int fi = jblk * kBlock + hfr;
+      fi = min(fi, a.n_frames - 1);
+      s.inp = *reinterpret_cast<const float*>(ibase + (in ? (unsigned)fi * 4u : 0u));
+    };
+    // drop a job's history into LDS; for a block's first job also x0 and the input samples
+    auto drop = [&](const HSlot& s, const VDesc& J, int succ_blk) {
+      lds_st4(lds, v_hist + (unsigned)J.st_win_b, s.h[0]);
+      lds_st4(lds, v_hist + (unsigned)J.st_tb0_b, s.h[1]);
+      lds_st4(lds, v_hist + (unsigned)J.st_tb1_b, s.h[2]);
+      if (J.flags & MV_SUCC_FIRST)
+      {
+        const bool live = in && (succ_blk * kBlock + hfr < a.n_frames);
+        const float iv = live ? s.inp : 0.0f;
+        lds_st4(lds, v_hist + (unsigned)J.st_win_b + (unsigned)(kBlock * SC * 4), r1q * iv);
+        if ((lane & 3) == 0)
+          lds_f[kWsCondOff + (succ_blk & 1) * kBlock + hfr] = iv;
+      }
+    };
+
+    HSlot slot[D];
+#pragma unroll
+    for (int u = 0; u < D; u++)
+    {
+      const VDesc F = P->vdesc[u + NJ - 1 - D]; // the descriptor whose f_* fields describe job u
+      fetch(slot[u], F.f_rbase, F.f_R, F.f_L1, F.f_ring_id, F.f_q16max, false, 0);
+    }
+    int ji = 0, blk = 0;
+    int fj = D + 1, fblk = 0; // job / block whose history is fetched next
+    int nvalid = min(kBlock, a.n_frames);
+    {
+      // "job -1": job 0's history (and x0 / inputs of block 0) go to LDS, slot 0 is refilled with job D
+      const VDesc J = P->vdesc[NJ - 1];
+      drop(slot[0], J, 0);
+      fetch(slot[0], J.f_rbase, J.f_R, J.f_L1, J.f_ring_id, J.f_q16max, false, 0);
+    }
+    VDesc Dn = P->vdesc[0];
+    for (int q0 = 0; q0 < total_pad; q0 += D)
+    {
+#pragma unroll
+      for (int u = 0; u < D; u++)
+      {
+        const bool active = q0 + u < total;
+        const VDesc J = Dn;
+        Dn = P->vdesc[ji + 1 == NJ ? 0 : ji + 1];
+        const int flags = active ? J.flags : 0;
+        const int un = (u + 1) % D;
+        lds_barrier();
+        // this job's input rows (published by the previous job / dropped as x0) -> history ring
+        if ((flags & MV_RING) && hfr < nvalid && v_hq16 <= (unsigned)J.q16max)
+        {
+          const f4 xin = lds_ld4(lds, v_hist + (unsigned)J.ap_src_b);
+          const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + hfr);
+          const unsigned widx = min(v, v - (unsigned)J.R);
+          ring_store<WT>(stb, __umul24(widx, (unsigned)J.q16max + 16u) + v_hq16 + (unsigned)J.ring_b, xin);
+        }
+        // successor's history -> LDS (other halves of the double buffers), then refill the slot
+        drop(slot[un], J, blk + 1);
+        {
+          const bool valid = fblk < n_blocks;
+          fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_R : 64, valid ? J.f_L1 : 32, valid ? J.f_ring_id : 0,
+                valid ? J.f_q16max : 0, valid && (fblk > blk), valid ? fblk : blk);
+          if (++fj == NJ)
+          {
+            fj = 0;
+            fblk++;
+          }
+        }
+        if (active && ++ji == NJ)
+        {
+          ji = 0;
+          wposv += nvalid;
+          if (wposv >= ring_len_v)
+            wposv -= ring_len_v;
+          blk++;
+          nvalid = min(kBlock, a.n_frames - blk * kBlock);
+        }
+      }
+    }
+    if (w == 4 && lane < a.n_rings)
+      wpos_tbl[lane] = wposv;
+  }
+}
+
 namespace
 {
 template <int ACT_T, bool DBG>
@@ -1189,6 +1463,36 @@ hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t st
     launch_a1_mfma_wt<ACT_TANH, false>(a, n_blocks, stream);
   else
     launch_a1_mfma_wt<-1, false>(a, n_blocks, stream);
+  return hipGetLastError();
+}
+
+hipError_t launch_a1_ws(const A1Args& a, int n_blocks, int act, hipStream_t stream)
+{
+  const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
+#define NAM_WS_LAUNCH(ACT, WT) \
+  hipLaunchKernelGGL((nam_a1_ws_kernel<ACT, WT>), dim3(n_blocks), dim3(512), 0, stream, a.plan, a.blob, a)
+  if (act == ACT_FASTTANH)
+  {
+    if (wt)
+      NAM_WS_LAUNCH(ACT_FASTTANH, true);
+    else
+      NAM_WS_LAUNCH(ACT_FASTTANH, false);
+  }
+  else if (act == ACT_TANH)
+  {
+    if (wt)
+      NAM_WS_LAUNCH(ACT_TANH, true);
+    else
+      NAM_WS_LAUNCH(ACT_TANH, false);
+  }
+  else
+  {
+    if (wt)
+      NAM_WS_LAUNCH(-1, true);
+    else
+      NAM_WS_LAUNCH(-1, false);
+  }
+#undef NAM_WS_LAUNCH
   return hipGetLastError();
 }
 

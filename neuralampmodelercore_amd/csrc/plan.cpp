@@ -375,6 +375,185 @@ bool a1_channel_supported(int c)
   return c == 1 || c == 2 || c == 3 || c == 4 || c == 6 || c == 8 || c == 12 || c == 16;
 }
 
+// Job table of nam_a1_ws_kernel (plan.h: CDesc / VDesc). Requires what build_a1's MFMA table requires, plus
+// at least two layers per array (the extra tile of a job serves either its array's entry or its exit).
+void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
+{
+  A1Plan& a1 = plan.a1;
+  const int n_arrays = (int)wn.arrays.size();
+  int n_layers = 0;
+  for (const auto& A : wn.arrays)
+  {
+    if (A.num_layers() < 2)
+      return;
+    n_layers += A.num_layers();
+  }
+  if (wn.arrays[0].input_size != 1)
+    return;
+  const int NJ = (n_layers + 1) / 2 * 2;
+  if (NJ > kMJobMax || NJ < kWsPrefetch + 2)
+    return;
+  while (plan.blob.size() % 64)
+    plan.blob.push_back(0.0f);
+  a1.ws_tiles_off = (int)plan.blob.size();
+  plan.blob.resize(plan.blob.size() + (size_t)NJ * kWsTileFloats, 0.0f);
+  a1.ws_consts_off = (int)plan.blob.size();
+  plan.blob.resize(plan.blob.size() + (size_t)NJ * 64, 0.0f);
+  a1.ws_r1_off = (int)plan.blob.size();
+  plan.blob.resize(plan.blob.size() + 64, 0.0f);
+  a1.ws_jobs = NJ;
+  auto tile_at = [&](int job, int tile, int o, int in_idx) -> float& {
+    // A-operand element W[o][in_idx] of v_mfma_f32_16x16x4_f32: input channel 4g + s is fed by lane group g
+    // in k-step s, so it lives in lane (g, o) of tile `tile` = tile_base + s; lane-major [lane][20].
+    const int g = in_idx / 4;
+    return plan.blob[(size_t)a1.ws_tiles_off + (size_t)job * kWsTileFloats + (size_t)(g * 16 + o) * 20 + tile];
+  };
+  auto const_at = [&](int job, int vec, int i) -> float& { return plan.blob[(size_t)a1.ws_consts_off + (size_t)job * 64 + vec * 16 + i]; };
+
+  // where each array's pieces sit in the weight stream (same order as build_a1 walks it)
+  struct Ptrs
+  {
+    const float* rech;
+    std::vector<const float*> layer;
+    const float* head;
+  };
+  std::vector<Ptrs> ptrs(n_arrays);
+  {
+    const float* w = wn.weights.data();
+    for (int ai = 0; ai < n_arrays; ai++)
+    {
+      const LayerArraySpec& A = wn.arrays[ai];
+      const int C = A.channels, K = A.kernel_sizes[0], H = A.head_size;
+      ptrs[ai].rech = w;
+      w += (size_t)C * A.input_size;
+      for (int l = 0; l < A.num_layers(); l++)
+      {
+        ptrs[ai].layer.push_back(w);
+        w += (size_t)C * C * K + C + C + (size_t)C * C + C;
+      }
+      ptrs[ai].head = w;
+      w += (size_t)H * C + (A.head_bias ? H : 0);
+    }
+  }
+  auto xw = [](int buf) { return kMfXwOff + buf * kMfXwFloats; };
+  auto tb = [](int buf, int tap) { return kMfTbOff + (buf * 2 + tap) * kMfTbFloats; };
+  struct JobGeo
+  {
+    int C = 4, d = 0, R = 64, ring_off = 0, ring_id = 0, real = 0;
+  };
+  std::vector<JobGeo> geo(NJ);
+  std::memset(a1.cdesc, 0, sizeof(a1.cdesc));
+  std::memset(a1.vdesc, 0, sizeof(a1.vdesc));
+  int ji = 0;
+  for (int ai = 0; ai < n_arrays; ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    const A1Array& arr = a1.arr[ai];
+    const int C = A.channels, K = A.kernel_sizes[0], H = A.head_size;
+    const int NL = A.num_layers();
+    for (int l = 0; l < NL; l++, ji++)
+    {
+      CDesc& D = a1.cdesc[ji];
+      JobGeo& G = geo[ji];
+      G.C = C;
+      G.d = A.dilations[l];
+      G.R = arr.ring_len[l];
+      G.ring_off = arr.ring_off[l];
+      G.ring_id = arr.ring_id[l];
+      G.real = 1;
+      const float* w = ptrs[ai].layer[l];
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < C; ci++)
+          for (int k = 0; k < K; k++)
+            tile_at(ji, k * 4 + ci % 4, co, ci) = *(w++);
+      for (int co = 0; co < C; co++)
+        const_at(ji, 0, co) = *(w++);
+      for (int co = 0; co < C; co++)
+        const_at(ji, 1, co) = *(w++);
+      for (int co = 0; co < C; co++)
+        for (int ci = 0; ci < C; ci++)
+          tile_at(ji, 12 + ci % 4, co, ci) = *(w++);
+      for (int co = 0; co < C; co++)
+        const_at(ji, 2, co) = *(w++);
+      D.flags = CD_LAYER;
+      D.act = A.activations[0].type;
+      D.g16max = 16 * (C / 4 - 1);
+      D.pubmax = D.g16max;
+      auto head_into = [&](int src_array) { // extra tile = head rechannel of src_array, extra consts = its bias
+        const LayerArraySpec& S = wn.arrays[src_array];
+        const float* hw = ptrs[src_array].head;
+        for (int h = 0; h < S.head_size; h++)
+          for (int c = 0; c < S.channels; c++)
+            tile_at(ji, 16 + c % 4, h, c) = *(hw++);
+        for (int h = 0; h < S.head_size; h++)
+          const_at(ji, 3, h) = S.head_bias ? *(hw++) : 0.0f;
+      };
+      if (l == 0 && ai == 0)
+      {
+        D.flags |= CD_X0;
+        for (int co = 0; co < C; co++)
+        {
+          const_at(ji, 3, co) = ptrs[0].rech[co];
+          plan.blob[(size_t)a1.ws_r1_off + co] = ptrs[0].rech[co];
+        }
+      }
+      else if (l == 0)
+      {
+        D.flags |= CD_PRE_HEAD;
+        head_into(ai - 1);
+      }
+      if (l == NL - 1 && ai + 1 < n_arrays)
+      {
+        D.flags |= CD_POST_RECH;
+        const LayerArraySpec& N = wn.arrays[ai + 1];
+        const float* rw = ptrs[ai + 1].rech; // [co][ci], no bias
+        for (int co = 0; co < N.channels; co++)
+          for (int ci = 0; ci < N.input_size; ci++)
+            tile_at(ji, 16 + ci % 4, co, ci) = *(rw++);
+        D.pubmax = 16 * (N.channels / 4 - 1);
+      }
+      else if (l == NL - 1)
+      {
+        D.flags |= CD_POST_OUT;
+        head_into(ai);
+      }
+      (void)H;
+    }
+  }
+  for (int j = 0; j < NJ; j++)
+  {
+    const JobGeo& G = geo[j];
+    const int buf = j & 1;
+    CDesc& D = a1.cdesc[j];
+    D.consts_b = (kWsConstsOff + j * 64) * 4;
+    for (int k = 0; k < 2; k++)
+    {
+      const int L = G.real ? (2 - k) * G.d : 0;
+      const int off = (L <= kBlock) ? xw(buf) + (kBlock - L) * kMfSC : tb(buf, k);
+      (k == 0 ? D.tap0_b : D.tap1_b) = off * 4;
+    }
+    D.pub_b = (xw(buf ^ 1) + kBlock * kMfSC) * 4;
+    VDesc& V = a1.vdesc[j];
+    const int nbuf = (j + 1) & 1;
+    const JobGeo& F = geo[(j + 1 + kWsPrefetch) % NJ];
+    V.flags = (G.real ? MV_RING : 0) | (j == NJ - 1 ? MV_SUCC_FIRST : 0);
+    V.st_win_b = xw(nbuf) * 4;
+    V.st_tb0_b = tb(nbuf, 0) * 4;
+    V.st_tb1_b = tb(nbuf, 1) * 4;
+    V.f_rbase = F.real ? F.ring_off * 4 : 0;
+    V.f_R = F.real ? F.R : 64;
+    V.f_L1 = F.real ? F.d : 32;
+    V.f_ring_id = F.real ? F.ring_id : 0;
+    V.f_q16max = F.real ? 16 * (F.C / 4 - 1) : 0;
+    V.ap_src_b = (xw(buf) + kBlock * kMfSC) * 4;
+    V.ring_b = G.ring_off * 4;
+    V.R = G.real ? G.R : 64;
+    V.ring_id = G.real ? G.ring_id : 0;
+    V.q16max = 16 * (G.C / 4 - 1);
+  }
+  a1.ws_ok = 1;
+}
+
 void build_a1(const WaveNetSpec& wn, Plan& plan)
 {
   A1Plan& a1 = plan.a1;
@@ -653,6 +832,7 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
     D.f_q16max = 16 * (F.CS - 1);
   }
   a1.mfma_ok = 1;
+  build_a1_ws(wn, plan);
 }
 
 } // namespace
@@ -702,6 +882,13 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
         plan.a1.mdesc[j].ring_b += table * 4;
       if (plan.a1.mdesc[j].flags & MD_F_RING)
         plan.a1.mdesc[j].f_rbase += table * 4;
+    }
+    for (int j = 0; j < plan.a1.ws_jobs; j++)
+    {
+      // (an idle job has ring_b == 0 and never appends; its prefetch geometry points at the table, harmless)
+      if (plan.a1.vdesc[j].flags & MV_RING)
+        plan.a1.vdesc[j].ring_b += table * 4;
+      plan.a1.vdesc[j].f_rbase += table * 4;
     }
   }
   return plan;

@@ -172,6 +172,54 @@ struct MDesc // 24 x int32
 };
 static_assert(sizeof(MDesc) == 96, "MDesc must stay 96 bytes");
 
+// ---- wave-specialised MFMA kernel (nam_a1_ws_kernel): one job per LAYER -------------------------------
+// The rechannel / head-rechannel steps ride on the neighbouring layer jobs (one extra weight tile + one
+// extra constant vector per job), so a block is exactly n_layers jobs (+1 idle job when that is odd: the
+// LDS double buffers alternate per job and must come back to parity 0 at the start of every block).
+// Compute waves (0-3) and mover waves (4-7) execute from separate descriptors.
+constexpr int kWsPrefetch = 6; // mover: jobs of history loads in flight
+constexpr int kWsTilePrefetch = 3; // compute: jobs of weight tiles in flight
+constexpr int kWsUnroll = 6; // both loops run a multiple of this many jobs (same number of barriers)
+constexpr int kWsTileFloats = 64 * 20; // per job: [lane][5 tiles x 4]: conv tap 0,1,2 | layer1x1 | extra
+constexpr int kWsConstsOff = kMfTbOff + 4 * kMfTbFloats; // consts [jobs][64]: bias | mixin | 1x1 bias | extra
+constexpr int kWsCondOff = kWsConstsOff + kMJobMax * 64; // input samples [block parity][64]
+constexpr int kWsLdsFloats = kWsCondOff + 2 * kBlock;
+static_assert(kWsLdsFloats * 4 <= 65536, "nam_a1_ws_kernel uses static LDS");
+
+enum CDescFlags : int32_t
+{
+  CD_LAYER = 1,
+  CD_X0 = 2, // first job of a block: x = rechannel column (extra consts) * input sample, head = 0
+  CD_PRE_HEAD = 4, // first layer of a later array: head = HeadW(prev array) . head + head bias (extra tile / consts)
+  CD_POST_RECH = 8, // last layer of a non-final array: x = RechW(next array) . x (extra tile) before publishing
+  CD_POST_OUT = 16 // last layer of the final array: out = head_scale * (HeadW . head + head bias)[0]
+};
+struct CDesc // 8 x int32, one s_load_dwordx8
+{
+  int32_t flags;
+  int32_t act;
+  int32_t g16max; // 16 * (C/4 - 1): clamp for the lane's channel-quad byte offset when reading operands
+  int32_t consts_b; // LDS byte offset of this job's 64 constants
+  int32_t tap0_b, tap1_b; // LDS byte offset of frame 0 of tap k's operand rows
+  int32_t pub_b; // LDS byte offset of frame 0 of the window rows x is published to
+  int32_t pubmax; // 16 * (C_published/4 - 1): lanes beyond do not publish
+};
+enum VDescFlags : int32_t
+{
+  MV_RING = 1, // append this job's input (window rows of its buffer) to its history ring
+  MV_SUCC_FIRST = 2 // the successor is the next block's first job: also drop x0 = rechannel * input and the input itself
+};
+struct VDesc // 16 x int32, one s_load_dwordx16
+{
+  int32_t flags;
+  int32_t st_win_b, st_tb0_b, st_tb1_b; // LDS byte offsets where the SUCCESSOR's history sets are dropped
+  int32_t f_rbase, f_R, f_L1, f_ring_id, f_q16max; // ring geometry of the job prefetched now (kWsPrefetch + 1 ahead)
+  int32_t ap_src_b; // LDS byte offset of frame 0 of this job's input rows (current half of its window)
+  int32_t ring_b, R, ring_id, q16max; // this job's ring
+  int32_t pad0, pad1;
+};
+static_assert(sizeof(CDesc) == 32 && sizeof(VDesc) == 64, "descriptor sizes are part of the kernel ABI");
+
 struct A1Plan
 {
   int32_t valid = 0;
@@ -186,6 +234,13 @@ struct A1Plan
   A1Array arr[kA1MaxArrays];
   MJob mjobs[kMJobMax];
   MDesc mdesc[kMJobMax];
+  // wave-specialised kernel
+  int32_t ws_ok = 0;
+  int32_t ws_jobs = 0; // jobs per block (even)
+  int32_t ws_tiles_off = 0, ws_consts_off = 0, ws_r1_off = 0; // blob offsets: tiles [jobs][1280], consts [jobs][64], 16 floats
+  int32_t ws_pad = 0;
+  CDesc cdesc[kMJobMax];
+  VDesc vdesc[kMJobMax];
 };
 
 // ---- LSTM ------------------------------------------------------------------------------------
