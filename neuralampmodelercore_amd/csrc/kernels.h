@@ -43,7 +43,10 @@ struct A1Args
   int n_rings, n_mjobs;
   int tiles_off, consts_off; // blob offsets (floats) of the tile areas / consts table
   float head_scale;
-  int r1_off; // wave-specialised kernel: blob offset of the first array's rechannel column (16 floats)
+  // wave-specialised kernel
+  int r1_off; // blob offset of the first array's rechannel column (16 floats)
+  int xt_off, n_xt; // blob offset / count of the extra tiles
+  int lds_tiles_b, lds_xt_b, lds_cond_b, lds_bytes; // dynamic LDS layout (bytes)
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 

@@ -1166,38 +1166,51 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
 }
 
 // ================================================================================================
-// nam_a1_ws_kernel — wave-specialised version of the MFMA kernel: 8 wavefronts per stream.
-//   waves 0-3 (compute): per job one barrier, 7 LDS operand reads, 16-20 MFMAs, activation, publish x,
-//                        prefetch of the weight tiles kWsTilePrefetch jobs ahead. No history traffic.
-//   waves 4-7 (movers) : per job drop the successor's prefetched history (3 x 16 B per lane) into the LDS
-//                        double buffers, append the job's input rows (LDS window) to its HBM ring, and
-//                        issue the history loads of the job kWsPrefetch + 1 ahead. At block boundaries
-//                        they also materialise x0 = rechannel * input and the input samples in LDS.
-// Each SIMD hosts one compute and one mover wave, so address arithmetic / memory instructions of the mover
+// nam_a1_ws_kernel — wave-specialised MFMA kernel: 8 wavefronts per stream, one job per LAYER.
+//   waves 0-3 (compute): per job one barrier, 3 LDS reads on the critical path (two shifted taps + the input
+//                        sample), 16-20 MFMAs, activation, publish x. The job's weight tiles and constants are
+//                        already in registers: they are read from LDS one job ahead, in the shadow of the MFMAs.
+//                        No vector-memory instructions except the output store.
+//   waves 4-7 (movers) : per job drop the successor's prefetched history (3 x 16 B per lane) and the weight
+//                        tiles of the job after it (16 B per lane) into the LDS double buffers, append the
+//                        job's input rows (LDS window) to its HBM ring, and issue the loads of the job
+//                        kWsPrefetch + 1 ahead. At block boundaries they also materialise
+//                        x0 = rechannel * input and the input samples in LDS.
+// Each SIMD hosts one compute and one mover wave, so the mover's address arithmetic / memory instructions
 // fill the issue slots the compute wave leaves between dependent MFMA / VALU instructions.
-// Jobs are LAYERS only (plan.h: CDesc / VDesc); rechannel and head steps ride on neighbouring layer jobs.
+// Rechannel and head-rechannel steps ride on the neighbouring layer jobs (plan.h: CDesc / VDesc).
 // ================================================================================================
+#ifndef NAM_WS_ABL
+#define NAM_WS_ABL 0
+#endif
 namespace ws
 {
 using mf::f4;
 constexpr int SC = kMfSC;
 constexpr int D = kWsPrefetch;
-constexpr int DT = kWsTilePrefetch;
 struct HSlot
 {
   f4 h[3]; // [0] previous 64 frames (window), [1] tap 0 (lookback 2d), [2] tap 1 (lookback d)
+  f4 tile; // 16 B of the weight tiles of the job AFTER the one the history belongs to
   float inp; // input sample of frame hfr of the block the job belongs to
+};
+struct Ops // one job's register-resident operands (compute waves)
+{
+  f4 t[4]; // A tiles: conv tap 0,1,2 | layer1x1
+  f4 xt; // extra tile (rechannel / head rechannel) when the job has one
+  f4 bv, mv, b1v, ev; // conv bias | input mixin | 1x1 bias | extra (rechannel column or head bias)
 };
 } // namespace ws
 
-template <int ACT_T, bool WT>
+template <int ACT_T, bool WT, bool PROF>
 __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict__ P, const float* __restrict__ blob,
                                                         const A1Args a)
 {
   using namespace mf;
   using ws::HSlot;
+  using ws::Ops;
   constexpr int SC = ws::SC;
-  __shared__ __attribute__((aligned(16))) float lds_f[kWsLdsFloats];
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
   char* const lds = reinterpret_cast<char*>(lds_f);
 
   const int tid = threadIdx.x;
@@ -1210,25 +1223,46 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
   const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
   const int total = n_blocks * NJ;
   const int total_pad = (total + kWsUnroll - 1) / kWsUnroll * kWsUnroll; // both roles: same number of barriers
+  const unsigned lds_tiles_b = (unsigned)a.lds_tiles_b, lds_cond_b = (unsigned)a.lds_cond_b;
 
-  // constants table -> LDS (all 512 threads; visible at the first barrier)
+  // constants table and extra tiles -> LDS (all 512 threads; visible at the prologue barrier)
   {
     const float* __restrict__ csrc = blob + a.consts_off;
-    constexpr int N = (kMJobMax * 64 + 511) / 512;
-    float cv[N];
+    const float* __restrict__ xsrc = blob + a.xt_off;
+    constexpr int NC = kWsJobMax * 64 / 512, NX = kWsXtMax * 256 / 512;
+    float cv[NC], xv[NX];
 #pragma unroll
-    for (int i = 0; i < N; i++)
-      cv[i] = (tid + 512 * i < NJ * 64) ? csrc[tid + 512 * i] : 0.0f;
+    for (int i = 0; i < NC; i++)
+      cv[i] = csrc[tid + 512 * i]; // the blob tables are padded to their maximum sizes
 #pragma unroll
-    for (int i = 0; i < N; i++)
-      if (tid + 512 * i < kMJobMax * 64)
+    for (int i = 0; i < NX; i++)
+      xv[i] = xsrc[tid + 512 * i];
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+      if (tid + 512 * i < NJ * 64)
         lds_f[kWsConstsOff + tid + 512 * i] = cv[i];
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+      if (tid + 512 * i < a.n_xt * 256)
+        lds_f[a.lds_xt_b / 4 + tid + 512 * i] = xv[i];
   }
 
+  long long bar_cycles = 0, t_begin = 0; // PROF: cycles this wave spent inside barriers / total
+  if constexpr (PROF)
+    t_begin = __builtin_readcyclecounter();
+  auto job_barrier = [&]() {
+    if constexpr (PROF)
+    {
+      const long long t0 = __builtin_readcyclecounter();
+      lds_barrier();
+      bar_cycles += __builtin_readcyclecounter() - t0;
+    }
+    else
+      lds_barrier();
+  };
   if (w < 4)
   {
     // ------------------------------------------------ compute role ------------------------------------
-    constexpr int DT = ws::DT;
     const int g = lane >> 4; // channel quad: this lane owns channels 4g..4g+3
     const int frame = 16 * w + (lane & 15);
     float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
@@ -1236,82 +1270,94 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     const float act_p0 = a.act_p0;
     const unsigned v_g16 = (unsigned)g * 16u;
     const unsigned v_tap = (unsigned)(frame * SC) * 4u;
-    const unsigned v_cond = (unsigned)(kWsCondOff + frame) * 4u;
-    const char* tiles0 = reinterpret_cast<const char*>(blob + a.tiles_off);
-    const unsigned v_tile = (unsigned)lane * 80u;
-    auto fetch_tiles = [&](f4 (&t)[5], int job) {
-      const char* tp = tiles0 + (size_t)job * (kWsTileFloats * 4);
+    const unsigned v_cond = lds_cond_b + (unsigned)frame * 4u;
+    const unsigned v_lane16 = (unsigned)lane * 16u;
+    // a job's operands: 4 tiles from tile buffer `tbuf`, its extra tile, 4 constant vectors
+    auto load_ops = [&](Ops& o, const CDesc& J, int tbuf) {
+      const unsigned a_t = v_lane16 + lds_tiles_b + (unsigned)tbuf * (kWsTileFloats * 4u);
 #pragma unroll
-      for (int q = 0; q < 5; q++)
-        t[q] = *reinterpret_cast<const f4*>(tp + (v_tile + 16u * q));
+      for (int q = 0; q < 4; q++)
+        o.t[q] = lds_ld4(lds, a_t + 1024u * q);
+      o.xt = lds_ld4(lds, v_lane16 + (unsigned)J.xt_b);
+      const unsigned a_c = v_g16 + (unsigned)J.consts_b;
+      o.bv = lds_ld4(lds, a_c);
+      o.mv = lds_ld4(lds, a_c + 64u);
+      o.b1v = lds_ld4(lds, a_c + 128u);
+      o.ev = lds_ld4(lds, a_c + 192u);
     };
-    f4 ta[DT][5];
-#pragma unroll
-    for (int u = 0; u < DT; u++)
-      fetch_tiles(ta[u], u); // NJ >= kWsPrefetch + 2 > DT
     f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f};
-    int ji = 0, blk = 0, jt = DT;
+    int ji = 0, blk = 0;
     int nvalid = min(kBlock, a.n_frames);
     CDesc Dn = P->cdesc[0];
-    for (int q0 = 0; q0 < total_pad; q0 += DT)
+    Ops ops[2];
+    job_barrier(); // prologue barrier: consts, extra tiles, job 0's tiles / history / x0 are in LDS
+    load_ops(ops[0], Dn, 0);
+
+    for (int q0 = 0; q0 < total_pad; q0 += 2)
     {
 #pragma unroll
-      for (int u = 0; u < DT; u++)
+      for (int u = 0; u < 2; u++)
       {
         const bool active = q0 + u < total;
         const CDesc J = Dn;
         Dn = P->cdesc[ji + 1 == NJ ? 0 : ji + 1];
         const int flags = active ? J.flags : 0;
-        lds_barrier();
-        // operand reads: 2 shifted taps, 4 constant vectors, the frame's input sample
-        const unsigned gq16 = min(v_g16, (unsigned)J.g16max);
+        const Ops& O = ops[u];
+        job_barrier();
+        // critical-path operand reads: 2 shifted taps and the frame's input sample
+        const unsigned gq16 = min(v_g16, (unsigned)(J.gp & 0xff));
         const unsigned a_tap = v_tap + gq16;
-        const f4 bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
-        const f4 bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
-        const unsigned a_c = v_g16 + (unsigned)J.consts_b;
-        const f4 bv4 = lds_ld4(lds, a_c), mv = lds_ld4(lds, a_c + 64u), b1v = lds_ld4(lds, a_c + 128u);
-        const f4 ev = lds_ld4(lds, a_c + 192u);
+        const f4 bt0 = (NAM_WS_ABL & 32) ? x : lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
+        const f4 bt1 = (NAM_WS_ABL & 32) ? x : lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
         const float cond = *reinterpret_cast<const float*>(lds + (v_cond + (unsigned)(blk & 1) * (kBlock * 4u)));
         if (flags & CD_X0)
         {
-          x = ev * cond; // ev = first array's rechannel column (in_size == 1)
+          x = O.ev * cond; // ev = first array's rechannel column (in_size == 1)
           head = f4{0.f, 0.f, 0.f, 0.f};
         }
         else if (flags & CD_PRE_HEAD)
-          head = mfma4(ta[u][4], head, f4{0.f, 0.f, 0.f, 0.f}) + ev; // previous array's head rechannel + bias
+          head = mfma4(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev; // previous array's head rechannel + bias
         // dilated conv: 3 taps x 4 k-steps; tap 2 (current frame) multiplies the lane's own x
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        acc0 = mfma4(ta[u][0], bt0, acc0);
-        acc1 = mfma4(ta[u][1], bt1, acc1);
-        acc0 = mfma4(ta[u][2], x, acc0);
+        if (NAM_WS_ABL & 8)
+        {
+          acc0 = bt0 * O.t[0] + x * O.t[2];
+          acc1 = bt1 * O.t[1];
+        }
+        else
+        {
+          acc0 = mfma4(O.t[0], bt0, acc0);
+          acc1 = mfma4(O.t[1], bt1, acc1);
+          acc0 = mfma4(O.t[2], x, acc0);
+        }
+        // in the shadow of the MFMAs: next job's operands (its tiles were dropped one job ago)
+        if (!(NAM_WS_ABL & 16))
+          load_ops(ops[u ^ 1], Dn, u ^ 1);
         const f4 acc = acc0 + acc1;
         if (flags & CD_LAYER)
         {
           f4 pre;
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            pre[r] = fmaf(mv[r], cond, acc[r] + bv4[r]);
-          const f4 z = act4<ACT_T>(J.act, pre, act_p0);
+            pre[r] = fmaf(O.mv[r], cond, acc[r] + O.bv[r]);
+          const f4 z = (NAM_WS_ABL & 4) ? pre : act4<ACT_T>(J.act, pre, act_p0);
           head += z;
-          const f4 y = mfma4(ta[u][3], z, f4{0.f, 0.f, 0.f, 0.f});
-          x = x + (y + b1v);
+          const f4 y = (NAM_WS_ABL & 64) ? z * O.t[3] : mfma4(O.t[3], z, f4{0.f, 0.f, 0.f, 0.f});
+          x = x + (y + O.b1v);
           if (flags & CD_POST_OUT)
           {
-            const f4 hout = mfma4(ta[u][4], head, f4{0.f, 0.f, 0.f, 0.f}) + ev;
+            const f4 hout = mfma4(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev;
             if (out && g == 0 && frame < nvalid)
               out[(size_t)blk * kBlock + frame] = head_scale * hout[0];
           }
           else
           {
             if (flags & CD_POST_RECH)
-              x = mfma4(ta[u][4], x, f4{0.f, 0.f, 0.f, 0.f}); // next array's rechannel (no bias)
-            if (v_g16 <= (unsigned)J.pubmax)
+              x = mfma4(O.xt, x, f4{0.f, 0.f, 0.f, 0.f}); // next array's rechannel (no bias)
+            if (v_g16 <= (unsigned)(J.gp >> 8))
               lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
           }
         }
-        fetch_tiles(ta[u], jt);
-        if (++jt == NJ)
-          jt = 0;
         if (active && ++ji == NJ)
         {
           ji = 0;
@@ -1325,17 +1371,24 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
   {
     // ------------------------------------------------ mover role --------------------------------------
     constexpr int D = ws::D;
+    const int mtid = tid - 256;
     const int hfr = 16 * (w - 4) + (lane >> 2); // frame inside a 64-frame set
     const unsigned v_hq16 = (unsigned)(lane & 3) * 16u; // channel quad
     const unsigned v_hist = (unsigned)(hfr * SC + 4 * (lane & 3)) * 4u;
+    const unsigned v_mt16 = (unsigned)mtid * 16u;
     int* wpos_tbl = reinterpret_cast<int*>(st);
     const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
     const char* ibase = in ? reinterpret_cast<const char*>(in) : stb; // silence: any valid word, masked later
+    const char* tiles0 = reinterpret_cast<const char*>(blob + a.tiles_off);
     int wposv = wpos_tbl[lane]; // lane r = write position of ring r
     const int ring_len_v = P->ring_len_by_id[lane];
     const f4 r1q = *reinterpret_cast<const f4*>(blob + a.r1_off + 4 * (lane & 3));
 
-    auto fetch = [&](HSlot& s, int f_rbase, int f_R, int f_L1, int f_ring_id, int f_q16max, bool next_block, int jblk) {
+    // history of one job + the tiles of job `tjob`
+    auto fetch = [&](HSlot& s, int f_rbase, int f_R, int f_L1, int f_ring_id, int f_q16max, bool next_block, int jblk,
+                     int tjob) {
+      if (NAM_WS_ABL & 1)
+        return;
       int wp = __builtin_amdgcn_readlane(wposv, f_ring_id);
       if (next_block)
       {
@@ -1356,42 +1409,51 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         const unsigned idx = min(v, v - (unsigned)f_R);
         s.h[t] = *reinterpret_cast<const f4*>(stb + (__umul24(idx, cmul) + vq));
       }
+      s.tile = *reinterpret_cast<const f4*>(tiles0 + ((unsigned)tjob * (kWsTileFloats * 4u) + v_mt16));
       int fi = jblk * kBlock + hfr;
       fi = min(fi, a.n_frames - 1);
       s.inp = *reinterpret_cast<const float*>(ibase + (in ? (unsigned)fi * 4u : 0u));
     };
-    // drop a job's history into LDS; for a block's first job also x0 and the input samples
-    auto drop = [&](const HSlot& s, const VDesc& J, int succ_blk) {
+    // drop a job's history (+ the following job's tiles) into LDS; for a block's first job also x0 and the inputs
+    auto drop = [&](const HSlot& s, const VDesc& J, int succ_blk, int tbuf) {
+      if (NAM_WS_ABL & 2)
+        return;
       lds_st4(lds, v_hist + (unsigned)J.st_win_b, s.h[0]);
       lds_st4(lds, v_hist + (unsigned)J.st_tb0_b, s.h[1]);
       lds_st4(lds, v_hist + (unsigned)J.st_tb1_b, s.h[2]);
+      lds_st4(lds, v_mt16 + lds_tiles_b + (unsigned)tbuf * (kWsTileFloats * 4u), s.tile);
       if (J.flags & MV_SUCC_FIRST)
       {
         const bool live = in && (succ_blk * kBlock + hfr < a.n_frames);
         const float iv = live ? s.inp : 0.0f;
         lds_st4(lds, v_hist + (unsigned)J.st_win_b + (unsigned)(kBlock * SC * 4), r1q * iv);
         if ((lane & 3) == 0)
-          lds_f[kWsCondOff + (succ_blk & 1) * kBlock + hfr] = iv;
+          *reinterpret_cast<float*>(lds + (lds_cond_b + (unsigned)((succ_blk & 1) * kBlock + hfr) * 4u)) = iv;
       }
     };
 
     HSlot slot[D];
+    // job 0's tiles go straight to tile buffer 0; slot u = history of job u + tiles of job u + 1
+    const f4 tile0 = *reinterpret_cast<const f4*>(tiles0 + v_mt16);
 #pragma unroll
     for (int u = 0; u < D; u++)
     {
       const VDesc F = P->vdesc[u + NJ - 1 - D]; // the descriptor whose f_* fields describe job u
-      fetch(slot[u], F.f_rbase, F.f_R, F.f_L1, F.f_ring_id, F.f_q16max, false, 0);
+      fetch(slot[u], F.f_rbase, F.f_R, F.f_L1, F.f_ring_id, F.f_q16max, false, 0, u + 1);
     }
     int ji = 0, blk = 0;
     int fj = D + 1, fblk = 0; // job / block whose history is fetched next
+    int ftile = D + 2; // job whose tiles are fetched next (NJ >= D + 3)
     int nvalid = min(kBlock, a.n_frames);
     {
       // "job -1": job 0's history (and x0 / inputs of block 0) go to LDS, slot 0 is refilled with job D
       const VDesc J = P->vdesc[NJ - 1];
-      drop(slot[0], J, 0);
-      fetch(slot[0], J.f_rbase, J.f_R, J.f_L1, J.f_ring_id, J.f_q16max, false, 0);
+      lds_st4(lds, v_mt16 + lds_tiles_b, tile0);
+      drop(slot[0], J, 0, 1);
+      fetch(slot[0], J.f_rbase, J.f_R, J.f_L1, J.f_ring_id, J.f_q16max, false, 0, D + 1);
     }
     VDesc Dn = P->vdesc[0];
+    job_barrier(); // prologue barrier (matches the compute role)
     for (int q0 = 0; q0 < total_pad; q0 += D)
     {
 #pragma unroll
@@ -1402,26 +1464,29 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         Dn = P->vdesc[ji + 1 == NJ ? 0 : ji + 1];
         const int flags = active ? J.flags : 0;
         const int un = (u + 1) % D;
-        lds_barrier();
+        job_barrier();
         // this job's input rows (published by the previous job / dropped as x0) -> history ring
-        if ((flags & MV_RING) && hfr < nvalid && v_hq16 <= (unsigned)J.q16max)
+        if (!(NAM_WS_ABL & 2) && (flags & MV_RING) && hfr < nvalid && v_hq16 <= (unsigned)J.q16max)
         {
           const f4 xin = lds_ld4(lds, v_hist + (unsigned)J.ap_src_b);
           const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + hfr);
           const unsigned widx = min(v, v - (unsigned)J.R);
           ring_store<WT>(stb, __umul24(widx, (unsigned)J.q16max + 16u) + v_hq16 + (unsigned)J.ring_b, xin);
         }
-        // successor's history -> LDS (other halves of the double buffers), then refill the slot
-        drop(slot[un], J, blk + 1);
+        // successor's history and the tiles of the job after it -> LDS (the halves of the double buffers
+        // nobody reads during this job), then refill the slot
+        drop(slot[un], J, blk + 1, u & 1);
         {
           const bool valid = fblk < n_blocks;
           fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_R : 64, valid ? J.f_L1 : 32, valid ? J.f_ring_id : 0,
-                valid ? J.f_q16max : 0, valid && (fblk > blk), valid ? fblk : blk);
+                valid ? J.f_q16max : 0, valid && (fblk > blk), valid ? fblk : blk, ftile);
           if (++fj == NJ)
           {
             fj = 0;
             fblk++;
           }
+          if (++ftile == NJ)
+            ftile = 0;
         }
         if (active && ++ji == NJ)
         {
@@ -1436,6 +1501,15 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     }
     if (w == 4 && lane < a.n_rings)
       wpos_tbl[lane] = wposv;
+  }
+  if constexpr (PROF)
+  {
+    // rows 0..7 of the debug buffer: per wave of workgroup 0: {barrier cycles, total cycles}
+    if (a.dbg && blockIdx.x == 0 && lane == 0)
+    {
+      a.dbg[w * 8 + 0] = bar_cycles;
+      a.dbg[w * 8 + 1] = __builtin_readcyclecounter() - t_begin;
+    }
   }
 }
 
@@ -1466,34 +1540,37 @@ hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t st
   return hipGetLastError();
 }
 
+namespace
+{
+template <int ACT_T, bool WT, bool PROF>
+hipError_t launch_ws_inst(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  static int lds_limit = 0; // per instantiation: dynamic LDS the runtime has been told about
+  if (a.lds_bytes > lds_limit)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_ws_kernel<ACT_T, WT, PROF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    lds_limit = a.lds_bytes;
+  }
+  hipLaunchKernelGGL((nam_a1_ws_kernel<ACT_T, WT, PROF>), dim3(n_blocks), dim3(512), a.lds_bytes, stream, a.plan, a.blob, a);
+  return hipGetLastError();
+}
+} // namespace
+
 hipError_t launch_a1_ws(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
-#define NAM_WS_LAUNCH(ACT, WT) \
-  hipLaunchKernelGGL((nam_a1_ws_kernel<ACT, WT>), dim3(n_blocks), dim3(512), 0, stream, a.plan, a.blob, a)
+  if (a.dbg) // developer tool: barrier-wait profile of workgroup 0
+    return launch_ws_inst<-1, false, true>(a, n_blocks, stream);
   if (act == ACT_FASTTANH)
-  {
-    if (wt)
-      NAM_WS_LAUNCH(ACT_FASTTANH, true);
-    else
-      NAM_WS_LAUNCH(ACT_FASTTANH, false);
-  }
-  else if (act == ACT_TANH)
-  {
-    if (wt)
-      NAM_WS_LAUNCH(ACT_TANH, true);
-    else
-      NAM_WS_LAUNCH(ACT_TANH, false);
-  }
-  else
-  {
-    if (wt)
-      NAM_WS_LAUNCH(-1, true);
-    else
-      NAM_WS_LAUNCH(-1, false);
-  }
-#undef NAM_WS_LAUNCH
-  return hipGetLastError();
+    return wt ? launch_ws_inst<ACT_FASTTANH, true, false>(a, n_blocks, stream)
+              : launch_ws_inst<ACT_FASTTANH, false, false>(a, n_blocks, stream);
+  if (act == ACT_TANH)
+    return wt ? launch_ws_inst<ACT_TANH, true, false>(a, n_blocks, stream)
+              : launch_ws_inst<ACT_TANH, false, false>(a, n_blocks, stream);
+  return wt ? launch_ws_inst<-1, true, false>(a, n_blocks, stream) : launch_ws_inst<-1, false, false>(a, n_blocks, stream);
 }
 
 int lstm_lds_bytes(const LSTMArgs& a)

@@ -219,7 +219,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.tiles_off = p.a1.n_mjobs > 0 ? p.a1.mjobs[0].tiles : 0;
       a.consts_off = p.a1.mconsts_off;
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
-      a.r1_off = 0;
+      a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = 0;
       if (kernel == NAM_HIP_KERNEL_A1_MFMA || kernel == NAM_HIP_KERNEL_A1_WS)
       {
         // uniform activation across arrays -> compile-time specialised kernel, else run-time dispatch
@@ -233,6 +233,12 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.tiles_off = p.a1.ws_tiles_off;
           a.consts_off = p.a1.ws_consts_off;
           a.r1_off = p.a1.ws_r1_off;
+          a.xt_off = p.a1.ws_xt_off;
+          a.n_xt = p.a1.ws_n_xt;
+          a.lds_tiles_b = p.a1.ws_lds_tiles_b;
+          a.lds_xt_b = p.a1.ws_lds_xt_b;
+          a.lds_cond_b = p.a1.ws_lds_cond_b;
+          a.lds_bytes = p.a1.ws_lds_bytes;
           NAM_HIP_CHECK(launch_a1_ws(a, n, act, s));
         }
         else

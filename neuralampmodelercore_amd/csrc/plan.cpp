@@ -391,22 +391,39 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   if (wn.arrays[0].input_size != 1)
     return;
   const int NJ = (n_layers + 1) / 2 * 2;
-  if (NJ > kMJobMax || NJ < kWsPrefetch + 2)
+  const int n_xt = 2 * n_arrays - 1;
+  if (NJ > kWsJobMax || NJ < kWsPrefetch + 3 || n_xt > kWsXtMax)
     return;
   while (plan.blob.size() % 64)
     plan.blob.push_back(0.0f);
   a1.ws_tiles_off = (int)plan.blob.size();
   plan.blob.resize(plan.blob.size() + (size_t)NJ * kWsTileFloats, 0.0f);
+  a1.ws_xt_off = (int)plan.blob.size();
+  plan.blob.resize(plan.blob.size() + (size_t)kWsXtMax * 256, 0.0f);
   a1.ws_consts_off = (int)plan.blob.size();
-  plan.blob.resize(plan.blob.size() + (size_t)NJ * 64, 0.0f);
+  plan.blob.resize(plan.blob.size() + (size_t)kWsJobMax * 64, 0.0f);
   a1.ws_r1_off = (int)plan.blob.size();
   plan.blob.resize(plan.blob.size() + 64, 0.0f);
   a1.ws_jobs = NJ;
+  a1.ws_n_xt = n_xt;
+  // LDS layout behind the history buffers
+  const int lds_consts = kWsConstsOff;
+  const int lds_tiles = lds_consts + NJ * 64;
+  const int lds_xt = lds_tiles + 2 * kWsTileFloats;
+  const int lds_cond = lds_xt + n_xt * 256;
+  a1.ws_lds_tiles_b = lds_tiles * 4;
+  a1.ws_lds_xt_b = lds_xt * 4;
+  a1.ws_lds_cond_b = lds_cond * 4;
+  a1.ws_lds_bytes = (lds_cond + 2 * kBlock) * 4;
+  // A-operand element W[o][in_idx] of v_mfma_f32_16x16x4_f32: input channel 4g + s is fed by lane group g in
+  // k-step s, so it is element s of the 16-byte record of lane (g, o). tile 0..2 = conv taps, 3 = layer1x1;
+  // tile -1-n = extra tile n.
+  int xt_next = 0;
   auto tile_at = [&](int job, int tile, int o, int in_idx) -> float& {
-    // A-operand element W[o][in_idx] of v_mfma_f32_16x16x4_f32: input channel 4g + s is fed by lane group g
-    // in k-step s, so it lives in lane (g, o) of tile `tile` = tile_base + s; lane-major [lane][20].
-    const int g = in_idx / 4;
-    return plan.blob[(size_t)a1.ws_tiles_off + (size_t)job * kWsTileFloats + (size_t)(g * 16 + o) * 20 + tile];
+    const int g = in_idx / 4, s = in_idx % 4;
+    if (tile < 0)
+      return plan.blob[(size_t)a1.ws_xt_off + (size_t)(-1 - tile) * 256 + (size_t)(g * 16 + o) * 4 + s];
+    return plan.blob[(size_t)a1.ws_tiles_off + (size_t)job * kWsTileFloats + (size_t)tile * 256 + (size_t)(g * 16 + o) * 4 + s];
   };
   auto const_at = [&](int job, int vec, int i) -> float& { return plan.blob[(size_t)a1.ws_consts_off + (size_t)job * 64 + vec * 16 + i]; };
 
@@ -465,26 +482,28 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
       for (int co = 0; co < C; co++)
         for (int ci = 0; ci < C; ci++)
           for (int k = 0; k < K; k++)
-            tile_at(ji, k * 4 + ci % 4, co, ci) = *(w++);
+            tile_at(ji, k, co, ci) = *(w++);
       for (int co = 0; co < C; co++)
         const_at(ji, 0, co) = *(w++);
       for (int co = 0; co < C; co++)
         const_at(ji, 1, co) = *(w++);
       for (int co = 0; co < C; co++)
         for (int ci = 0; ci < C; ci++)
-          tile_at(ji, 12 + ci % 4, co, ci) = *(w++);
+          tile_at(ji, 3, co, ci) = *(w++);
       for (int co = 0; co < C; co++)
         const_at(ji, 2, co) = *(w++);
       D.flags = CD_LAYER;
       D.act = A.activations[0].type;
-      D.g16max = 16 * (C / 4 - 1);
-      D.pubmax = D.g16max;
+      int g16max = 16 * (C / 4 - 1), pubmax = g16max;
+      D.xt_b = a1.ws_lds_xt_b;
       auto head_into = [&](int src_array) { // extra tile = head rechannel of src_array, extra consts = its bias
         const LayerArraySpec& S = wn.arrays[src_array];
         const float* hw = ptrs[src_array].head;
+        const int xt = xt_next++;
+        D.xt_b = a1.ws_lds_xt_b + xt * 1024;
         for (int h = 0; h < S.head_size; h++)
           for (int c = 0; c < S.channels; c++)
-            tile_at(ji, 16 + c % 4, h, c) = *(hw++);
+            tile_at(ji, -1 - xt, h, c) = *(hw++);
         for (int h = 0; h < S.head_size; h++)
           const_at(ji, 3, h) = S.head_bias ? *(hw++) : 0.0f;
       };
@@ -507,16 +526,19 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
         D.flags |= CD_POST_RECH;
         const LayerArraySpec& N = wn.arrays[ai + 1];
         const float* rw = ptrs[ai + 1].rech; // [co][ci], no bias
+        const int xt = xt_next++;
+        D.xt_b = a1.ws_lds_xt_b + xt * 1024;
         for (int co = 0; co < N.channels; co++)
           for (int ci = 0; ci < N.input_size; ci++)
-            tile_at(ji, 16 + ci % 4, co, ci) = *(rw++);
-        D.pubmax = 16 * (N.channels / 4 - 1);
+            tile_at(ji, -1 - xt, co, ci) = *(rw++);
+        pubmax = 16 * (N.channels / 4 - 1);
       }
       else if (l == NL - 1)
       {
         D.flags |= CD_POST_OUT;
         head_into(ai);
       }
+      D.gp = g16max | (pubmax << 8);
       (void)H;
     }
   }
@@ -526,6 +548,8 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
     const int buf = j & 1;
     CDesc& D = a1.cdesc[j];
     D.consts_b = (kWsConstsOff + j * 64) * 4;
+    if (!G.real)
+      D.xt_b = a1.ws_lds_xt_b;
     for (int k = 0; k < 2; k++)
     {
       const int L = G.real ? (2 - k) * G.d : 0;

@@ -178,13 +178,13 @@ static_assert(sizeof(MDesc) == 96, "MDesc must stay 96 bytes");
 // LDS double buffers alternate per job and must come back to parity 0 at the start of every block).
 // Compute waves (0-3) and mover waves (4-7) execute from separate descriptors.
 constexpr int kWsPrefetch = 6; // mover: jobs of history loads in flight
-constexpr int kWsTilePrefetch = 3; // compute: jobs of weight tiles in flight
 constexpr int kWsUnroll = 6; // both loops run a multiple of this many jobs (same number of barriers)
-constexpr int kWsTileFloats = 64 * 20; // per job: [lane][5 tiles x 4]: conv tap 0,1,2 | layer1x1 | extra
-constexpr int kWsConstsOff = kMfTbOff + 4 * kMfTbFloats; // consts [jobs][64]: bias | mixin | 1x1 bias | extra
-constexpr int kWsCondOff = kWsConstsOff + kMJobMax * 64; // input samples [block parity][64]
-constexpr int kWsLdsFloats = kWsCondOff + 2 * kBlock;
-static_assert(kWsLdsFloats * 4 <= 65536, "nam_a1_ws_kernel uses static LDS");
+constexpr int kWsJobMax = 32; // jobs (layers) per block
+constexpr int kWsXtMax = 4; // extra tiles (rechannel / head rechannel matrices) per model
+constexpr int kWsTileFloats = 4 * 256; // per job: [conv tap 0,1,2 | layer1x1][lane][4 k-steps]
+// LDS (floats): window [2][128][SC] | taps [2][2][64][SC] | consts [jobs][64] | tiles [2][1024] |
+//               extra tiles [n][256] | input samples [2][64]        (dynamic: sized per model, see ws_lds_*)
+constexpr int kWsConstsOff = kMfTbOff + 4 * kMfTbFloats;
 
 enum CDescFlags : int32_t
 {
@@ -198,11 +198,12 @@ struct CDesc // 8 x int32, one s_load_dwordx8
 {
   int32_t flags;
   int32_t act;
-  int32_t g16max; // 16 * (C/4 - 1): clamp for the lane's channel-quad byte offset when reading operands
-  int32_t consts_b; // LDS byte offset of this job's 64 constants
+  int32_t gp; // bits 0-7: 16 * (C/4 - 1), clamp for the lane's channel-quad byte offset when reading operands;
+              // bits 8-15: 16 * (C_published/4 - 1), lanes beyond do not publish
+  int32_t consts_b; // LDS byte offset of this job's 64 constants: bias | mixin | 1x1 bias | extra
   int32_t tap0_b, tap1_b; // LDS byte offset of frame 0 of tap k's operand rows
   int32_t pub_b; // LDS byte offset of frame 0 of the window rows x is published to
-  int32_t pubmax; // 16 * (C_published/4 - 1): lanes beyond do not publish
+  int32_t xt_b; // LDS byte offset of this job's extra tile (any valid tile when it has none)
 };
 enum VDescFlags : int32_t
 {
@@ -237,10 +238,12 @@ struct A1Plan
   // wave-specialised kernel
   int32_t ws_ok = 0;
   int32_t ws_jobs = 0; // jobs per block (even)
-  int32_t ws_tiles_off = 0, ws_consts_off = 0, ws_r1_off = 0; // blob offsets: tiles [jobs][1280], consts [jobs][64], 16 floats
+  int32_t ws_tiles_off = 0, ws_consts_off = 0, ws_r1_off = 0; // blob offsets: tiles [jobs][1024], consts [jobs][64], 16 floats
+  int32_t ws_xt_off = 0, ws_n_xt = 0; // blob offset / count of the extra tiles [n][256]
+  int32_t ws_lds_tiles_b = 0, ws_lds_xt_b = 0, ws_lds_cond_b = 0, ws_lds_bytes = 0; // LDS layout (bytes)
   int32_t ws_pad = 0;
-  CDesc cdesc[kMJobMax];
-  VDesc vdesc[kMJobMax];
+  CDesc cdesc[kWsJobMax];
+  VDesc vdesc[kWsJobMax];
 };
 
 // ---- LSTM ------------------------------------------------------------------------------------
