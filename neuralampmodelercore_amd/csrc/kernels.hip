@@ -1190,7 +1190,7 @@ constexpr int SC = kMfSC;
 constexpr int D = kWsPrefetch;
 struct HSlot
 {
-  f4 h[3]; // [0] previous 64 frames (window), [1] tap 0 (lookback 2d), [2] tap 1 (lookback d)
+  f4 h[2]; // the job's two history sets (plan.h, VDesc)
   f4 tile; // 16 B of the weight tiles of the job AFTER the one the history belongs to
   float inp; // input sample of frame hfr of the block the job belongs to
 };
@@ -1248,6 +1248,16 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
   }
 
   long long bar_cycles = 0, t_begin = 0; // PROF: cycles this wave spent inside barriers / total
+  long long seg[5] = {0, 0, 0, 0, 0}; // PROF (compute waves): taps ready | conv done | x updated | published | job end
+  long long t_seg = 0;
+#define NAM_WS_STAMP(k, ...) \
+  if constexpr (PROF) \
+  { \
+    asm volatile("" ::__VA_ARGS__); \
+    const long long t_now = __builtin_readcyclecounter(); \
+    seg[k] += t_now - t_seg; \
+    t_seg = t_now; \
+  }
   if constexpr (PROF)
     t_begin = __builtin_readcyclecounter();
   auto job_barrier = [&]() {
@@ -1310,6 +1320,9 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         const f4 bt0 = (NAM_WS_ABL & 32) ? x : lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
         const f4 bt1 = (NAM_WS_ABL & 32) ? x : lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
         const float cond = *reinterpret_cast<const float*>(lds + (v_cond + (unsigned)(blk & 1) * (kBlock * 4u)));
+        if constexpr (PROF)
+          t_seg = __builtin_readcyclecounter();
+        NAM_WS_STAMP(0, "v"(bt0), "v"(bt1), "v"(cond))
         if (flags & CD_X0)
         {
           x = O.ev * cond; // ev = first array's rechannel column (in_size == 1)
@@ -1318,7 +1331,9 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         else if (flags & CD_PRE_HEAD)
           head = mfma4(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev; // previous array's head rechannel + bias
         // dilated conv: 3 taps x 4 k-steps; tap 2 (current frame) multiplies the lane's own x
-        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // three independent accumulator chains, interleaved so that no MFMA waits for its predecessor; the
+        // conv bias and the input mixin ride in as initial accumulators
+        f4 acc0 = O.bv, acc1 = O.mv * cond, acc2 = {0.f, 0.f, 0.f, 0.f};
         if (NAM_WS_ABL & 8)
         {
           acc0 = bt0 * O.t[0] + x * O.t[2];
@@ -1326,24 +1341,36 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         }
         else
         {
-          acc0 = mfma4(O.t[0], bt0, acc0);
-          acc1 = mfma4(O.t[1], bt1, acc1);
-          acc0 = mfma4(O.t[2], x, acc0);
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+          {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
+          }
         }
         // in the shadow of the MFMAs: next job's operands (its tiles were dropped one job ago)
-        if (!(NAM_WS_ABL & 16))
+        if (!(NAM_WS_ABL & (16 | 128)))
           load_ops(ops[u ^ 1], Dn, u ^ 1);
-        const f4 acc = acc0 + acc1;
+        const f4 pre = (acc0 + acc1) + acc2;
+        NAM_WS_STAMP(1, "v"(pre))
         if (flags & CD_LAYER)
         {
-          f4 pre;
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            pre[r] = fmaf(O.mv[r], cond, acc[r] + O.bv[r]);
           const f4 z = (NAM_WS_ABL & 4) ? pre : act4<ACT_T>(J.act, pre, act_p0);
           head += z;
-          const f4 y = (NAM_WS_ABL & 64) ? z * O.t[3] : mfma4(O.t[3], z, f4{0.f, 0.f, 0.f, 0.f});
-          x = x + (y + O.b1v);
+          // layer1x1 as two chains of two; the residual and the 1x1 bias are the initial accumulator
+          f4 y0 = x + O.b1v, y1 = {0.f, 0.f, 0.f, 0.f};
+          if (NAM_WS_ABL & 64)
+            y0 += z * O.t[3];
+          else
+          {
+            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][0], z[0], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][1], z[1], y1, 0, 0, 0);
+            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][2], z[2], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][3], z[3], y1, 0, 0, 0);
+          }
+          x = y0 + y1;
+          NAM_WS_STAMP(2, "v"(x))
           if (flags & CD_POST_OUT)
           {
             const f4 hout = mfma4(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev;
@@ -1358,12 +1385,16 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
               lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
           }
         }
+        if (NAM_WS_ABL & 128)
+          load_ops(ops[u ^ 1], Dn, u ^ 1);
+        NAM_WS_STAMP(3, "v"(x))
         if (active && ++ji == NJ)
         {
           ji = 0;
           blk++;
           nvalid = min(kBlock, a.n_frames - blk * kBlock);
         }
+        NAM_WS_STAMP(4, "s"(ji))
       }
     }
   }
@@ -1385,8 +1416,8 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     const f4 r1q = *reinterpret_cast<const f4*>(blob + a.r1_off + 4 * (lane & 3));
 
     // history of one job + the tiles of job `tjob`
-    auto fetch = [&](HSlot& s, int f_rbase, int f_R, int f_L1, int f_ring_id, int f_q16max, bool next_block, int jblk,
-                     int tjob) {
+    auto fetch = [&](HSlot& s, int f_rbase, int f_R, int f_LA, int f_LB, int f_ring_id, int f_q16max, bool next_block,
+                     int jblk, int tjob) {
       if (NAM_WS_ABL & 1)
         return;
       int wp = __builtin_amdgcn_readlane(wposv, f_ring_id);
@@ -1398,16 +1429,19 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
       }
       const unsigned vq = min(v_hq16, (unsigned)f_q16max) + (unsigned)f_rbase;
       const unsigned cmul = (unsigned)f_q16max + 16u;
-      const int Ls[3] = {kBlock, 2 * f_L1, f_L1};
+      const int Ls[2] = {f_LA, f_LB};
 #pragma unroll
-      for (int t = 0; t < 3; t++)
+      for (int t = 0; t < 2; t++)
       {
         int sb = wp - Ls[t];
         if (sb < 0)
           sb += f_R;
         const unsigned v = (unsigned)(hfr + sb);
         const unsigned idx = min(v, v - (unsigned)f_R);
-        s.h[t] = *reinterpret_cast<const f4*>(stb + (__umul24(idx, cmul) + vq));
+        // a job without a second set still issues the load (the number of loads in flight stays static),
+        // but every lane reads the same cached 16 bytes
+        const unsigned off = (t == 1 && f_LB == 0) ? 0u : __umul24(idx, cmul) + vq;
+        s.h[t] = *reinterpret_cast<const f4*>(stb + off);
       }
       s.tile = *reinterpret_cast<const f4*>(tiles0 + ((unsigned)tjob * (kWsTileFloats * 4u) + v_mt16));
       int fi = jblk * kBlock + hfr;
@@ -1418,15 +1452,15 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     auto drop = [&](const HSlot& s, const VDesc& J, int succ_blk, int tbuf) {
       if (NAM_WS_ABL & 2)
         return;
-      lds_st4(lds, v_hist + (unsigned)J.st_win_b, s.h[0]);
-      lds_st4(lds, v_hist + (unsigned)J.st_tb0_b, s.h[1]);
-      lds_st4(lds, v_hist + (unsigned)J.st_tb1_b, s.h[2]);
+      lds_st4(lds, v_hist + (unsigned)J.st_a_b, s.h[0]);
+      if (J.flags & MV_SUCC_B)
+        lds_st4(lds, v_hist + (unsigned)J.st_b_b, s.h[1]);
       lds_st4(lds, v_mt16 + lds_tiles_b + (unsigned)tbuf * (kWsTileFloats * 4u), s.tile);
       if (J.flags & MV_SUCC_FIRST)
       {
         const bool live = in && (succ_blk * kBlock + hfr < a.n_frames);
         const float iv = live ? s.inp : 0.0f;
-        lds_st4(lds, v_hist + (unsigned)J.st_win_b + (unsigned)(kBlock * SC * 4), r1q * iv);
+        lds_st4(lds, v_hist + (unsigned)J.st_x0_b, r1q * iv);
         if ((lane & 3) == 0)
           *reinterpret_cast<float*>(lds + (lds_cond_b + (unsigned)((succ_blk & 1) * kBlock + hfr) * 4u)) = iv;
       }
@@ -1439,7 +1473,7 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     for (int u = 0; u < D; u++)
     {
       const VDesc F = P->vdesc[u + NJ - 1 - D]; // the descriptor whose f_* fields describe job u
-      fetch(slot[u], F.f_rbase, F.f_R, F.f_L1, F.f_ring_id, F.f_q16max, false, 0, u + 1);
+      fetch(slot[u], F.f_rbase, F.f_R, F.f_LA, F.f_LB, F.f_ring_id, F.f_q16max, false, 0, u + 1);
     }
     int ji = 0, blk = 0;
     int fj = D + 1, fblk = 0; // job / block whose history is fetched next
@@ -1450,7 +1484,7 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
       const VDesc J = P->vdesc[NJ - 1];
       lds_st4(lds, v_mt16 + lds_tiles_b, tile0);
       drop(slot[0], J, 0, 1);
-      fetch(slot[0], J.f_rbase, J.f_R, J.f_L1, J.f_ring_id, J.f_q16max, false, 0, D + 1);
+      fetch(slot[0], J.f_rbase, J.f_R, J.f_LA, J.f_LB, J.f_ring_id, J.f_q16max, false, 0, D + 1);
     }
     VDesc Dn = P->vdesc[0];
     job_barrier(); // prologue barrier (matches the compute role)
@@ -1478,8 +1512,8 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         drop(slot[un], J, blk + 1, u & 1);
         {
           const bool valid = fblk < n_blocks;
-          fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_R : 64, valid ? J.f_L1 : 32, valid ? J.f_ring_id : 0,
-                valid ? J.f_q16max : 0, valid && (fblk > blk), valid ? fblk : blk, ftile);
+          fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_R : 64, valid ? J.f_LA : 64, valid ? J.f_LB : 0,
+                valid ? J.f_ring_id : 0, valid ? J.f_q16max : 0, valid && (fblk > blk), valid ? fblk : blk, ftile);
           if (++fj == NJ)
           {
             fj = 0;
@@ -1509,6 +1543,8 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     {
       a.dbg[w * 8 + 0] = bar_cycles;
       a.dbg[w * 8 + 1] = __builtin_readcyclecounter() - t_begin;
+      for (int k = 0; k < 5; k++)
+        a.dbg[w * 8 + 2 + k] = seg[k];
     }
   }
 }
@@ -1563,7 +1599,8 @@ hipError_t launch_a1_ws(const A1Args& a, int n_blocks, int act, hipStream_t stre
 {
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
   if (a.dbg) // developer tool: barrier-wait profile of workgroup 0
-    return launch_ws_inst<-1, false, true>(a, n_blocks, stream);
+    return act == ACT_FASTTANH ? launch_ws_inst<ACT_FASTTANH, false, true>(a, n_blocks, stream)
+                               : launch_ws_inst<-1, false, true>(a, n_blocks, stream);
   if (act == ACT_FASTTANH)
     return wt ? launch_ws_inst<ACT_FASTTANH, true, false>(a, n_blocks, stream)
               : launch_ws_inst<ACT_FASTTANH, false, false>(a, n_blocks, stream);

@@ -559,14 +559,32 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
     D.pub_b = (xw(buf ^ 1) + kBlock * kMfSC) * 4;
     VDesc& V = a1.vdesc[j];
     const int nbuf = (j + 1) & 1;
+    const JobGeo& N = geo[(j + 1) % NJ]; // successor: its history is dropped during job j
     const JobGeo& F = geo[(j + 1 + kWsPrefetch) % NJ];
-    V.flags = (G.real ? MV_RING : 0) | (j == NJ - 1 ? MV_SUCC_FIRST : 0);
-    V.st_win_b = xw(nbuf) * 4;
-    V.st_tb0_b = tb(nbuf, 0) * 4;
-    V.st_tb1_b = tb(nbuf, 1) * 4;
+    // which sets a job needs (plan.h, VDesc)
+    auto sets = [&](const JobGeo& G, int& LA, int& LB, int& dst_a, int& dst_b, int buf) {
+      LA = kBlock, LB = 0, dst_a = xw(buf), dst_b = tb(buf, 0);
+      if (!G.real || 2 * G.d <= kBlock)
+        return;
+      if (G.d <= kBlock)
+        LB = 2 * G.d;
+      else
+      {
+        LA = 2 * G.d, LB = G.d;
+        dst_a = tb(buf, 0), dst_b = tb(buf, 1);
+      }
+    };
+    int LA, LB, da, db;
+    sets(N, LA, LB, da, db, nbuf);
+    V.flags = (G.real ? MV_RING : 0) | (j == NJ - 1 ? MV_SUCC_FIRST : 0) | (LB ? MV_SUCC_B : 0);
+    V.st_a_b = da * 4;
+    V.st_b_b = db * 4;
+    V.st_x0_b = (xw(nbuf) + kBlock * kMfSC) * 4;
+    sets(F, LA, LB, da, db, 0);
     V.f_rbase = F.real ? F.ring_off * 4 : 0;
     V.f_R = F.real ? F.R : 64;
-    V.f_L1 = F.real ? F.d : 32;
+    V.f_LA = F.real ? LA : 64;
+    V.f_LB = F.real ? LB : 0;
     V.f_ring_id = F.real ? F.ring_id : 0;
     V.f_q16max = F.real ? 16 * (F.C / 4 - 1) : 0;
     V.ap_src_b = (xw(buf) + kBlock * kMfSC) * 4;

@@ -208,16 +208,22 @@ struct CDesc // 8 x int32, one s_load_dwordx8
 enum VDescFlags : int32_t
 {
   MV_RING = 1, // append this job's input (window rows of its buffer) to its history ring
-  MV_SUCC_FIRST = 2 // the successor is the next block's first job: also drop x0 = rechannel * input and the input itself
+  MV_SUCC_FIRST = 2, // the successor is the next block's first job: also drop x0 = rechannel * input and the input itself
+  MV_SUCC_B = 4 // the successor has a second history set
 };
+// A job reads at most two 64-frame history sets from its ring (lookbacks LA >= LB, in frames):
+//   2d <= 64      : A = previous block (L = 64) -> window;                  both taps read the window
+//   d <= 64 < 2d  : A = previous block -> window, B = tap 0 (L = 2d) -> tap buffer 0
+//   d > 64        : A = tap 0 (L = 2d) -> tap buffer 0, B = tap 1 (L = d) -> tap buffer 1
 struct VDesc // 16 x int32, one s_load_dwordx16
 {
   int32_t flags;
-  int32_t st_win_b, st_tb0_b, st_tb1_b; // LDS byte offsets where the SUCCESSOR's history sets are dropped
-  int32_t f_rbase, f_R, f_L1, f_ring_id, f_q16max; // ring geometry of the job prefetched now (kWsPrefetch + 1 ahead)
+  int32_t st_a_b, st_b_b, st_x0_b; // LDS byte offsets where the SUCCESSOR's sets / x0 rows are dropped
+  int32_t f_rbase, f_R, f_LA, f_LB, f_ring_id, f_q16max; // ring geometry of the job prefetched now (kWsPrefetch + 1
+                                                         // ahead); f_LB == 0: no second set (the load is redirected)
   int32_t ap_src_b; // LDS byte offset of frame 0 of this job's input rows (current half of its window)
   int32_t ring_b, R, ring_id, q16max; // this job's ring
-  int32_t pad0, pad1;
+  int32_t pad0;
 };
 static_assert(sizeof(CDesc) == 32 && sizeof(VDesc) == 64, "descriptor sizes are part of the kernel ABI");
 

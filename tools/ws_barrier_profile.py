@@ -15,3 +15,6 @@ jobs = (nfr + 63) // 64 * 20
 for w in range(8):
     bar, tot = int(t[w, 0]), int(t[w, 1])
     print(f"wave {w} ({'compute' if w < 4 else 'mover'}): total {tot} cyc = {tot / jobs:.0f}/job, in barrier {bar} = {bar / jobs:.0f}/job ({100.0 * bar / max(tot, 1):.0f}%)")
+    if w < 4:
+        names = ["barrier exit->taps ready", "->conv done", "->x updated", "->published", "->job end (bookkeeping)"]
+        print("      " + "; ".join(f"{n} {int(t[w, 2 + k]) / jobs:.0f}" for k, n in enumerate(names)))
