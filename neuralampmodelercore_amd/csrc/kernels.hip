@@ -19,6 +19,8 @@
 //   gating NAM/gating_activations.h:59-228 · FiLM NAM/film.h:76-204 · LSTM NAM/lstm.cpp:31-168.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace namhip
@@ -704,6 +706,15 @@ __device__ __forceinline__ f4 mfma4(const f4& a, const f4& b, f4 acc)
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
   return acc;
 }
+template <int NK>
+__device__ __forceinline__ f4 mfma_n(const f4& a, const f4& b, f4 acc)
+{
+#pragma unroll
+  for (int s = 0; s < NK; s++)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+  return acc;
+}
+using f2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f4 lds_ld4(const char* lds, unsigned byte_off)
 {
   return *reinterpret_cast<const f4*>(lds + byte_off);
@@ -1282,6 +1293,7 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
     const unsigned v_tap = (unsigned)(frame * SC) * 4u;
     const unsigned v_cond = lds_cond_b + (unsigned)frame * 4u;
     const unsigned v_lane16 = (unsigned)lane * 16u;
+    const unsigned v_gh8 = (unsigned)(g & 1) * 16u + (unsigned)(g >> 1) * 8u; // half layout: the lane's channel pair
     // a job's operands: 4 tiles from tile buffer `tbuf`, its extra tile, 4 constant vectors
     auto load_ops = [&](Ops& o, const CDesc& J, int tbuf) {
       const unsigned a_t = v_lane16 + lds_tiles_b + (unsigned)tbuf * (kWsTileFloats * 4u);
@@ -1314,77 +1326,101 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
         const int flags = active ? J.flags : 0;
         const Ops& O = ops[u];
         job_barrier();
-        // critical-path operand reads: 2 shifted taps and the frame's input sample
-        const unsigned gq16 = min(v_g16, (unsigned)(J.gp & 0xff));
-        const unsigned a_tap = v_tap + gq16;
-        const f4 bt0 = (NAM_WS_ABL & 32) ? x : lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
-        const f4 bt1 = (NAM_WS_ABL & 32) ? x : lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
         const float cond = *reinterpret_cast<const float*>(lds + (v_cond + (unsigned)(blk & 1) * (kBlock * 4u)));
-        if constexpr (PROF)
-          t_seg = __builtin_readcyclecounter();
-        NAM_WS_STAMP(0, "v"(bt0), "v"(bt1), "v"(cond))
-        if (flags & CD_X0)
-        {
-          x = O.ev * cond; // ev = first array's rechannel column (in_size == 1)
-          head = f4{0.f, 0.f, 0.f, 0.f};
-        }
-        else if (flags & CD_PRE_HEAD)
-          head = mfma4(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev; // previous array's head rechannel + bias
-        // dilated conv: 3 taps x 4 k-steps; tap 2 (current frame) multiplies the lane's own x
-        // three independent accumulator chains, interleaved so that no MFMA waits for its predecessor; the
-        // conv bias and the input mixin ride in as initial accumulators
-        f4 acc0 = O.bv, acc1 = O.mv * cond, acc2 = {0.f, 0.f, 0.f, 0.f};
-        if (NAM_WS_ABL & 8)
-        {
-          acc0 = bt0 * O.t[0] + x * O.t[2];
-          acc1 = bt1 * O.t[1];
-        }
-        else
-        {
+        // everything between the barrier and the publish, for NK k-steps per matrix (4: full layout, 2: half)
+        auto job_body = [&](auto nk_tag) {
+          constexpr int NK = decltype(nk_tag)::value;
+          // critical-path operand reads: the two shifted taps. Full layout: the lane's channel quad (16 B);
+          // half layout: the two channels this lane feeds to the MFMAs (8 B).
+          f4 bt0 = x, bt1 = x;
+          if (!(NAM_WS_ABL & 32))
+          {
+            if constexpr (NK == 4)
+            {
+              const unsigned a_tap = v_tap + min(v_g16, (unsigned)(J.gp & 0xff));
+              bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
+              bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
+            }
+            else
+            {
+              const f2 p0 = *reinterpret_cast<const f2*>(lds + (v_tap + v_gh8 + (unsigned)J.tap0_b));
+              const f2 p1 = *reinterpret_cast<const f2*>(lds + (v_tap + v_gh8 + (unsigned)J.tap1_b));
+              bt0 = f4{p0[0], p0[1], 0.f, 0.f};
+              bt1 = f4{p1[0], p1[1], 0.f, 0.f};
+            }
+          }
+          NAM_WS_STAMP(0, "v"(bt0), "v"(bt1), "v"(cond))
+          if (flags & CD_X0)
+          {
+            x = O.ev * cond; // ev = first array's rechannel column (in_size == 1)
+            head = f4{0.f, 0.f, 0.f, 0.f};
+          }
+          else if (flags & CD_PRE_HEAD) // previous array's head rechannel + bias, in this array's layout
+            head = ((flags & CD_PREV_HALF) ? mfma_n<2>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f})
+                                           : mfma_n<4>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}))
+                   + O.ev;
+          // dilated conv: 3 taps x NK k-steps; tap 2 (current frame) multiplies the lane's own x. Three
+          // independent accumulator chains, interleaved so that no MFMA waits for its predecessor; the conv
+          // bias and the input mixin ride in as initial accumulators.
+          f4 acc0 = O.bv, acc1 = O.mv * cond, acc2 = {0.f, 0.f, 0.f, 0.f};
+          if (NAM_WS_ABL & 8)
+          {
+            acc0 = bt0 * O.t[0] + x * O.t[2];
+            acc1 = bt1 * O.t[1];
+          }
+          else
+          {
 #pragma unroll
-          for (int s = 0; s < 4; s++)
-          {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
+            for (int s = 0; s < NK; s++)
+            {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
+            }
           }
-        }
-        // in the shadow of the MFMAs: next job's operands (its tiles were dropped one job ago)
-        if (!(NAM_WS_ABL & (16 | 128)))
-          load_ops(ops[u ^ 1], Dn, u ^ 1);
-        const f4 pre = (acc0 + acc1) + acc2;
-        NAM_WS_STAMP(1, "v"(pre))
-        if (flags & CD_LAYER)
-        {
-          const f4 z = (NAM_WS_ABL & 4) ? pre : act4<ACT_T>(J.act, pre, act_p0);
-          head += z;
-          // layer1x1 as two chains of two; the residual and the 1x1 bias are the initial accumulator
-          f4 y0 = x + O.b1v, y1 = {0.f, 0.f, 0.f, 0.f};
-          if (NAM_WS_ABL & 64)
-            y0 += z * O.t[3];
-          else
+          // in the shadow of the MFMAs: next job's operands (its tiles were dropped one job ago)
+          if (!(NAM_WS_ABL & (16 | 128)))
+            load_ops(ops[u ^ 1], Dn, u ^ 1);
+          const f4 pre = (acc0 + acc1) + acc2;
+          NAM_WS_STAMP(1, "v"(pre))
+          if (flags & CD_LAYER)
           {
-            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][0], z[0], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][1], z[1], y1, 0, 0, 0);
-            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][2], z[2], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][3], z[3], y1, 0, 0, 0);
+            const f4 z = (NAM_WS_ABL & 4) ? pre : act4<ACT_T>(J.act, pre, act_p0);
+            head += z;
+            // layer1x1 as two chains; the residual and the 1x1 bias are the initial accumulator
+            f4 y0 = x + O.b1v, y1 = {0.f, 0.f, 0.f, 0.f};
+            if (NAM_WS_ABL & 64)
+              y0 += z * O.t[3];
+            else
+            {
+#pragma unroll
+              for (int s = 0; s < NK; s += 2)
+              {
+                y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s], z[s], y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s + 1], z[s + 1], y1, 0, 0, 0);
+              }
+            }
+            x = y0 + y1;
+            NAM_WS_STAMP(2, "v"(x))
+            if (flags & CD_POST_OUT)
+            {
+              const f4 hout = mfma_n<NK>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev;
+              if (out && g == 0 && frame < nvalid)
+                out[(size_t)blk * kBlock + frame] = head_scale * hout[0];
+            }
+            else
+            {
+              if (flags & CD_POST_RECH)
+                x = mfma_n<NK>(O.xt, x, f4{0.f, 0.f, 0.f, 0.f}); // next array's rechannel (no bias), its layout
+              if (v_g16 <= (unsigned)(J.gp >> 8))
+                lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
+            }
           }
-          x = y0 + y1;
-          NAM_WS_STAMP(2, "v"(x))
-          if (flags & CD_POST_OUT)
-          {
-            const f4 hout = mfma4(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev;
-            if (out && g == 0 && frame < nvalid)
-              out[(size_t)blk * kBlock + frame] = head_scale * hout[0];
-          }
-          else
-          {
-            if (flags & CD_POST_RECH)
-              x = mfma4(O.xt, x, f4{0.f, 0.f, 0.f, 0.f}); // next array's rechannel (no bias)
-            if (v_g16 <= (unsigned)(J.gp >> 8))
-              lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
-          }
-        }
+        };
+        if (flags & CD_HALF)
+          job_body(std::integral_constant<int, 2>{});
+        else
+          job_body(std::integral_constant<int, 4>{});
         if (NAM_WS_ABL & 128)
           load_ops(ops[u ^ 1], Dn, u ^ 1);
         NAM_WS_STAMP(3, "v"(x))

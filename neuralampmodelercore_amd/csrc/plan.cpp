@@ -415,17 +415,42 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   a1.ws_lds_xt_b = lds_xt * 4;
   a1.ws_lds_cond_b = lds_cond * 4;
   a1.ws_lds_bytes = (lds_cond + 2 * kBlock) * 4;
-  // A-operand element W[o][in_idx] of v_mfma_f32_16x16x4_f32: input channel 4g + s is fed by lane group g in
-  // k-step s, so it is element s of the 16-byte record of lane (g, o). tile 0..2 = conv taps, 3 = layer1x1;
-  // tile -1-n = extra tile n.
+  // ---- register layouts -------------------------------------------------------------------------------
+  // A compute lane (g = lane / 16) keeps 4 channel values (e = 0..3) of its frame. FULL layout: channel 4g + e.
+  // HALF layout (8-channel arrays): lane groups 2, 3 duplicate groups 0, 1 with the quad rotated by two,
+  //   channel(g, e) = 4 (g % 2) + (e + 2 (g / 2)) % 4,
+  // so that k-step m (m = 0, 1) of an MFMA can take element m of EVERY lane and still cover all 8 input
+  // channels: in_channel(g, m) = 4 (g % 2) + 2 (g / 2) + m. Half the MFMAs per matrix, no cross-lane traffic.
+  // Output rows are produced directly in the consumer's layout (duplicated / rotated A-tile rows).
+  enum { FULL = 0, HALF = 1 };
+  auto mode_of = [](int channels) { return channels == 8 ? HALF : FULL; };
+  auto out_chan = [](int mode, int g, int e) { return mode == HALF ? 4 * (g % 2) + (e + 2 * (g / 2)) % 4 : 4 * g + e; };
+  auto in_chan = [](int mode, int g, int m) { return mode == HALF ? 4 * (g % 2) + 2 * (g / 2) + m : 4 * g + m; };
+  auto nk_of = [](int mode) { return mode == HALF ? 2 : 4; };
+  // A tile of v_mfma_f32_16x16x4_f32 for the matrix W (Co x Ci, accessed through `at(co, ci)`): the record of
+  // lane (g_k, row i) holds W[out_chan(i / 4, i % 4)][in_chan(g_k, m)] in element m. tile 0..2 = conv taps,
+  // 3 = layer1x1; tile -1-n = extra tile n.
   int xt_next = 0;
-  auto tile_at = [&](int job, int tile, int o, int in_idx) -> float& {
-    const int g = in_idx / 4, s = in_idx % 4;
-    if (tile < 0)
-      return plan.blob[(size_t)a1.ws_xt_off + (size_t)(-1 - tile) * 256 + (size_t)(g * 16 + o) * 4 + s];
-    return plan.blob[(size_t)a1.ws_tiles_off + (size_t)job * kWsTileFloats + (size_t)tile * 256 + (size_t)(g * 16 + o) * 4 + s];
+  auto fill_tile = [&](int job, int tile, int Co, int Ci, int mode_out, int mode_in, auto at) {
+    float* base = tile < 0 ? &plan.blob[(size_t)a1.ws_xt_off + (size_t)(-1 - tile) * 256]
+                           : &plan.blob[(size_t)a1.ws_tiles_off + (size_t)job * kWsTileFloats + (size_t)tile * 256];
+    for (int gk = 0; gk < 4; gk++)
+      for (int i = 0; i < 16; i++)
+        for (int m = 0; m < nk_of(mode_in); m++)
+        {
+          const int co = out_chan(mode_out, i / 4, i % 4), ci = in_chan(mode_in, gk, m);
+          base[(gk * 16 + i) * 4 + m] = (co < Co && ci < Ci) ? at(co, ci) : 0.0f;
+        }
   };
-  auto const_at = [&](int job, int vec, int i) -> float& { return plan.blob[(size_t)a1.ws_consts_off + (size_t)job * 64 + vec * 16 + i]; };
+  // per-channel constants in the lane layout: entry (g, e) = v[out_chan(g, e)]
+  auto fill_const = [&](int job, int vec, int n, int mode, auto at) {
+    for (int g = 0; g < 4; g++)
+      for (int e = 0; e < 4; e++)
+      {
+        const int c = out_chan(mode, g, e);
+        plan.blob[(size_t)a1.ws_consts_off + (size_t)job * 64 + vec * 16 + g * 4 + e] = c < n ? at(c) : 0.0f;
+      }
+  };
 
   // where each array's pieces sit in the weight stream (same order as build_a1 walks it)
   struct Ptrs
@@ -478,48 +503,45 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
       G.ring_off = arr.ring_off[l];
       G.ring_id = arr.ring_id[l];
       G.real = 1;
+      const int mode = mode_of(C);
       const float* w = ptrs[ai].layer[l];
-      for (int co = 0; co < C; co++)
-        for (int ci = 0; ci < C; ci++)
-          for (int k = 0; k < K; k++)
-            tile_at(ji, k, co, ci) = *(w++);
-      for (int co = 0; co < C; co++)
-        const_at(ji, 0, co) = *(w++);
-      for (int co = 0; co < C; co++)
-        const_at(ji, 1, co) = *(w++);
-      for (int co = 0; co < C; co++)
-        for (int ci = 0; ci < C; ci++)
-          tile_at(ji, 3, co, ci) = *(w++);
-      for (int co = 0; co < C; co++)
-        const_at(ji, 2, co) = *(w++);
-      D.flags = CD_LAYER;
+      const float* cw = w; // conv [co][ci][k]
+      const float* cbias = cw + (size_t)C * C * K;
+      const float* mix = cbias + C; // input mixin [co] (condition size 1)
+      const float* w1 = mix + C; // layer1x1 [co][ci]
+      const float* b1 = w1 + (size_t)C * C;
+      for (int k = 0; k < K; k++)
+        fill_tile(ji, k, C, C, mode, mode, [&](int co, int ci) { return cw[((size_t)co * C + ci) * K + k]; });
+      fill_tile(ji, 3, C, C, mode, mode, [&](int co, int ci) { return w1[(size_t)co * C + ci]; });
+      fill_const(ji, 0, C, mode, [&](int c) { return cbias[c]; });
+      fill_const(ji, 1, C, mode, [&](int c) { return mix[c]; });
+      fill_const(ji, 2, C, mode, [&](int c) { return b1[c]; });
+      D.flags = CD_LAYER | (mode == HALF ? CD_HALF : 0);
       D.act = A.activations[0].type;
       int g16max = 16 * (C / 4 - 1), pubmax = g16max;
       D.xt_b = a1.ws_lds_xt_b;
-      auto head_into = [&](int src_array) { // extra tile = head rechannel of src_array, extra consts = its bias
+      // extra tile = head rechannel of src_array (+ its bias as the extra consts), outputs in layout `mode_out`
+      auto head_into = [&](int src_array, int mode_out) {
         const LayerArraySpec& S = wn.arrays[src_array];
         const float* hw = ptrs[src_array].head;
+        const float* hb = hw + (size_t)S.head_size * S.channels;
         const int xt = xt_next++;
         D.xt_b = a1.ws_lds_xt_b + xt * 1024;
-        for (int h = 0; h < S.head_size; h++)
-          for (int c = 0; c < S.channels; c++)
-            tile_at(ji, -1 - xt, h, c) = *(hw++);
-        for (int h = 0; h < S.head_size; h++)
-          const_at(ji, 3, h) = S.head_bias ? *(hw++) : 0.0f;
+        fill_tile(ji, -1 - xt, S.head_size, S.channels, mode_out, mode_of(S.channels),
+                  [&](int h, int c) { return hw[(size_t)h * S.channels + c]; });
+        fill_const(ji, 3, S.head_size, mode_out, [&](int h) { return S.head_bias ? hb[h] : 0.0f; });
       };
       if (l == 0 && ai == 0)
       {
         D.flags |= CD_X0;
+        fill_const(ji, 3, C, mode, [&](int c) { return ptrs[0].rech[c]; });
         for (int co = 0; co < C; co++)
-        {
-          const_at(ji, 3, co) = ptrs[0].rech[co];
-          plan.blob[(size_t)a1.ws_r1_off + co] = ptrs[0].rech[co];
-        }
+          plan.blob[(size_t)a1.ws_r1_off + co] = ptrs[0].rech[co]; // movers: natural order
       }
       else if (l == 0)
       {
-        D.flags |= CD_PRE_HEAD;
-        head_into(ai - 1);
+        D.flags |= CD_PRE_HEAD | (mode_of(wn.arrays[ai - 1].channels) == HALF ? CD_PREV_HALF : 0);
+        head_into(ai - 1, mode);
       }
       if (l == NL - 1 && ai + 1 < n_arrays)
       {
@@ -528,15 +550,14 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
         const float* rw = ptrs[ai + 1].rech; // [co][ci], no bias
         const int xt = xt_next++;
         D.xt_b = a1.ws_lds_xt_b + xt * 1024;
-        for (int co = 0; co < N.channels; co++)
-          for (int ci = 0; ci < N.input_size; ci++)
-            tile_at(ji, -1 - xt, co, ci) = *(rw++);
+        fill_tile(ji, -1 - xt, N.channels, N.input_size, mode_of(N.channels), mode,
+                  [&](int co, int ci) { return rw[(size_t)co * N.input_size + ci]; });
         pubmax = 16 * (N.channels / 4 - 1);
       }
       else if (l == NL - 1)
       {
         D.flags |= CD_POST_OUT;
-        head_into(ai);
+        head_into(ai, FULL);
       }
       D.gp = g16max | (pubmax << 8);
       (void)H;

@@ -192,7 +192,9 @@ enum CDescFlags : int32_t
   CD_X0 = 2, // first job of a block: x = rechannel column (extra consts) * input sample, head = 0
   CD_PRE_HEAD = 4, // first layer of a later array: head = HeadW(prev array) . head + head bias (extra tile / consts)
   CD_POST_RECH = 8, // last layer of a non-final array: x = RechW(next array) . x (extra tile) before publishing
-  CD_POST_OUT = 16 // last layer of the final array: out = head_scale * (HeadW . head + head bias)[0]
+  CD_POST_OUT = 16, // last layer of the final array: out = head_scale * (HeadW . head + head bias)[0]
+  CD_HALF = 32, // 8-channel array: duplicated / rotated lane layout, two k-steps per matrix (plan.cpp)
+  CD_PREV_HALF = 64 // CD_PRE_HEAD: the previous array's head accumulator is in the half layout
 };
 struct CDesc // 8 x int32, one s_load_dwordx8
 {
