@@ -5,7 +5,7 @@ L=neuralampmodelercore_amd/lib
 cp $L/libnam_hip.so $L/libnam_hip.so.base
 for v in base "$@"; do
   cp $L/libnam_hip.so.$v $L/libnam_hip.so
-  for args in "--launch block --steps 2000 --warmup 200" "--launch resident --steps 2000 --warmup 200"; do
+  for args in "--launch block --steps 3000 --warmup 300"; do
     python bench.py --kernel ${KERNEL:-a1_ws} $args --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read())
