@@ -18,4 +18,3 @@ for w in range(8):
     if w < 4:
         names = ["barrier exit->taps ready", "->conv done", "->x updated", "->published", "->job end (bookkeeping)"]
         print("      " + "; ".join(f"{n} {int(t[w, 2 + k]) / jobs:.0f}" for k, n in enumerate(names)))
-print(f"workgroup 0 wall clock: entry->prologue barrier {(int(t[8, 1]) - int(t[8, 0])) * 10} ns, prologue->exit {(int(t[8, 2]) - int(t[8, 1])) * 10} ns")
