@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--model", default="wavenet_a1_standard")
     ap.add_argument("--fast-tanh", type=int, default=1, help="benchmodel default: fast tanh ON (tools/benchmodel.cpp:27)")
     ap.add_argument("--launch", choices=["block", "resident"], default="block")
-    ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma", "a1_ws"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=1, help="verify stream 0 of rank 0 against the oracle after timing")
     args = ap.parse_args()
@@ -213,7 +213,7 @@ def main():
 
     batch = model.batch(n_streams, block, device=local_rank)
     if args.kernel != "auto":
-        batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA, "a1_ws": nam.KERNEL_A1_WS}[args.kernel])
+        batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[args.kernel])
     batch.Reset(prewarm=True)
     # a dedicated (non-null) HIP stream: the kernels are launched on it through the C ABI and the
     # HIP events that time them are recorded on the same stream
@@ -290,7 +290,7 @@ def main():
         hist = wavenet_history_bytes_per_sample(mj["config"]) if mj["architecture"] == "WaveNet" else 0
         bytes_per_sample = hist + 4 * (ic + oc)
         achieved_gbs = bytes_per_sample * samples_per_launch / avg_launch_s / 1e9
-        kname = {1: "generic", 2: "a1_valu", 3: "a1_mfma", 4: "a1_ws"}.get(batch.get_kernel(), "?")
+        kname = {1: "generic", 2: "a1_valu", 3: "a1_mfma"}.get(batch.get_kernel(), "?")
         tr = measured_traffic(kname, n_streams, block, args.launch)
         out = {
             "metric": "real-time audio streams (xRT) at 48 kHz, wavenet_a1_standard" if args.model == "wavenet_a1_standard"

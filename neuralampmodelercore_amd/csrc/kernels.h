@@ -69,7 +69,6 @@ struct LSTMArgs
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
-hipError_t launch_a1_ws(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);
 int lstm_lds_bytes(const LSTMArgs& a);
 hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,

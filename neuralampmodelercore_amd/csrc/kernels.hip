@@ -576,44 +576,23 @@ __global__ __launch_bounds__(64) void nam_a1_kernel(const A1Plan* __restrict__ P
 }
 
 // ------------------------------------------------------------------------------------------------
-// A1-family MFMA kernel: one workgroup (4 wavefronts) per stream, 64-frame blocks, job pipeline
+// A1-family MFMA kernel — shared helpers (the kernel itself, nam_a1_mfma_kernel, is further down)
 // ------------------------------------------------------------------------------------------------
-// Every matrix product of the model is (C x Kdim) * (Kdim x 64 frames); wave w owns frames
+// Every matrix product of the model is (C x Kdim) * (Kdim x 64 frames); compute wave w owns frames
 // [16w, 16w+16) and issues v_mfma_f32_16x16x4_f32 (exact fp32: bitwise an ordered fmaf chain).
-// Lane l = (g = l >> 4, j = l & 15) of wave w:
+// Lane l = (g = l >> 4, j = l & 15) of wave w, FULL layout (plan.cpp describes the HALF layout of
+// 8-channel arrays):
 //   D (4 VGPR)  out channels 4g + r, r = 0..3, of frame 16w + j          (residual x, head, z live here)
 //   B operand   k-step s feeds row k = g with channel 4g + s of frame 16w + j — THE LANE'S OWN D VALUES,
 //               so the current tap, the 1x1, the rechannel and the head need no data movement at all
-//   A operand   tile value W[out = j][in = 4g + s] (plan.h: tiles are packed for exactly this mapping)
-// Only the time-shifted taps leave the registers: each lane fetches its 4 channels of frame
-// (16w + j - L) with ONE 16-byte LDS read from a frame-major window (lookback L <= 64:
-// [previous 64 | current 64] frames) or tap buffer (L > 64), both filled from the stream's
-// frame-major history ring in HBM with 16-byte accesses.
-//
-// The model is flattened into a job table (plan.h: rechannel / layer / head; MDesc holds every
-// host-decidable quantity as a ready byte offset). With one workgroup per CU (the 256-stream
-// headline shape) a wavefront has its SIMD to itself and issues at most ~1 instruction per 4 clocks,
-// so the kernel is written for INSTRUCTION COUNT: 16-byte LDS / VMEM operations only, scalar ring
-// arithmetic, one descriptor load per job, activation resolved at compile time.
-// The path is also bound by the latency of the history reads (3,840 B per stream-sample stream
-// through HBM / Infinity Cache; they cannot live in LDS), so every global load a job needs — its
-// 64 B of weight-tile values per lane, three 64-frame history sets, the input sample — is issued
-// kMfPrefetch jobs ahead into rotating VGPR slots; history is dropped into LDS one job early. A raw
-// s_barrier (no vmcnt drain) keeps the loads in flight and, because every load is unconditional
-// (selects act on the ADDRESS, no branch surrounds a load), the compiler's counted
-// s_waitcnt vmcnt(N) retires exactly the oldest slot.
+//   A operand   tile value W[out = j][in = 4g + s] (plan.cpp packs the tiles for exactly this mapping)
+// Only the time-shifted taps leave the registers: each lane fetches its channels of frame
+// (16w + j - L) with ONE LDS read from a frame-major window (lookback L <= 64: [previous 64 |
+// current 64] frames) or tap buffer (L > 64), both filled from the stream's frame-major history ring
+// in HBM with 16-byte accesses.
 namespace mf
 {
 using f4 = __attribute__((ext_vector_type(4))) float;
-constexpr int SC = kMfSC;
-constexpr int D = kMfPrefetch;
-
-struct Slot // one job's worth of prefetched history, per lane
-{
-  f4 h[3]; // [0] = previous 64 frames (window), [1] = tap 0 (lookback 2d), [2] = tap 1 (lookback d)
-  float inp; // the lane's input sample of the block the job belongs to (used by the block's first job)
-};
-
 __device__ __forceinline__ float rcp(float x)
 {
   return __builtin_amdgcn_rcpf(x);
@@ -698,14 +677,6 @@ __device__ __forceinline__ void lds_barrier()
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ f4 mfma4(const f4& a, const f4& b, f4 acc)
-{
-  // four k-steps: step s multiplies tile value a[s] with the lane's channel-s value b[s]
-#pragma unroll
-  for (int s = 0; s < 4; s++)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-  return acc;
-}
 template <int NK>
 __device__ __forceinline__ f4 mfma_n(const f4& a, const f4& b, f4 acc)
 {
@@ -740,295 +711,6 @@ __device__ __forceinline__ void ring_store(char* base, unsigned off, mf::f4 v)
     *reinterpret_cast<mf::f4*>(base + off) = v;
 }
 
-template <int ACT_T, bool DBG, bool WT>
-__global__ __launch_bounds__(256) void nam_a1_mfma_kernel(const A1Plan* __restrict__ P,
-                                                          const float* __restrict__ blob, const A1Args a)
-{
-  using namespace mf;
-  // one LDS array (a single __shared__ object keeps every access a plain ds_* instruction); plan.h kMf*:
-  //   window  [2][128][SC]     [buf][frame -64..63][channel]: previous 64 | current 64 frames of a layer input
-  //   taps    [2][2][64][SC]   [buf][tap][frame 0..63][channel]: far taps (lookback > 64)
-  //   consts  [jobs][48]
-  // (weight tiles never touch LDS: each wave loads its own copy straight into VGPRs, L1 serves the repeats)
-  __shared__ __attribute__((aligned(16))) float lds_f[kMfLdsFloats];
-  char* const lds = reinterpret_cast<char*>(lds_f);
-
-  const int tid = threadIdx.x;
-  long long* wall = nullptr; // DBG: wall-clock (100 MHz) stamps of the first / last workgroup: rows 95 / 94
-  if constexpr (DBG)
-  {
-    if (a.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-      wall = a.dbg + (blockIdx.x == 0 ? 95 : 94) * 8;
-    if (wall)
-      wall[0] = wall_clock64();
-  }
-  const int lane = tid & 63;
-  const int w = uni(tid >> 6); // wave id = 16-frame tile
-  const int g = lane >> 4; // channel quad: this lane owns channels 4g..4g+3
-  const int frame = 16 * w + (lane & 15); // this lane's frame inside the 64-frame block
-  const int hfr = 16 * w + (lane >> 2); // history mover: frame inside a 64-frame set
-  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
-  float* st = a.state + (size_t)stream * a.state_stride;
-  char* stb = reinterpret_cast<char*>(st);
-  int* wpos_tbl = reinterpret_cast<int*>(st);
-  const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
-  float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
-  const char* ibase = in ? reinterpret_cast<const char*>(in) : stb; // silence: any valid word, masked to 0 later
-  const int n_rings = a.n_rings;
-  const int NJ = a.n_mjobs;
-  const float head_scale = a.head_scale;
-  const float act_p0 = a.act_p0;
-  const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
-  const int total = n_blocks * NJ;
-
-  // per-lane byte offsets that never change
-  const unsigned v_g16 = (unsigned)g * 16u; // this lane's channel quad inside a frame row
-  const unsigned v_tap = (unsigned)(frame * SC) * 4u; // row of this lane's frame in a 64-frame operand set
-  const unsigned v_hist = (unsigned)(hfr * SC + 4 * (lane & 3)) * 4u; // where this lane drops its 16 B of history
-  const unsigned v_hq16 = (unsigned)(lane & 3) * 16u; // history mover: channel quad
-  const unsigned v_tile = (unsigned)lane * 64u; // this lane's 16 tile values inside a job's 4 KB tile area
-
-  // prologue: everything below is an independent load off kernel arguments (no load depends on another)
-  int wposv = wpos_tbl[lane]; // the table is 64 words: every wave keeps its own copy of all ring positions
-  const int ring_len_v = P->ring_len_by_id[lane];
-  {
-    const float* __restrict__ csrc = blob + a.consts_off;
-    float cv[(kMJobMax * 48 + 255) / 256];
-#pragma unroll
-    for (int i = 0; i < (kMJobMax * 48 + 255) / 256; i++)
-      cv[i] = (tid + 256 * i < NJ * 48) ? csrc[tid + 256 * i] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < (kMJobMax * 48 + 255) / 256; i++)
-      if (tid + 256 * i < kMJobMax * 48)
-        lds_f[kMfConstsOff + tid + 256 * i] = cv[i];
-  }
-
-  // ---- history prefetch of the job described by (rbase, cmul, R, L0, L1, ring_id, q16max): 4 loads ----
-  auto fetch = [&](Slot& s, int f_rbase, int f_cmul, int f_R, int f_L0, int f_L1, int f_ring_id, int f_q16max,
-                   bool next_block, int jblk) {
-    int wp = __builtin_amdgcn_readlane(wposv, f_ring_id);
-    if (next_block)
-    {
-      wp += kBlock;
-      if (wp >= f_R)
-        wp -= f_R;
-    }
-    const unsigned vq = min(v_hq16, (unsigned)f_q16max) + (unsigned)f_rbase;
-    const int Ls[3] = {kBlock, f_L0, f_L1};
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-    {
-      int sb = wp - Ls[t]; // scalar: ring index of the set's frame 0 (before the per-wave 16w offset)
-      if (sb < 0)
-        sb += f_R;
-      const unsigned v = (unsigned)(hfr + sb);
-      const unsigned idx = min(v, v - (unsigned)f_R); // v < 2R: wraps at most once
-      s.h[t] = *reinterpret_cast<const f4*>(stb + (__umul24(idx, (unsigned)f_cmul) + vq));
-    }
-    int fi = jblk * kBlock + frame;
-    fi = min(fi, a.n_frames - 1);
-    s.inp = *reinterpret_cast<const float*>(ibase + (in ? (unsigned)fi * 4u : 0u));
-  };
-  // ---- weight-tile prefetch: this lane's 16 A-operand values (64 contiguous bytes) of job `job`; the tile
-  // areas of consecutive jobs are contiguous in the blob ----
-  const char* tiles0 = reinterpret_cast<const char*>(blob + a.tiles_off);
-  auto fetch_tiles = [&](f4 (&ta)[4], int job) {
-    const char* tp = tiles0 + (size_t)job * 4096;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      ta[q] = *reinterpret_cast<const f4*>(tp + (v_tile + 16u * q));
-  };
-
-  Slot slot[D];
-  f4 ta[D][4];
-#pragma unroll
-  for (int u = 0; u < D; u++)
-  {
-    // job u's history (u < NJ always: a model has at least 3 jobs... use the generic path otherwise)
-    const MJob J = P->mjobs[u % NJ];
-    const bool fr = J.type == MJ_LAYER && J.ring_id >= 0;
-    fetch(slot[u], fr ? J.ring_off * 4 : 0, fr ? J.C * 4 : 0, fr ? J.R : 64, fr ? 2 * J.d : 64, fr ? J.d : 64,
-          fr ? J.ring_id : 0, 16 * (J.CS - 1), u >= NJ, u / NJ);
-    fetch_tiles(ta[u], u % NJ);
-  }
-
-  // running state
-  f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f}, hprev = {0.f, 0.f, 0.f, 0.f};
-  int ji = 0, blk = 0;
-  int jt = D % NJ; // job whose tiles are fetched next
-  int fblk = (D + 1) / NJ; // block of the job whose history is fetched next (job ji + 1 + D)
-  int fj = (D + 1) % NJ;
-  int nvalid = min(kBlock, a.n_frames);
-  bool lane_live = frame < nvalid;
-  MDesc Dn = P->mdesc[0]; // descriptors are scalar-loaded one job ahead of their use
-  float cond = (in && lane_live) ? slot[0].inp : 0.0f; // job 0 is the block's first job
-  // job 0's history goes to LDS now (job 0 is never a LAYER, but keep the pipeline uniform); afterwards
-  // every job drops its SUCCESSOR's history while it computes. Slot 0 is then refilled with job D.
-  {
-    const MJob J0 = P->mjobs[0];
-    lds_st4(lds, v_hist + (unsigned)(kMfXwOff + J0.buf * kMfXwFloats) * 4u, slot[0].h[0]);
-    const MJob J = P->mjobs[D % NJ];
-    const bool fr = J.type == MJ_LAYER && J.ring_id >= 0;
-    fetch(slot[0], fr ? J.ring_off * 4 : 0, fr ? J.C * 4 : 0, fr ? J.R : 64, fr ? 2 * J.d : 64, fr ? J.d : 64,
-          fr ? J.ring_id : 0, 16 * (J.CS - 1), D >= NJ, D / NJ);
-  }
-  // (consts + job 0's history become visible at job 0's barrier; no vmcnt drain here)
-  if (DBG && wall)
-    wall[1] = wall_clock64();
-
-  // Software pipeline, one barrier per job. In job i (u = i % D):
-  //   barrier                 -> job i's history (dropped during job i-1) and x published by job i-1 are visible
-  //   issue job i's LDS operand reads (2 shifted taps + 3 constant vectors; weight tiles are in ta[u])
-  //   drop job i+1's history (slot u+1) into the OTHER halves of the double buffers, refill that slot with
-  //   job i+1+D; conv MFMAs; activation; 1x1; publish x; ring append; refill ta[u] with job i+D
-  for (int q0 = 0; q0 < total; q0 += D)
-  {
-#pragma unroll
-    for (int u = 0; u < D; u++)
-    {
-      // NOTE: no branch around a whole job: past the end it degenerates to flags = 0 (barrier, history drop
-      // and dummy prefetch only), which keeps the number of loads in flight statically known.
-      const bool active = q0 + u < total;
-      const MDesc J = Dn;
-      Dn = P->mdesc[ji + 1 == NJ ? 0 : ji + 1];
-      const int flags = active ? J.flags : 0;
-      const int un = (u + 1) % D; // constant after unrolling: slot[] stays in registers
-      long long* dbg = nullptr;
-      if constexpr (DBG)
-        dbg = (a.dbg && blockIdx.x == 0 && tid == 0 && q0 + u < 94) ? a.dbg + (q0 + u) * 8 : nullptr;
-      if (DBG && dbg)
-        dbg[0] = __builtin_readcyclecounter();
-      lds_barrier();
-      if (DBG && dbg)
-        dbg[1] = __builtin_readcyclecounter();
-
-      // 1. operand reads first (their latency starts now): 2 shifted taps + 3 constant vectors, 16 B each.
-      //    Lanes whose channel quad does not exist (g >= C/4) read the last real quad: finite data that
-      //    only ever meets zero weights.
-      const unsigned gq16 = min(v_g16, (unsigned)J.g16max);
-      const unsigned a_tap = v_tap + gq16;
-      const f4 bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
-      const f4 bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
-      const unsigned a_c = v_g16 + (unsigned)J.consts_b;
-      const f4 bv4 = lds_ld4(lds, a_c), mv = lds_ld4(lds, a_c + 64u), b1v = lds_ld4(lds, a_c + 128u);
-      if (DBG && dbg)
-      {
-        asm volatile("" ::"v"(bv4), "v"(mv), "v"(b1v), "v"(bt0), "v"(bt1));
-        dbg[6] = __builtin_readcyclecounter();
-      }
-      const f4 x_in = x; // the layer INPUT: appended to the history ring at the end of the job
-      // 2. successor: drop job i+1's history into LDS (3 x 16 B; quads beyond its C land in row padding),
-      //    then refill that slot with the history of job i+1+D
-      const float inp_next = slot[un].inp;
-      lds_st4(lds, v_hist + (unsigned)J.st_win_b, slot[un].h[0]);
-      lds_st4(lds, v_hist + (unsigned)J.st_tb0_b, slot[un].h[1]);
-      lds_st4(lds, v_hist + (unsigned)J.st_tb1_b, slot[un].h[2]);
-      if (DBG && dbg)
-        dbg[7] = __builtin_readcyclecounter();
-      {
-        const bool valid = fblk < n_blocks;
-        fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_cmul : 0, valid ? J.f_R : 64, valid ? J.f_L0 : 64,
-              valid ? J.f_L1 : 64, valid ? J.f_ring_id : 0, J.f_q16max, valid && (fblk > blk), valid ? fblk : blk);
-        if (++fj == NJ)
-        {
-          fj = 0;
-          fblk++;
-        }
-      }
-      if (DBG && dbg)
-        dbg[2] = __builtin_readcyclecounter();
-
-      // 3. dilated conv, 3 taps x 4 k-steps; tap 2 (the current frame) multiplies the lane's own x. Two
-      //    accumulators shorten the dependent chain. Issued for EVERY job type (others discard it) so the
-      //    MFMAs share a basic block with the code above.
-      f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      acc0 = mfma4(ta[u][0], bt0, acc0);
-      acc1 = mfma4(ta[u][1], bt1, acc1);
-      acc0 = mfma4(ta[u][2], x, acc0);
-      const f4 acc = acc0 + acc1;
-
-      if (flags & MD_LAYER)
-      {
-        if (DBG && dbg)
-        {
-          asm volatile("" ::"v"(acc));
-          dbg[3] = __builtin_readcyclecounter();
-        }
-        // 4. bias + input mixin + activation; head accumulate
-        f4 pre;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          pre[r] = fmaf(mv[r], cond, acc[r] + bv4[r]);
-        const f4 z = act4<ACT_T>(J.act, pre, act_p0);
-        head += z;
-        // 5. layer1x1: z is already this lane's B operand
-        const f4 y = mfma4(ta[u][3], z, f4{0.f, 0.f, 0.f, 0.f});
-        x = x + (y + b1v);
-        if (DBG && dbg)
-        {
-          asm volatile("" ::"v"(x));
-          dbg[4] = __builtin_readcyclecounter();
-        }
-        // 6. publish x (the next layer's input) into the other window buffer; append the layer INPUT to its
-        //    history ring (frame-major: 16 B per lane). Lanes without real channels / frames stay out.
-        if (v_g16 <= (unsigned)J.g16max)
-        {
-          lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
-          if ((flags & MD_RING) && lane_live)
-          {
-            const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + frame);
-            const unsigned widx = min(v, v - (unsigned)J.R);
-            ring_store<WT>(stb, __umul24(widx, (unsigned)J.cmul) + v_g16 + (unsigned)J.ring_b, x_in);
-          }
-        }
-      }
-      else if (flags & MD_RECH1)
-      {
-        x = bv4 * cond; // consts[0..15] = rechannel column (in_size == 1)
-        head = f4{0.f, 0.f, 0.f, 0.f};
-        if (v_g16 <= (unsigned)J.g16max)
-          lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
-      }
-      else if (flags & MD_RECH)
-      {
-        // the previous array's last-layer output is still in x (this lane's own channels)
-        x = mfma4(ta[u][0], x, f4{0.f, 0.f, 0.f, 0.f});
-        head = (flags & MD_FIRST) ? f4{0.f, 0.f, 0.f, 0.f} : hprev;
-        if (v_g16 <= (unsigned)J.g16max)
-          lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
-      }
-      else if (flags & MD_HEAD) // hout[h] = bh[h] + sum_c Wh[h][c] * head[c]
-      {
-        hprev = mfma4(ta[u][0], head, f4{0.f, 0.f, 0.f, 0.f}) + bv4;
-        if ((flags & MD_LAST) && out && g == 0 && lane_live)
-          out[(size_t)blk * kBlock + frame] = head_scale * hprev[0];
-      }
-      // 7. this job's weight tiles are consumed: refill the tile slot for the job D ahead
-      fetch_tiles(ta[u], jt);
-      if (++jt == NJ)
-        jt = 0;
-      if (DBG && dbg)
-        dbg[5] = __builtin_readcyclecounter();
-
-      if (active && ++ji == NJ)
-      {
-        // block finished: advance every ring's write position, take the next block's input sample
-        ji = 0;
-        wposv += nvalid;
-        if (wposv >= ring_len_v)
-          wposv -= ring_len_v;
-        blk++;
-        nvalid = min(kBlock, a.n_frames - blk * kBlock);
-        lane_live = frame < nvalid;
-        cond = (in && lane_live) ? inp_next : 0.0f;
-      }
-    }
-  }
-  if (w == 0 && lane < n_rings)
-    wpos_tbl[lane] = wposv;
-  if (DBG && wall)
-    wall[2] = wall_clock64();
-}
 
 // ------------------------------------------------------------------------------------------------
 // LSTM: lanes = streams (a true per-sample recurrence — NAM/lstm.cpp:103-168)
@@ -1177,7 +859,7 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
 }
 
 // ================================================================================================
-// nam_a1_ws_kernel — wave-specialised MFMA kernel: 8 wavefronts per stream, one job per LAYER.
+// nam_a1_mfma_kernel — wave-specialised fp32-MFMA kernel: 8 wavefronts per stream, one job per LAYER.
 //   waves 0-3 (compute): per job one barrier, 3 LDS reads on the critical path (two shifted taps + the input
 //                        sample), 16-20 MFMAs, activation, publish x. The job's weight tiles and constants are
 //                        already in registers: they are read from LDS one job ahead, in the shadow of the MFMAs.
@@ -1214,7 +896,7 @@ struct Ops // one job's register-resident operands (compute waves)
 } // namespace ws
 
 template <int ACT_T, bool WT, bool PROF>
-__global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict__ P, const float* __restrict__ blob,
+__global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restrict__ P, const float* __restrict__ blob,
                                                         const A1Args a)
 {
   using namespace mf;
@@ -1587,63 +1269,36 @@ __global__ __launch_bounds__(512) void nam_a1_ws_kernel(const A1Plan* __restrict
 
 namespace
 {
-template <int ACT_T, bool DBG>
-void launch_a1_mfma_wt(const A1Args& a, int n_blocks, hipStream_t stream)
-{
-  // short launches write ring appends through (see ring_store)
-  if (a.n_frames <= 2 * kBlock)
-    hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, DBG, true>), dim3(n_blocks), dim3(256), 0, stream, a.plan, a.blob, a);
-  else
-    hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, DBG, false>), dim3(n_blocks), dim3(256), 0, stream, a.plan, a.blob, a);
-}
-} // namespace
-
-hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream)
-{
-  // activation resolved at compile time for the two types that matter; a timeline build for the developer tool
-  if (a.dbg)
-    launch_a1_mfma_wt<-1, true>(a, n_blocks, stream);
-  else if (act == ACT_FASTTANH)
-    launch_a1_mfma_wt<ACT_FASTTANH, false>(a, n_blocks, stream);
-  else if (act == ACT_TANH)
-    launch_a1_mfma_wt<ACT_TANH, false>(a, n_blocks, stream);
-  else
-    launch_a1_mfma_wt<-1, false>(a, n_blocks, stream);
-  return hipGetLastError();
-}
-
-namespace
-{
 template <int ACT_T, bool WT, bool PROF>
-hipError_t launch_ws_inst(const A1Args& a, int n_blocks, hipStream_t stream)
+hipError_t launch_mfma_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 {
   static int lds_limit = 0; // per instantiation: dynamic LDS the runtime has been told about
   if (a.lds_bytes > lds_limit)
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_ws_kernel<ACT_T, WT, PROF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_mfma_kernel<ACT_T, WT, PROF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess)
       return e;
     lds_limit = a.lds_bytes;
   }
-  hipLaunchKernelGGL((nam_a1_ws_kernel<ACT_T, WT, PROF>), dim3(n_blocks), dim3(512), a.lds_bytes, stream, a.plan, a.blob, a);
+  hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, WT, PROF>), dim3(n_blocks), dim3(512), a.lds_bytes, stream, a.plan, a.blob, a);
   return hipGetLastError();
 }
 } // namespace
 
-hipError_t launch_a1_ws(const A1Args& a, int n_blocks, int act, hipStream_t stream)
+hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
   if (a.dbg) // developer tool: barrier-wait profile of workgroup 0
-    return act == ACT_FASTTANH ? launch_ws_inst<ACT_FASTTANH, false, true>(a, n_blocks, stream)
-                               : launch_ws_inst<-1, false, true>(a, n_blocks, stream);
+    return act == ACT_FASTTANH ? launch_mfma_inst<ACT_FASTTANH, false, true>(a, n_blocks, stream)
+                               : launch_mfma_inst<-1, false, true>(a, n_blocks, stream);
   if (act == ACT_FASTTANH)
-    return wt ? launch_ws_inst<ACT_FASTTANH, true, false>(a, n_blocks, stream)
-              : launch_ws_inst<ACT_FASTTANH, false, false>(a, n_blocks, stream);
+    return wt ? launch_mfma_inst<ACT_FASTTANH, true, false>(a, n_blocks, stream)
+              : launch_mfma_inst<ACT_FASTTANH, false, false>(a, n_blocks, stream);
   if (act == ACT_TANH)
-    return wt ? launch_ws_inst<ACT_TANH, true, false>(a, n_blocks, stream)
-              : launch_ws_inst<ACT_TANH, false, false>(a, n_blocks, stream);
-  return wt ? launch_ws_inst<-1, true, false>(a, n_blocks, stream) : launch_ws_inst<-1, false, false>(a, n_blocks, stream);
+    return wt ? launch_mfma_inst<ACT_TANH, true, false>(a, n_blocks, stream)
+              : launch_mfma_inst<ACT_TANH, false, false>(a, n_blocks, stream);
+  return wt ? launch_mfma_inst<-1, true, false>(a, n_blocks, stream) : launch_mfma_inst<-1, false, false>(a, n_blocks, stream);
 }
 
 int lstm_lds_bytes(const LSTMArgs& a)

@@ -177,16 +177,13 @@ int refresh_map(nam_hip_batch* b, WidthGroup& g)
 int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 {
   const bool a1 = g.plan->a1.valid && g.d_a1;
-  const bool mfma = a1 && g.plan->a1.mfma_ok;
-  const bool ws = mfma && g.plan->a1.ws_ok;
+  const bool mfma = a1 && g.plan->a1.ws_ok;
   const int fallback = a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
   switch (b->kernel)
   {
     case NAM_HIP_KERNEL_GENERIC: return NAM_HIP_KERNEL_GENERIC;
     case NAM_HIP_KERNEL_A1: return fallback;
-    case NAM_HIP_KERNEL_A1_MFMA: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback;
-    case NAM_HIP_KERNEL_A1_WS: return ws ? NAM_HIP_KERNEL_A1_WS : fallback;
-    default: return ws ? NAM_HIP_KERNEL_A1_WS : (mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback);
+    default: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback; // AUTO or A1_MFMA
   }
 }
 
@@ -215,34 +212,27 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.act_p0 = 0.01f;
       a.dbg = b->dbg;
       a.n_rings = p.a1.n_rings;
-      a.n_mjobs = p.a1.n_mjobs;
-      a.tiles_off = p.a1.n_mjobs > 0 ? p.a1.mjobs[0].tiles : 0;
-      a.consts_off = p.a1.mconsts_off;
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
+      a.n_mjobs = a.tiles_off = a.consts_off = 0;
       a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = 0;
-      if (kernel == NAM_HIP_KERNEL_A1_MFMA || kernel == NAM_HIP_KERNEL_A1_WS)
+      if (kernel == NAM_HIP_KERNEL_A1_MFMA)
       {
         // uniform activation across arrays -> compile-time specialised kernel, else run-time dispatch
         int act = p.a1.arr[0].act;
         for (int i = 1; i < p.a1.n_arrays; i++)
           if (p.a1.arr[i].act != act)
             act = -1;
-        if (kernel == NAM_HIP_KERNEL_A1_WS)
-        {
-          a.n_mjobs = p.a1.ws_jobs;
-          a.tiles_off = p.a1.ws_tiles_off;
-          a.consts_off = p.a1.ws_consts_off;
-          a.r1_off = p.a1.ws_r1_off;
-          a.xt_off = p.a1.ws_xt_off;
-          a.n_xt = p.a1.ws_n_xt;
-          a.lds_tiles_b = p.a1.ws_lds_tiles_b;
-          a.lds_xt_b = p.a1.ws_lds_xt_b;
-          a.lds_cond_b = p.a1.ws_lds_cond_b;
-          a.lds_bytes = p.a1.ws_lds_bytes;
-          NAM_HIP_CHECK(launch_a1_ws(a, n, act, s));
-        }
-        else
-          NAM_HIP_CHECK(launch_a1_mfma(a, n, act, s));
+        a.n_mjobs = p.a1.ws_jobs;
+        a.tiles_off = p.a1.ws_tiles_off;
+        a.consts_off = p.a1.ws_consts_off;
+        a.r1_off = p.a1.ws_r1_off;
+        a.xt_off = p.a1.ws_xt_off;
+        a.n_xt = p.a1.ws_n_xt;
+        a.lds_tiles_b = p.a1.ws_lds_tiles_b;
+        a.lds_xt_b = p.a1.ws_lds_xt_b;
+        a.lds_cond_b = p.a1.ws_lds_cond_b;
+        a.lds_bytes = p.a1.ws_lds_bytes;
+        NAM_HIP_CHECK(launch_a1_mfma(a, n, act, s));
       }
       else
         NAM_HIP_CHECK(launch_a1(a, n, s));
@@ -435,8 +425,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
   info->output_level = s.output_level;
   info->num_weights = s.arch == ARCH_WAVENET ? (int64_t)s.wavenet.weights.size() : (int64_t)s.lstm.weights.size();
   info->fast_tanh = s.fast_tanh ? 1 : 0;
-  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && p.a1.mfma_ok) ? 2 : 0)
-                       | ((p.a1.valid && p.a1.mfma_ok && p.a1.ws_ok) ? 4 : 0);
+  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && p.a1.ws_ok) ? 2 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -683,17 +672,15 @@ int nam_hip_batch_synchronize(nam_hip_batch* batch)
 
 int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
-  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_WS)
+  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_MFMA)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
   if (kernel >= NAM_HIP_KERNEL_A1)
     for (const auto& g : batch->groups)
     {
       if (g.plan->arch != ARCH_WAVENET || !g.plan->a1.valid)
         return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 kernels cannot run this model");
-      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !g.plan->a1.mfma_ok)
+      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !g.plan->a1.ws_ok)
         return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 MFMA kernel cannot run this model");
-      if (kernel == NAM_HIP_KERNEL_A1_WS && !(g.plan->a1.mfma_ok && g.plan->a1.ws_ok))
-        return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the wave-specialised A1 kernel cannot run this model");
     }
   batch->kernel = kernel;
   return NAM_HIP_OK;

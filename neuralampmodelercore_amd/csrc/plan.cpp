@@ -375,8 +375,9 @@ bool a1_channel_supported(int c)
   return c == 1 || c == 2 || c == 3 || c == 4 || c == 6 || c == 8 || c == 12 || c == 16;
 }
 
-// Job table of nam_a1_ws_kernel (plan.h: CDesc / VDesc). Requires what build_a1's MFMA table requires, plus
-// at least two layers per array (the extra tile of a job serves either its array's entry or its exit).
+// Job table of nam_a1_mfma_kernel (plan.h: CDesc / VDesc). Requires channels % 4 == 0 (<= 16), kernel size 3,
+// a mono input, and at least two layers per array (the extra tile of a job serves either its array's entry
+// or its exit).
 void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
 {
   A1Plan& a1 = plan.a1;
@@ -390,6 +391,14 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   }
   if (wn.arrays[0].input_size != 1)
     return;
+  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    if (A.channels % 4 != 0 || A.channels > 16 || A.kernel_sizes[0] != 3 || A.head_size > 16)
+      return;
+    if (ai > 0 && (A.input_size % 4 != 0 || A.input_size > 16))
+      return;
+  }
   const int NJ = (n_layers + 1) / 2 * 2;
   const int n_xt = 2 * n_arrays - 1;
   if (NJ > kWsJobMax || NJ < kWsPrefetch + 3 || n_xt > kWsXtMax)
@@ -739,162 +748,6 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
   }
   a1.valid = 1;
 
-  // ---- MFMA job table (v_mfma_f32_16x16x4_f32 A-operand tiles) ----
-  int n_jobs = 0;
-  bool mfma_ok = true;
-  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
-  {
-    const LayerArraySpec& A = wn.arrays[ai];
-    if (A.channels % 4 != 0 || A.channels > 16 || A.kernel_sizes[0] != 3)
-      mfma_ok = false;
-    if (ai > 0 && (A.input_size % 4 != 0 || A.input_size > 16))
-      mfma_ok = false;
-    if (A.head_size > 16)
-      mfma_ok = false;
-    n_jobs += 2 + A.num_layers();
-  }
-  if (!mfma_ok || n_jobs > kMJobMax)
-    return;
-  while (plan.blob.size() % 64)
-    plan.blob.push_back(0.0f);
-  const size_t tiles_base = plan.blob.size();
-  plan.blob.resize(tiles_base + (size_t)n_jobs * 1024 + (size_t)n_jobs * 48 + 64, 0.0f);
-  a1.mconsts_off = (int)(tiles_base + (size_t)n_jobs * 1024);
-  a1.n_mjobs = n_jobs;
-  auto tile_at = [&](int job, int tile, int o, int in_idx) -> float& {
-    // A-operand element W[o][in_idx]: input channel c = 4g + s is fed by lane group g in k-step s, so it
-    // lives in lane (g, o) of tile `tile` (the caller passes tile = tile_base + s with s = in_idx % 4).
-    // The tile area is stored lane-major, [lane][16 tiles], so one lane's 16 operands are 64 contiguous bytes.
-    const int g = in_idx / 4;
-    return plan.blob[tiles_base + (size_t)job * 1024 + (size_t)(g * 16 + o) * 16 + tile];
-  };
-  auto const_at = [&](int job, int vec, int i) -> float& { return plan.blob[(size_t)a1.mconsts_off + (size_t)job * 48 + vec * 16 + i]; };
-  w = wn.weights.data();
-  int ji = 0;
-  for (size_t ai = 0; ai < wn.arrays.size(); ai++)
-  {
-    const LayerArraySpec& A = wn.arrays[ai];
-    const A1Array& arr = a1.arr[ai];
-    const int C = A.channels, K = A.kernel_sizes[0], H = A.head_size, CS = C / 4, IN = A.input_size;
-    auto base_job = [&](int type) -> MJob& {
-      MJob& J = a1.mjobs[ji];
-      std::memset(&J, 0, sizeof(J));
-      J.type = type;
-      J.C = C;
-      J.CS = CS;
-      J.K = K;
-      J.ring_id = -1;
-      J.tiles = (int)(tiles_base + (size_t)ji * 1024);
-      J.consts = ji * 48;
-      J.act = A.activations[0].type;
-      return J;
-    };
-    {
-      MJob& J = base_job(IN == 1 ? MJ_RECH1 : MJ_RECH);
-      J.steps = IN == 1 ? 0 : 4;
-      J.first = ai == 0 ? 1 : 0;
-      for (int co = 0; co < C; co++)
-        for (int ci = 0; ci < IN; ci++)
-        {
-          const float v = *(w++);
-          if (IN == 1)
-            const_at(ji, 0, co) = v;
-          else
-            tile_at(ji, ci % 4, co, ci) = v;
-        }
-      ji++;
-    }
-    for (int l = 0; l < A.num_layers(); l++)
-    {
-      MJob& J = base_job(MJ_LAYER);
-      J.d = A.dilations[l];
-      J.R = arr.ring_len[l];
-      J.ring_off = arr.ring_off[l];
-      J.ring_id = arr.ring_id[l];
-      for (int co = 0; co < C; co++)
-        for (int ci = 0; ci < C; ci++)
-          for (int k = 0; k < K; k++)
-            tile_at(ji, k * 4 + ci % 4, co, ci) = *(w++);
-      for (int co = 0; co < C; co++)
-        const_at(ji, 0, co) = *(w++);
-      for (int co = 0; co < C; co++)
-        const_at(ji, 1, co) = *(w++);
-      for (int co = 0; co < C; co++)
-        for (int ci = 0; ci < C; ci++)
-          tile_at(ji, 12 + ci % 4, co, ci) = *(w++);
-      for (int co = 0; co < C; co++)
-        const_at(ji, 2, co) = *(w++);
-      ji++;
-    }
-    {
-      MJob& J = base_job(MJ_HEAD);
-      J.steps = 4;
-      J.last = (ai + 1 == wn.arrays.size()) ? 1 : 0;
-      for (int h = 0; h < H; h++)
-        for (int c = 0; c < C; c++)
-          tile_at(ji, c % 4, h, c) = *(w++);
-      for (int h = 0; h < H; h++)
-        const_at(ji, 0, h) = A.head_bias ? *(w++) : 0.0f;
-      ji++;
-    }
-  }
-  // static double-buffer parity: RECH1 publishes into the buffer the next job reads; LAYER / RECH read
-  // `buf` and publish into `buf ^ 1`.
-  {
-    int b = 0;
-    for (int j = 0; j < n_jobs; j++)
-    {
-      a1.mjobs[j].buf = b;
-      if (a1.mjobs[j].type == MJ_LAYER || a1.mjobs[j].type == MJ_RECH)
-        b ^= 1;
-    }
-    // the sequence repeats every block: the first job of the next block must not publish into a buffer
-    // that a late wave could still be reading; every block ends with HEAD jobs (no window traffic), so
-    // any parity is safe there.
-  }
-  // executable descriptors
-  for (int j = 0; j < n_jobs; j++)
-  {
-    const MJob& J = a1.mjobs[j];
-    const MJob& N = a1.mjobs[(j + 1) % n_jobs]; // successor: its history is dropped into LDS during job j
-    const int fj = (j + 1 + kMfPrefetch) % n_jobs; // job whose history is prefetched during job j
-    const MJob& F = a1.mjobs[fj];
-    MDesc& D = a1.mdesc[j];
-    std::memset(&D, 0, sizeof(D));
-    auto xw = [](int buf) { return kMfXwOff + buf * kMfXwFloats; };
-    auto tb = [](int buf, int tap) { return kMfTbOff + (buf * 2 + tap) * kMfTbFloats; };
-    D.flags = (J.type == MJ_LAYER ? MD_LAYER : 0) | (J.type == MJ_RECH1 ? MD_RECH1 : 0) | (J.type == MJ_RECH ? MD_RECH : 0)
-              | (J.type == MJ_HEAD ? MD_HEAD : 0) | (J.first ? MD_FIRST : 0) | (J.last ? MD_LAST : 0)
-              | ((J.type == MJ_LAYER && J.ring_id >= 0) ? MD_RING : 0) | ((F.type == MJ_LAYER && F.ring_id >= 0) ? MD_F_RING : 0)
-              | ((j + 1 + kMfPrefetch >= n_jobs) ? MD_F_NEXT : 0);
-    D.act = J.act;
-    D.g16max = 16 * (J.CS - 1);
-    D.consts_b = (kMfConstsOff + J.consts) * 4;
-    for (int k = 0; k < 2; k++)
-    {
-      const int L = (J.type == MJ_LAYER) ? (2 - k) * J.d : 0;
-      const int off = (L <= kBlock) ? xw(J.buf) + (kBlock - L) * kMfSC : tb(J.buf, k);
-      (k == 0 ? D.tap0_b : D.tap1_b) = off * 4;
-    }
-    const int pub_buf = (J.type == MJ_RECH1) ? J.buf : (J.buf ^ 1);
-    D.pub_b = (xw(pub_buf) + kBlock * kMfSC) * 4;
-    D.ring_b = J.ring_off * 4;
-    D.cmul = J.C * 4;
-    D.R = J.R > 0 ? J.R : 64;
-    D.ring_id = J.ring_id >= 0 ? J.ring_id : 0;
-    D.st_win_b = xw(N.buf) * 4;
-    D.st_tb0_b = tb(N.buf, 0) * 4;
-    D.st_tb1_b = tb(N.buf, 1) * 4;
-    const bool fr = F.type == MJ_LAYER && F.ring_id >= 0;
-    D.f_rbase = fr ? F.ring_off * 4 : 0;
-    D.f_cmul = fr ? F.C * 4 : 0;
-    D.f_R = fr ? F.R : 64;
-    D.f_L0 = fr ? 2 * F.d : 64;
-    D.f_L1 = fr ? F.d : 64;
-    D.f_ring_id = fr ? F.ring_id : 0;
-    D.f_q16max = 16 * (F.CS - 1);
-  }
-  a1.mfma_ok = 1;
   build_a1_ws(wn, plan);
 }
 
@@ -937,15 +790,6 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
       for (int l = 0; l < plan.a1.arr[a].n_layers; l++)
         if (plan.a1.arr[a].ring_id[l] >= 0)
           plan.a1.arr[a].ring_off[l] += table;
-    for (int j = 0; j < plan.a1.n_mjobs; j++)
-    {
-      if (plan.a1.mjobs[j].ring_id >= 0)
-        plan.a1.mjobs[j].ring_off += table;
-      if (plan.a1.mdesc[j].flags & MD_RING)
-        plan.a1.mdesc[j].ring_b += table * 4;
-      if (plan.a1.mdesc[j].flags & MD_F_RING)
-        plan.a1.mdesc[j].f_rbase += table * 4;
-    }
     for (int j = 0; j < plan.a1.ws_jobs; j++)
     {
       // (an idle job has ring_b == 0 and never appends; its prefetch geometry points at the table, harmless)

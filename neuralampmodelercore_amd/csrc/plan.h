@@ -89,90 +89,15 @@ struct A1Array
   int32_t ring_id[kA1MaxLayers];
 };
 
-// Job table of the MFMA kernel (nam_a1_mfma_kernel): the model flattened into a straight sequence
-// of jobs, each a handful of v_mfma_f32_16x16x4_f32 k-steps, so that weights and history can be
-// prefetched a fixed number of JOBS ahead regardless of array boundaries.
-//   tiles: 1024 floats per job, lane-major [lane 0..63][16 tiles]. Tile t is the A operand of one k-step:
-//          lane (g = lane >> 4, o = lane & 15) holds W[out = o][in = 4*g + s] where s = t & 3 is the k-step,
-//          i.e. lane group g always feeds ITS OWN channels 4g..4g+3 (the D-layout rows it holds).
-//          LAYER: tile 4*k + s = conv tap k, k-step s; tiles 12..15 = layer1x1. RECH / HEAD: tiles 0..3.
-//   consts: 48 floats per job, padded to 16 per vector — LAYER: conv bias, mixin, b1x1; RECH1: rechannel
-//          column (in_size == 1); HEAD: head bias
-enum MJobType : int32_t
-{
-  MJ_RECH1 = 0, // x = w * input sample            (first array, in_size == 1)
-  MJ_RECH = 1, // x = Wre * previous array output  (MFMA)
-  MJ_LAYER = 2,
-  MJ_HEAD = 3 // head rechannel (K = 1)
-};
-
-struct MJob // 16 x int32
-{
-  int32_t type;
-  int32_t C; // channels of the array
-  int32_t CS; // C / 4
-  int32_t K; // LAYER: kernel size
-  int32_t d; // LAYER: dilation
-  int32_t R; // LAYER: ring length (frames), 0 = no ring
-  int32_t ring_off; // float offset of the ring inside the per-stream state
-  int32_t ring_id; // -1 = none
-  int32_t tiles; // blob offset of this job's 1024-float tile area
-  int32_t consts; // float offset inside the consts table
-  int32_t act; // LAYER: activation type
-  int32_t steps; // RECH / HEAD: number of k-steps (4)
-  int32_t first; // RECH1/RECH of the first array: head accumulator starts at zero
-  int32_t last; // HEAD of the last array: produces the output sample
-  int32_t buf; // which half of the double-buffered LDS window / tap buffers this job READS (see kernel)
-  int32_t pad1;
-};
-static_assert(sizeof(MJob) == 64, "MJob must stay 64 bytes");
-constexpr int kMJobMax = 40;
-
-// LDS geometry of nam_a1_mfma_kernel (shared by the host, which precomputes every per-job LDS offset)
+// LDS geometry of nam_a1_mfma_kernel's history buffers (shared with the host, which precomputes every
+// per-job LDS offset)
 constexpr int kMfSC = 24; // floats per frame row: 6 sixteen-byte slots => conflict-free ds_read_b128 for lane (g, j)
-constexpr int kMfPrefetch = 4; // jobs of global loads in flight
 constexpr int kMfXwFloats = 2 * kBlock * kMfSC; // one window: [previous 64 | current 64] frames
 constexpr int kMfTbFloats = kBlock * kMfSC; // one tap buffer: 64 frames
 constexpr int kMfXwOff = 0; // window [2 buffers]
 constexpr int kMfTbOff = kMfXwOff + 2 * kMfXwFloats; // tap buffers [2 buffers][2 taps]
-constexpr int kMfConstsOff = kMfTbOff + 4 * kMfTbFloats; // consts [jobs][48]
-constexpr int kMfLdsFloats = kMfConstsOff + kMJobMax * 48;
 
-// Per-job descriptor the kernel actually executes from: everything that can be decided on the host is —
-// LDS byte offsets, ring geometry of this job, where the SUCCESSOR's history is dropped, and the ring
-// geometry of the job whose history is prefetched now (kMfPrefetch + 1 jobs ahead).
-enum MDescFlags : int32_t
-{
-  MD_LAYER = 1,
-  MD_RECH1 = 2,
-  MD_RECH = 4,
-  MD_HEAD = 8,
-  MD_FIRST = 16, // head accumulator starts at zero
-  MD_LAST = 32, // produces the output sample
-  MD_RING = 64, // this job appends its input to a history ring
-  MD_F_RING = 256, // the prefetched job has a ring
-  MD_F_NEXT = 512 // the prefetched job belongs to the next block
-};
-
-struct MDesc // 24 x int32
-{
-  int32_t flags;
-  int32_t act;
-  int32_t g16max; // 16 * (C/4 - 1): clamp for the lane's channel-quad byte offset
-  int32_t consts_b; // LDS byte offset of this job's 48 constants
-  int32_t tap0_b, tap1_b; // LDS byte offset of frame 0 of tap k's operand rows (window: already shifted by 64 - L)
-  int32_t pub_b; // LDS byte offset of frame 0 of the window rows x is published to
-  int32_t ring_b; // byte offset of this job's ring inside the stream state
-  int32_t cmul; // bytes per ring frame (C * 4)
-  int32_t R; // ring length in frames
-  int32_t ring_id;
-  int32_t st_win_b, st_tb0_b, st_tb1_b; // LDS byte offsets where the SUCCESSOR's history sets are dropped
-  int32_t f_rbase, f_cmul, f_R, f_L0, f_L1, f_ring_id, f_q16max; // the prefetched job's ring geometry
-  int32_t pad0, pad1, pad2;
-};
-static_assert(sizeof(MDesc) == 96, "MDesc must stay 96 bytes");
-
-// ---- wave-specialised MFMA kernel (nam_a1_ws_kernel): one job per LAYER -------------------------------
+// ---- MFMA kernel (nam_a1_mfma_kernel, wave-specialised): one job per LAYER -------------------------------
 // The rechannel / head-rechannel steps ride on the neighbouring layer jobs (one extra weight tile + one
 // extra constant vector per job), so a block is exactly n_layers jobs (+1 idle job when that is odd: the
 // LDS double buffers alternate per job and must come back to parity 0 at the start of every block).
@@ -235,16 +160,11 @@ struct A1Plan
   int32_t n_arrays = 0;
   int32_t head_scale_off = 0; // blob offset
   int32_t n_rings = 0;
-  int32_t mfma_ok = 0; // nam_a1_mfma_kernel can run this model (channels % 4 == 0, K == 3)
-  int32_t n_mjobs = 0;
-  int32_t mconsts_off = 0; // blob offset of the consts table (n_mjobs * 48 floats)
-  int32_t pad = 0;
+  int32_t pad[4] = {0, 0, 0, 0};
   int32_t ring_len_by_id[64]; // R of ring r (for the per-block write-position update)
   A1Array arr[kA1MaxArrays];
-  MJob mjobs[kMJobMax];
-  MDesc mdesc[kMJobMax];
-  // wave-specialised kernel
-  int32_t ws_ok = 0;
+  // MFMA kernel
+  int32_t ws_ok = 0; // nam_a1_mfma_kernel can run this model (plan.cpp: build_a1_ws)
   int32_t ws_jobs = 0; // jobs per block (even)
   int32_t ws_tiles_off = 0, ws_consts_off = 0, ws_r1_off = 0; // blob offsets: tiles [jobs][1024], consts [jobs][64], 16 floats
   int32_t ws_xt_off = 0, ws_n_xt = 0; // blob offset / count of the extra tiles [n][256]

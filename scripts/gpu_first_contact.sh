@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer tool: first-contact check of a kernel variant under a hard timeout (a hung barrier must not eat the box)
 cd "$GRAFT_REPO_ROOT"
-K=${1:-a1_ws}
+K=${1:-a1_mfma}
 timeout 120 python - <<PY
 import numpy as np, sys, os
 sys.path.insert(0, ".")
@@ -9,7 +9,7 @@ import neuralampmodelercore_amd as nam
 from oracle import nam_oracle as orc
 from tests.signals import stream_bank
 orc.build()
-kern = {"a1_ws": nam.KERNEL_A1_WS, "a1_mfma": nam.KERNEL_A1_MFMA}["$K"]
+kern = {"a1_mfma": nam.KERNEL_A1_MFMA}["$K"]
 for name in ("wavenet_a1_standard", "wavenet", "slimmable_wavenet"):
     p = os.path.join("tests/golden/models", name + ".nam")
     m = nam.get_dsp(p, fast_tanh=True)

@@ -74,7 +74,7 @@ def test_block_partition_independence(nam_lib):
     nam = nam_lib
     x = stream_bank(3, 500, seed=5)
     model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
-    for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1, nam.KERNEL_A1_MFMA, nam.KERNEL_A1_WS):
+    for kernel in (nam.KERNEL_GENERIC, nam.KERNEL_A1, nam.KERNEL_A1_MFMA):
         b1 = model.batch(3, 512)
         b1.set_kernel(kernel)
         b1.Reset(prewarm=False)
@@ -101,7 +101,6 @@ def test_generic_and_a1_kernels_agree(nam_lib):
         assert model.info.has_a1_kernel & 1
         ys = []
         kernels = [nam.KERNEL_GENERIC, nam.KERNEL_A1] + ([nam.KERNEL_A1_MFMA] if model.info.has_a1_kernel & 2 else [])
-        kernels += [nam.KERNEL_A1_WS] if model.info.has_a1_kernel & 4 else []
         for kernel in kernels:
             b = model.batch(4, 64)
             b.set_kernel(kernel)
@@ -189,8 +188,6 @@ def test_hip_matches_committed_golden_vectors(nam_lib):
             kernels.append(nam.KERNEL_A1)
         if model.architecture == "WaveNet" and model.info.has_a1_kernel & 2:
             kernels.append(nam.KERNEL_A1_MFMA)
-        if model.architecture == "WaveNet" and model.info.has_a1_kernel & 4:
-            kernels.append(nam.KERNEL_A1_WS)
         for kernel in kernels:
             b = model.batch(3, 64)
             if model.architecture == "WaveNet":
@@ -204,7 +201,7 @@ def test_hip_matches_committed_golden_vectors(nam_lib):
             b.close()
 
 
-@pytest.mark.parametrize("kernel", ["generic", "a1", "a1_mfma", "a1_ws"])
+@pytest.mark.parametrize("kernel", ["generic", "a1", "a1_mfma"])
 def test_long_resident_render_wraps_every_ring(nam_lib, oracle, kernel):
     """One launch over 150 blocks: the d = 512 ring (1088 frames) wraps ~9 times; frames written by one
     wavefront are read back by others many blocks later (same-CU L1 coherence of global memory)."""
@@ -214,7 +211,7 @@ def test_long_resident_render_wraps_every_ring(nam_lib, oracle, kernel):
     x = stream_bank(n_streams, n, seed=21)
     model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
     b = model.batch(n_streams, 64)
-    b.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA, "a1_ws": nam.KERNEL_A1_WS}[kernel])
+    b.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[kernel])
     b.Reset(prewarm=True)
     xd = torch.from_numpy(x[:, None, :]).cuda()
     y = b.process_tensor(xd)

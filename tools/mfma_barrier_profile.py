@@ -1,4 +1,4 @@
-"""Developer tool: how long each wave of workgroup 0 of nam_a1_ws_kernel sits in barriers (shader cycles)."""
+"""Developer tool: how long each wave of workgroup 0 of nam_a1_mfma_kernel sits in barriers (shader cycles)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +8,7 @@ streams = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 nfr = int(sys.argv[2]) if len(sys.argv) > 2 else 64 * 50
 m = nam.get_dsp(os.path.join(ROOT, "tests/golden/models/wavenet_a1_standard.nam"), fast_tanh=True)
 b = m.batch(streams, 64)
-b.set_kernel(nam.KERNEL_A1_WS)
+b.set_kernel(nam.KERNEL_A1_MFMA)
 b.Reset(prewarm=True)
 t = b.debug_timeline(nfr)
 jobs = (nfr + 63) // 64 * 20
