@@ -47,6 +47,7 @@ struct A1Args
   int r1_off; // blob offset of the first array's rechannel column (16 floats)
   int xt_off, n_xt; // blob offset / count of the extra tiles
   int lds_tiles_b, lds_xt_b, lds_cond_b, lds_bytes; // dynamic LDS layout (bytes)
+  int prefetch; // the plan's ws_prefetch (mover prefetch depth the descriptors were built for)
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 

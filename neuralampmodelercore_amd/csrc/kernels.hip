@@ -867,7 +867,7 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
 //   waves 4-7 (movers) : per job drop the successor's prefetched history (3 x 16 B per lane) and the weight
 //                        tiles of the job after it (16 B per lane) into the LDS double buffers, append the
 //                        job's input rows (LDS window) to its HBM ring, and issue the loads of the job
-//                        kWsPrefetch + 1 ahead. At block boundaries they also materialise
+//                        D + 1 ahead (D = the plan's ws_prefetch). At block boundaries they also materialise
 //                        x0 = rechannel * input and the input samples in LDS.
 // Each SIMD hosts one compute and one mover wave, so the mover's address arithmetic / memory instructions
 // fill the issue slots the compute wave leaves between dependent MFMA / VALU instructions.
@@ -880,7 +880,6 @@ namespace ws
 {
 using mf::f4;
 constexpr int SC = kMfSC;
-constexpr int D = kWsPrefetch;
 struct HSlot
 {
   f4 h[2]; // the job's two history sets (plan.h, VDesc)
@@ -895,7 +894,7 @@ struct Ops // one job's register-resident operands (compute waves)
 };
 } // namespace ws
 
-template <int ACT_T, bool WT, bool PROF>
+template <int ACT_T, bool WT, bool PROF, int D>
 __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restrict__ P, const float* __restrict__ blob,
                                                         const A1Args a)
 {
@@ -915,7 +914,8 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
   const int NJ = a.n_mjobs;
   const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
   const int total = n_blocks * NJ;
-  const int total_pad = (total + kWsUnroll - 1) / kWsUnroll * kWsUnroll; // both roles: same number of barriers
+  constexpr int kUnroll = (D % 2 == 0) ? D : 2 * D; // both roles run a multiple of this many jobs (= barriers)
+  const int total_pad = (total + kUnroll - 1) / kUnroll * kUnroll;
   const unsigned lds_tiles_b = (unsigned)a.lds_tiles_b, lds_cond_b = (unsigned)a.lds_cond_b;
 
   // constants table and extra tiles -> LDS (all 512 threads; visible at the prologue barrier)
@@ -1119,7 +1119,6 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
   else
   {
     // ------------------------------------------------ mover role --------------------------------------
-    constexpr int D = ws::D;
     const int mtid = tid - 256;
     const int hfr = 16 * (w - 4) + (lane >> 2); // frame inside a 64-frame set
     const unsigned v_hq16 = (unsigned)(lane & 3) * 16u; // channel quad
@@ -1227,7 +1226,7 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
         }
         // successor's history and the tiles of the job after it -> LDS (the halves of the double buffers
         // nobody reads during this job), then refill the slot
-        drop(slot[un], J, blk + 1, u & 1);
+        drop(slot[un], J, blk + 1, (q0 + u) & 1);
         {
           const bool valid = fblk < n_blocks;
           fetch(slot[un], valid ? J.f_rbase : 0, valid ? J.f_R : 64, valid ? J.f_LA : 64, valid ? J.f_LB : 0,
@@ -1269,36 +1268,45 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
 
 namespace
 {
-template <int ACT_T, bool WT, bool PROF>
+template <int ACT_T, bool WT, bool PROF, int D>
 hipError_t launch_mfma_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 {
   static int lds_limit = 0; // per instantiation: dynamic LDS the runtime has been told about
   if (a.lds_bytes > lds_limit)
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_mfma_kernel<ACT_T, WT, PROF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_mfma_kernel<ACT_T, WT, PROF, D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess)
       return e;
     lds_limit = a.lds_bytes;
   }
-  hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, WT, PROF>), dim3(n_blocks), dim3(512), a.lds_bytes, stream, a.plan, a.blob, a);
+  hipLaunchKernelGGL((nam_a1_mfma_kernel<ACT_T, WT, PROF, D>), dim3(n_blocks), dim3(512), a.lds_bytes, stream, a.plan,
+                     a.blob, a);
   return hipGetLastError();
+}
+template <int ACT_T, bool WT, bool PROF>
+hipError_t launch_mfma_depth(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  return a.prefetch == 5 ? launch_mfma_inst<ACT_T, WT, PROF, 5>(a, n_blocks, stream)
+                         : launch_mfma_inst<ACT_T, WT, PROF, 6>(a, n_blocks, stream);
 }
 } // namespace
 
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
+  if (a.prefetch != 5 && a.prefetch != 6)
+    return hipErrorInvalidValue;
   if (a.dbg) // developer tool: barrier-wait profile of workgroup 0
-    return act == ACT_FASTTANH ? launch_mfma_inst<ACT_FASTTANH, false, true>(a, n_blocks, stream)
-                               : launch_mfma_inst<-1, false, true>(a, n_blocks, stream);
+    return act == ACT_FASTTANH ? launch_mfma_depth<ACT_FASTTANH, false, true>(a, n_blocks, stream)
+                               : launch_mfma_depth<-1, false, true>(a, n_blocks, stream);
   if (act == ACT_FASTTANH)
-    return wt ? launch_mfma_inst<ACT_FASTTANH, true, false>(a, n_blocks, stream)
-              : launch_mfma_inst<ACT_FASTTANH, false, false>(a, n_blocks, stream);
+    return wt ? launch_mfma_depth<ACT_FASTTANH, true, false>(a, n_blocks, stream)
+              : launch_mfma_depth<ACT_FASTTANH, false, false>(a, n_blocks, stream);
   if (act == ACT_TANH)
-    return wt ? launch_mfma_inst<ACT_TANH, true, false>(a, n_blocks, stream)
-              : launch_mfma_inst<ACT_TANH, false, false>(a, n_blocks, stream);
-  return wt ? launch_mfma_inst<-1, true, false>(a, n_blocks, stream) : launch_mfma_inst<-1, false, false>(a, n_blocks, stream);
+    return wt ? launch_mfma_depth<ACT_TANH, true, false>(a, n_blocks, stream)
+              : launch_mfma_depth<ACT_TANH, false, false>(a, n_blocks, stream);
+  return wt ? launch_mfma_depth<-1, true, false>(a, n_blocks, stream) : launch_mfma_depth<-1, false, false>(a, n_blocks, stream);
 }
 
 int lstm_lds_bytes(const LSTMArgs& a)

@@ -214,7 +214,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.n_rings = p.a1.n_rings;
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
       a.n_mjobs = a.tiles_off = a.consts_off = 0;
-      a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = 0;
+      a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = a.prefetch = 0;
       if (kernel == NAM_HIP_KERNEL_A1_MFMA)
       {
         // uniform activation across arrays -> compile-time specialised kernel, else run-time dispatch
@@ -232,6 +232,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
         a.lds_xt_b = p.a1.ws_lds_xt_b;
         a.lds_cond_b = p.a1.ws_lds_cond_b;
         a.lds_bytes = p.a1.ws_lds_bytes;
+        a.prefetch = p.a1.ws_prefetch;
         NAM_HIP_CHECK(launch_a1_mfma(a, n, act, s));
       }
       else

@@ -401,8 +401,10 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   }
   const int NJ = (n_layers + 1) / 2 * 2;
   const int n_xt = 2 * n_arrays - 1;
-  if (NJ > kWsJobMax || NJ < kWsPrefetch + 3 || n_xt > kWsXtMax)
+  const int PF = (NJ % 5 == 0) ? 5 : 6; // mover prefetch depth (plan.h)
+  if (NJ > kWsJobMax || NJ < PF + 3 || n_xt > kWsXtMax)
     return;
+  a1.ws_prefetch = PF;
   while (plan.blob.size() % 64)
     plan.blob.push_back(0.0f);
   a1.ws_tiles_off = (int)plan.blob.size();
@@ -590,7 +592,7 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
     VDesc& V = a1.vdesc[j];
     const int nbuf = (j + 1) & 1;
     const JobGeo& N = geo[(j + 1) % NJ]; // successor: its history is dropped during job j
-    const JobGeo& F = geo[(j + 1 + kWsPrefetch) % NJ];
+    const JobGeo& F = geo[(j + 1 + PF) % NJ];
     // which sets a job needs (plan.h, VDesc)
     auto sets = [&](const JobGeo& G, int& LA, int& LB, int& dst_a, int& dst_b, int buf) {
       LA = kBlock, LB = 0, dst_a = xw(buf), dst_b = tb(buf, 0);

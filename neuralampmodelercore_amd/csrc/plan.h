@@ -102,8 +102,10 @@ constexpr int kMfTbOff = kMfXwOff + 2 * kMfXwFloats; // tap buffers [2 buffers][
 // extra constant vector per job), so a block is exactly n_layers jobs (+1 idle job when that is odd: the
 // LDS double buffers alternate per job and must come back to parity 0 at the start of every block).
 // Compute waves (0-3) and mover waves (4-7) execute from separate descriptors.
-constexpr int kWsPrefetch = 6; // mover: jobs of history loads in flight
-constexpr int kWsUnroll = 6; // both loops run a multiple of this many jobs (same number of barriers)
+// Mover prefetch depth D (jobs of history loads in flight = the mover loop's unroll factor) is chosen per model
+// so that it divides the jobs per block: then a launch is an exact number of unrolled bodies and no idle jobs
+// pad its tail (one 64-frame launch of a 20-job model would otherwise run 24). Instantiated: 5 and 6.
+constexpr int kWsPrefetchMax = 6;
 constexpr int kWsJobMax = 32; // jobs (layers) per block
 constexpr int kWsXtMax = 4; // extra tiles (rechannel / head rechannel matrices) per model
 constexpr int kWsTileFloats = 4 * 256; // per job: [conv tap 0,1,2 | layer1x1][lane][4 k-steps]
@@ -146,7 +148,7 @@ struct VDesc // 16 x int32, one s_load_dwordx16
 {
   int32_t flags;
   int32_t st_a_b, st_b_b, st_x0_b; // LDS byte offsets where the SUCCESSOR's sets / x0 rows are dropped
-  int32_t f_rbase, f_R, f_LA, f_LB, f_ring_id, f_q16max; // ring geometry of the job prefetched now (kWsPrefetch + 1
+  int32_t f_rbase, f_R, f_LA, f_LB, f_ring_id, f_q16max; // ring geometry of the job prefetched now (ws_prefetch + 1
                                                          // ahead); f_LB == 0: no second set (the load is redirected)
   int32_t ap_src_b; // LDS byte offset of frame 0 of this job's input rows (current half of its window)
   int32_t ring_b, R, ring_id, q16max; // this job's ring
@@ -169,7 +171,7 @@ struct A1Plan
   int32_t ws_tiles_off = 0, ws_consts_off = 0, ws_r1_off = 0; // blob offsets: tiles [jobs][1024], consts [jobs][64], 16 floats
   int32_t ws_xt_off = 0, ws_n_xt = 0; // blob offset / count of the extra tiles [n][256]
   int32_t ws_lds_tiles_b = 0, ws_lds_xt_b = 0, ws_lds_cond_b = 0, ws_lds_bytes = 0; // LDS layout (bytes)
-  int32_t ws_pad = 0;
+  int32_t ws_prefetch = 6; // D
   CDesc cdesc[kWsJobMax];
   VDesc vdesc[kWsJobMax];
 };
