@@ -107,7 +107,7 @@ constexpr int kMfTbOff = kMfXwOff + 2 * kMfXwFloats; // tap buffers [2 buffers][
 // pad its tail (one 64-frame launch of a 20-job model would otherwise run 24). Instantiated: 5 and 6.
 constexpr int kWsPrefetchMax = 6;
 constexpr int kWsJobMax = 32; // jobs (layers) per block
-constexpr int kWsXtMax = 4; // extra tiles (rechannel / head rechannel matrices) per model
+constexpr int kWsXtMax = 8; // extra tiles (rechannel / head rechannel matrices) per model
 constexpr int kWsTileFloats = 4 * 256; // per job: [conv tap 0,1,2 | layer1x1][lane][4 k-steps]
 // LDS (floats): window [2][128][SC] | taps [2][2][64][SC] | consts [jobs][64] | tiles [2][1024] |
 //               extra tiles [n][256] | input samples [2][64]        (dynamic: sized per model, see ws_lds_*)

@@ -20,7 +20,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nam_oracle  # noqa: E402
 from signals import two_tone  # noqa: E402
 
-MODELS = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable_wavenet", "wavenet_condition_dsp"]
+MODELS = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable_wavenet", "wavenet_condition_dsp",
+          "synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed"]  # synth_*: make_synthetic_models.py
 
 
 def main():

@@ -1,0 +1,67 @@
+"""Writes small synthetic A1-family WaveNet fixtures (seeded random weights) that exercise the MFMA kernel's
+variants the shipped example models do not reach: odd layer counts (idle job + padded launch), prefetch depth
+5 / 6, 12- and 4-channel arrays (full lane layout, partial quads), two 8-channel arrays (half layout end to
+end), mixed activations (run-time activation dispatch), head bias on / off.
+
+    python tests/golden/make_synthetic_models.py      # then tests/golden/make_golden.py
+
+Weight stream order per layer array (NAM/wavenet/model.cpp:152-181,563-569): rechannel [C][in] (no bias);
+per layer conv [C][C][K], conv bias [C], input mixin [C][cond], layer1x1 [C][C], its bias [C];
+head rechannel [H][C] (+ bias [H] when head_bias); finally head_scale.
+"""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SPECS = {
+    # 7 + 6 = 13 layers -> 14 jobs with an idle one; depth 6; 14 % 6 != 0 -> padded tail
+    "synth_a1_13": dict(arrays=[(16, [1, 2, 4, 8, 16, 32, 64], "Tanh", False), (8, [1, 2, 4, 8, 16, 32], "Tanh", True)], seed=11),
+    # 12 and 4 channels (full layout, partial quads), dilations beyond one block, ReLU; 12 jobs, depth 6
+    "synth_a1_c12": dict(arrays=[(12, [128, 256, 512, 1, 2, 4], "ReLU", True), (4, [8, 16, 32, 64, 3, 5], "ReLU", True)], seed=12),
+    # two 8-channel arrays: half layout through X0, PRE_HEAD (previous half) and POST_RECH; 10 jobs, depth 5
+    "synth_a1_c8": dict(arrays=[(8, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 256, 512], "Tanh", True)], seed=13),
+    # mixed activations -> run-time dispatch; three arrays (16 -> 8 -> 4); 15 layers -> 16 jobs
+    "synth_a1_mixed": dict(arrays=[(16, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 1, 2], "ReLU", True),
+                                   (4, [4, 8, 16, 32, 64], "Sigmoid", True)], seed=14),
+}
+
+
+def build(name, arrays, seed):
+    rng = np.random.default_rng(seed)
+    layers, weights = [], []
+    n = len(arrays)
+    for i, (C, dil, act, hb) in enumerate(arrays):
+        in_size = 1 if i == 0 else arrays[i - 1][0]
+        head = 1 if i == n - 1 else arrays[i + 1][0]
+        K = 3
+        layers.append(dict(input_size=in_size, condition_size=1, head_size=head, channels=C, kernel_size=K, dilations=dil,
+                           activation=act, gated=False, head_bias=hb))
+
+        def w(shape, fan_in):
+            v = rng.standard_normal(shape).astype(np.float32) * np.float32(0.9 / np.sqrt(fan_in))
+            weights.extend(v.reshape(-1).tolist())
+
+        w((C, in_size), in_size)
+        for _ in dil:
+            w((C, C, K), C * K)
+            w((C,), 4.0)
+            w((C, 1), 1.0)
+            w((C, C), C)
+            w((C,), 4.0)
+        w((head, C), C * len(dil))
+        if hb:
+            w((head,), 4.0)
+    weights.append(0.05)
+    model = dict(version="0.5.4", architecture="WaveNet", config=dict(layers=layers, head=None, head_scale=0.05),
+                 metadata=dict(name=name, note="synthetic test fixture (seeded random weights)"), weights=weights, sample_rate=48000)
+    with open(os.path.join(HERE, "models", name + ".nam"), "w") as f:
+        json.dump(model, f)
+    return len(weights)
+
+
+if __name__ == "__main__":
+    for name, spec in SPECS.items():
+        print(name, build(name, **spec), "weights")

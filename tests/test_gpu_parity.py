@@ -11,6 +11,8 @@ from signals import stream_bank, two_tone
 pytestmark = pytest.mark.gpu
 
 WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet"]
+# synthetic A1-family fixtures (tests/golden/make_synthetic_models.py) that reach the MFMA kernel's variants
+SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed"]
 
 
 def _oracle_run(oracle, name, x, block, fast_tanh, ratio=None):
@@ -49,6 +51,30 @@ def test_wavenet_matches_oracle(nam_lib, oracle, name, fast_tanh, kernel):
         err = float(np.max(np.abs(r - y[s])))
         assert err <= _tol(fast_tanh) * scale, (name, s, err, scale)
     batch.close()
+
+
+@pytest.mark.parametrize("name", SYNTH_A1)
+@pytest.mark.parametrize("fast_tanh", [True, False])
+def test_mfma_kernel_variants_match_oracle(nam_lib, oracle, name, fast_tanh):
+    """Idle job + padded launch (13 layers), prefetch depth 5 and 6, 12- / 4-channel full layout, half layout
+    end to end, run-time activation dispatch — block launches, a ragged tail and one multi-block launch."""
+    nam = nam_lib
+    n_streams, block, n = 3, 64, 64 * 5 + 17
+    x = stream_bank(n_streams, n, seed=31)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    assert model.info.has_a1_kernel & 2, "fixture must be MFMA-eligible"
+    for mode, max_frames in (("blocks", block), ("one_launch", 512)):
+        refs = [_oracle_run(oracle, name, x[s], max_frames, fast_tanh) for s in range(n_streams)]
+        batch = model.batch(n_streams, max_frames)
+        batch.set_kernel(nam.KERNEL_A1_MFMA)
+        assert batch.get_kernel() == nam.KERNEL_A1_MFMA
+        batch.Reset(prewarm=True)
+        y = batch.process_stream(x, max_frames)
+        for s in range(n_streams):
+            scale = max(1.0, float(np.max(np.abs(refs[s]))))
+            err = float(np.max(np.abs(refs[s] - y[s])))
+            assert err <= _tol(fast_tanh) * scale, (name, mode, s, err, scale)
+        batch.close()
 
 
 def test_lstm_matches_oracle(nam_lib, oracle):
