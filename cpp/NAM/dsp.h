@@ -244,6 +244,12 @@ public:
   {
     detail::check(nam_hip_batch_set_slimmable_size(mBatch.get(), stream_ids, n, ratio));
   }
+  bool IsSlimmable() const { return mInfo.is_slimmable != 0; }
+  // Offline re-amp of one whole signal per stream (lengths may differ); planar float32 host buffers.
+  void render(const float* const* in, float* const* out, const int64_t* n_frames)
+  {
+    detail::check(nam_hip_batch_render_f32(mBatch.get(), in, out, n_frames));
+  }
 
 protected:
   int NumStreams() const override { return mStreams; }

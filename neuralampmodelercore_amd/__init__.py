@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "nam_hip_last_error", "nam_hip_version", "nam_hip_model_load", "nam_hip_model_load_json", "nam_hip_model_free",
     "nam_hip_model_get_info", "nam_hip_model_slimmable_breakpoints", "nam_hip_batch_create", "nam_hip_batch_destroy",
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
-    "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_synchronize",
+    "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_render_f32", "nam_hip_batch_synchronize",
     "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams",
     "nam_hip_batch_debug_timeline",
 ]
@@ -120,6 +120,7 @@ def load_library():
     L.nam_hip_batch_process_f32.argtypes = [vp, vp, vp, ci]
     L.nam_hip_batch_process_f64.argtypes = [vp, vp, vp, ci]
     L.nam_hip_batch_process_device.argtypes = [vp, vp, vp, ci, ctypes.c_int64, vp]
+    L.nam_hip_batch_render_f32.argtypes = [vp, vp, vp, vp]
     L.nam_hip_batch_synchronize.argtypes = [vp]
     L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
     L.nam_hip_batch_get_kernel.argtypes = [vp]
@@ -289,6 +290,19 @@ class Batch:
             x = x[:, None, :]
         outs = [self.process(x[:, :, s:s + block]) for s in range(0, x.shape[2], block)]
         return np.concatenate(outs, axis=2)
+
+    def render(self, signals) -> list:
+        """Offline re-amp of one whole (mono or [in_channels, n]) float32 signal per stream; lengths may differ.
+        Returns a list of [out_channels, n_s] arrays (tools/render.cpp's block loop as one resident launch)."""
+        ic, oc = self.model.NumInputChannels(), self.model.NumOutputChannels()
+        if len(signals) != self.n_streams:
+            raise ValueError(f"expected {self.n_streams} signals, got {len(signals)}")
+        ins = [np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(ic, -1)) for x in signals]
+        outs = [np.empty((oc, x.shape[1]), dtype=np.float32) for x in ins]
+        P = ctypes.c_void_p * self.n_streams
+        n = (ctypes.c_int64 * self.n_streams)(*[x.shape[1] for x in ins])
+        _check(self._L.nam_hip_batch_render_f32(self._h, P(*[x.ctypes.data for x in ins]), P(*[y.ctypes.data for y in outs]), n))
+        return outs
 
     def process_device(self, d_in: int, d_out: int, n_frames: int, frame_stride: Optional[int] = None,
                        stream: int = 0):

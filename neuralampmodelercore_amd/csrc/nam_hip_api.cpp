@@ -636,6 +636,53 @@ int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out,
   return NAM_HIP_OK;
 }
 
+int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float* const* out, const int64_t* n_frames)
+{
+  if (!batch || !in || !out || !n_frames)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_render_f32: bad argument");
+  const int N = batch->n_streams;
+  const int ic = batch->model->spec->in_channels(), oc = batch->model->spec->out_channels();
+  int64_t T = 0;
+  for (int s = 0; s < N; s++)
+  {
+    if (n_frames[s] < 0 || (n_frames[s] > 0 && (!in[s] || !out[s])))
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_render_f32: bad signal pointer / length");
+    T = std::max(T, n_frames[s]);
+  }
+  if (T == 0)
+    return NAM_HIP_OK;
+  if (T > (int64_t)1 << 30)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_render_f32: signal too long for one launch");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  // device-resident planar audio [stream][channel][T]; rows of shorter signals are zero-padded
+  float *d_in = nullptr, *d_out = nullptr;
+  const size_t in_bytes = (size_t)N * ic * T * sizeof(float), out_bytes = (size_t)N * oc * T * sizeof(float);
+  NAM_HIP_CHECK(hipMalloc(&d_in, in_bytes));
+  hipError_t e = hipMalloc(&d_out, out_bytes);
+  int rc = NAM_HIP_OK;
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_in, 0, in_bytes, batch->stream);
+  for (int s = 0; s < N && e == hipSuccess; s++)
+    if (n_frames[s] > 0)
+      e = hipMemcpy2DAsync(d_in + (size_t)s * ic * T, (size_t)T * sizeof(float), in[s], (size_t)n_frames[s] * sizeof(float),
+                           (size_t)n_frames[s] * sizeof(float), ic, hipMemcpyHostToDevice, batch->stream);
+  if (e == hipSuccess)
+    rc = nam_hip_batch_process_device(batch, d_in, d_out, (int)T, T, nullptr);
+  for (int s = 0; s < N && e == hipSuccess && rc == NAM_HIP_OK; s++)
+    if (n_frames[s] > 0)
+      e = hipMemcpy2DAsync(out[s], (size_t)n_frames[s] * sizeof(float), d_out + (size_t)s * oc * T, (size_t)T * sizeof(float),
+                           (size_t)n_frames[s] * sizeof(float), oc, hipMemcpyDeviceToHost, batch->stream);
+  const hipError_t es = hipStreamSynchronize(batch->stream);
+  (void)hipFree(d_in);
+  if (d_out)
+    (void)hipFree(d_out);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  NAM_HIP_CHECK(e);
+  NAM_HIP_CHECK(es);
+  return NAM_HIP_OK;
+}
+
 int nam_hip_batch_process_f64(nam_hip_batch* batch, const double* in, double* out, int n_frames)
 {
   if (!batch || !in || !out || n_frames < 0)

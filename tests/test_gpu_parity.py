@@ -272,3 +272,93 @@ def test_cpp_adapter_benchmodel_runs(nam_lib):
         assert "ms" in out.stdout
     bad = subprocess.run([exe, "/nonexistent.nam"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "does not exist" in bad.stderr
+
+
+def _read_f32_wav(path):
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[36:40] == b"data"
+    fmt, ch, sr = struct.unpack("<HHI", b[20:28])
+    assert (fmt, ch) == (3, 1)
+    return np.frombuffer(b[44:], dtype="<f4"), sr
+
+
+def test_render_ragged_batch_matches_oracle(nam_lib, oracle):
+    """nam_hip_batch_render_f32: whole signals of different lengths in one resident launch == the 64-frame
+    block loop of tools/render.cpp:163-197 run per stream."""
+    nam = nam_lib
+    lens = [64 * 9 + 5, 64 * 3, 1, 700]
+    x = stream_bank(len(lens), max(lens), seed=41)
+    for name, ft in (("wavenet_a1_standard", True), ("wavenet_condition_dsp", False), ("lstm", True)):
+        model = nam.get_dsp(model_path(name), fast_tanh=ft)
+        b = model.batch(len(lens), 64)
+        b.Reset(prewarm=True)
+        ys = b.render([x[s, :n] for s, n in enumerate(lens)])
+        for s, n in enumerate(lens):
+            r = _oracle_run(oracle, name, x[s, :n], 64, ft)
+            assert ys[s].shape == r.shape == (model.NumOutputChannels(), n)
+            assert float(np.max(np.abs(r - ys[s]))) <= _tol(ft) * max(1.0, float(np.max(np.abs(r)))), (name, s)
+        b.close()
+
+
+def test_cpp_render_tool(nam_lib, oracle, tmp_path):
+    """cpp/tools/render: the reference's command line (tools/render.cpp:97-110) and the batch form, on the
+    reference's example audio; output = mono float32 WAV of channel 0."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cpp")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "cpp", "tools", "render")
+    wav = os.path.join(ROOT, "tests", "golden", "audio", "input.wav")
+    x, sr = _read_f32_wav_any(wav)
+    out1 = str(tmp_path / "out.wav")
+    r = subprocess.run([exe, model_path("wavenet_a1_standard"), wav, out1], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    y, sr_out = _read_f32_wav(out1)
+    assert sr_out == 48000 and len(y) == len(x)
+    ref = _oracle_run(oracle, "wavenet_a1_standard", x, 64, False)[0]  # the tool leaves fast tanh off, like the reference's render
+    assert float(np.max(np.abs(ref - y))) <= 1e-4
+    # batch form: three files of different lengths through the slimmable model at a reduced width
+    files = []
+    for i, n in enumerate((96000, 12345, 64)):
+        p = str(tmp_path / f"in{i}.wav")
+        _write_f32_wav(p, x[:n], 48000)
+        files.append(p)
+    outdir = str(tmp_path / "rendered")
+    r = subprocess.run([exe, "--slim", "0.34", model_path("slimmable_wavenet"), "--batch", outdir] + files, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i, n in enumerate((96000, 12345, 64)):
+        y, _ = _read_f32_wav(os.path.join(outdir, f"in{i}.wav"))
+        ref = _oracle_run(oracle, "slimmable_wavenet", x[:n], 64, False, ratio=0.34)[0]
+        assert len(y) == n and float(np.max(np.abs(ref - y))) <= 1e-4
+    # error paths of the reference tool
+    bad = subprocess.run([exe, model_path("wavenet"), wav, out1, "extra"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Usage" in bad.stderr
+    bad = subprocess.run([exe, "--slim", "0.5", model_path("wavenet"), wav, out1], capture_output=True, text=True)
+    assert bad.returncode == 1 and "SlimmableModel" in bad.stderr
+    p44 = str(tmp_path / "sr44.wav")
+    _write_f32_wav(p44, x[:100], 44100)
+    bad = subprocess.run([exe, model_path("lstm"), p44, out1], capture_output=True, text=True)
+    assert bad.returncode == 1 and "does not match model expected rate" in bad.stderr
+
+
+def _write_f32_wav(path, x, sr):
+    import struct
+    data = np.asarray(x, dtype="<f4").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, sr, sr * 4, 4, 32)
+    open(path, "wb").write(hdr + b"data" + struct.pack("<I", len(data)) + data)
+
+
+def _read_f32_wav_any(path):
+    """the 24-bit PCM example file, decoded independently of the C++ reader"""
+    import struct
+    b = open(path, "rb").read()
+    fmt, ch, sr, _, _, bits = struct.unpack("<HHIIHH", b[20:36])
+    assert (fmt, ch, bits) == (1, 1, 24)
+    i = b.index(b"data")
+    n = struct.unpack("<I", b[i + 4:i + 8])[0]
+    raw = np.frombuffer(b[i + 8:i + 8 + n], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+    v = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
+    v = np.where(v >= 1 << 23, v - (1 << 24), v)
+    return (v / 8388608.0).astype(np.float32), sr
