@@ -47,6 +47,7 @@ extern "C" {
 
 #define NAM_HIP_ARCH_WAVENET 1
 #define NAM_HIP_ARCH_LSTM 2
+#define NAM_HIP_ARCH_CONTAINER 3 /* SlimmableContainer: submodels selected by nam_hip_batch_set_slimmable_size */
 
 /* kernel selection for nam_hip_batch_set_kernel */
 #define NAM_HIP_KERNEL_AUTO 0

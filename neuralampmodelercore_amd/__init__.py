@@ -189,7 +189,7 @@ class Model:
 
     @property
     def architecture(self) -> str:
-        return {1: "WaveNet", 2: "LSTM"}.get(self.info.architecture, "?")
+        return {1: "WaveNet", 2: "LSTM", 3: "SlimmableContainer"}.get(self.info.architecture, "?")
 
     @property
     def is_slimmable(self) -> bool:

@@ -56,6 +56,7 @@ struct LSTMArgs
   const float* blob;
   float* state;
   long state_stride;
+  const int* stream_map; // optional: launch position -> stream index; nullptr = identity
   const float* in;
   float* out;
   long io_stride;

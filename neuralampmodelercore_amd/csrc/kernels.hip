@@ -721,8 +721,10 @@ __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ 
   // LDS carve-up (floats): io tile [64 streams][65] | xh [(I+H) max][64] per layer | c [H][64] per layer | ifgo [4H][64]
   const int lane = threadIdx.x;
   const int s0 = blockIdx.x * kBlock;
-  const int stream = s0 + lane;
-  const bool live = stream < a.n_streams;
+  // position s0 + lane of this launch; the stream it stands for comes from the optional map (a batch whose
+  // streams run different submodels launches each group over its member list)
+  const bool live = s0 + lane < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + lane] : s0 + lane) : 0;
   const int H = a.hidden, NL = a.n_layers, I0 = a.input_size;
   const int in_ch = a.in_ch, out_ch = a.out_ch;
   float* tile_in = lds; // [in_ch][64][65]
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ 
   float* ifgo = cs + NL * H * kBlock; // [4H][64]
 
   // load recurrent state
-  float* st = a.state + (size_t)(live ? stream : 0) * a.state_stride;
+  float* st = a.state + (size_t)stream * a.state_stride;
   for (int l = 0; l < NL; l++)
     for (int i = 0; i < H; i++)
     {
@@ -748,9 +750,9 @@ __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ 
     for (int c = 0; c < in_ch; c++)
       for (int r = 0; r < kBlock; r++)
       {
-        const int s = s0 + r;
+        const int s = __shfl(stream, r); // the stream of position s0 + r
         float v = 0.0f;
-        if (a.in && s < a.n_streams && lane < nvalid)
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
           v = a.in[((size_t)s * in_ch + c) * a.io_stride + f0 + lane];
         tile_in[(c * kBlock + r) * 65 + lane] = v;
       }
@@ -809,8 +811,8 @@ __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ 
       for (int c = 0; c < out_ch; c++)
         for (int r = 0; r < kBlock; r++)
         {
-          const int s = s0 + r;
-          if (s < a.n_streams && lane < nvalid)
+          const int s = __shfl(stream, r);
+          if (s0 + r < a.n_streams && lane < nvalid)
             a.out[((size_t)s * out_ch + c) * a.io_stride + f0 + lane] = tile_out[(c * kBlock + r) * 65 + lane];
         }
   }

@@ -148,7 +148,8 @@ struct LSTMSpec
 enum Arch : int
 {
   ARCH_WAVENET = 1,
-  ARCH_LSTM = 2
+  ARCH_LSTM = 2,
+  ARCH_CONTAINER = 3 // SlimmableContainer (NAM/container.cpp): submodels of different sizes, one active at a time
 };
 
 struct ModelSpec
@@ -161,10 +162,16 @@ struct ModelSpec
   bool fast_tanh = false; // resolved at load time (the reference uses a process-global, activations.cpp:168)
   WaveNetSpec wavenet;
   LSTMSpec lstm;
+  // ARCH_CONTAINER: submodels sorted by ascending max_value; SetSlimmableSize(v) activates the first one with
+  // v < max_value, else the last (container.cpp:103-115). The container itself is always 1-in / 1-out
+  // (container.cpp:19) and has no weights of its own.
+  std::vector<double> sub_max_value;
+  std::vector<std::shared_ptr<ModelSpec>> submodels;
 
-  int in_channels() const { return arch == ARCH_WAVENET ? wavenet.in_channels : lstm.in_channels; }
-  int out_channels() const { return arch == ARCH_WAVENET ? wavenet.out_channels() : lstm.out_channels; }
+  int in_channels() const { return arch == ARCH_WAVENET ? wavenet.in_channels : arch == ARCH_LSTM ? lstm.in_channels : 1; }
+  int out_channels() const { return arch == ARCH_WAVENET ? wavenet.out_channels() : arch == ARCH_LSTM ? lstm.out_channels : 1; }
   int prewarm_samples() const;
+  int container_index(double val) const; // container.cpp:103-115
 };
 
 // ---- loader entry points (nam_loader.cpp) ----

@@ -69,8 +69,11 @@ struct nam_hip_model
   std::vector<Plan> plans;
   int full_width = 0; // index of the full-size plan
 
+  bool slimmable() const { return spec->arch == ARCH_CONTAINER || (spec->arch == ARCH_WAVENET && spec->wavenet.slimmable); }
   int width_for_ratio(double ratio) const
   {
+    if (spec->arch == ARCH_CONTAINER)
+      return spec->container_index(ratio); // plan i = submodel i
     if (!spec->wavenet.slimmable || spec->arch != ARCH_WAVENET)
       return 0;
     const std::vector<int> ch = channels_for_ratio(spec->wavenet, ratio);
@@ -152,6 +155,9 @@ int ensure_state(nam_hip_batch* b, WidthGroup& g)
   const size_t bytes = (size_t)b->n_streams * g.state_stride * sizeof(float);
   NAM_HIP_CHECK(hipMalloc(&g.d_state, bytes));
   NAM_HIP_CHECK(hipMemsetAsync(g.d_state, 0, bytes, b->stream));
+  if (g.plan->arch == ARCH_LSTM) // h0 / c0 from the weight stream, once per (sub)model instance (lstm.cpp:24-28)
+    NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, nullptr, b->n_streams, g.d_init,
+                                    (int)g.plan->lstm.init_state.size(), g.plan->state_floats, b->stream));
   return NAM_HIP_OK;
 }
 
@@ -257,13 +263,12 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
   }
   else
   {
-    if (d_map)
-      return fail(NAM_HIP_ERR_UNSUPPORTED, "LSTM batches do not support stream subsets");
     const LSTMPlan& L = p.lstm;
     LSTMArgs a;
     a.blob = g.d_blob;
     a.state = g.d_state;
     a.state_stride = g.state_stride;
+    a.stream_map = d_map;
     a.in = d_in;
     a.out = d_out;
     a.io_stride = io_stride;
@@ -360,6 +365,17 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
     }
     m->full_width = m->width_for_ratio(1.0);
   }
+  else if (m->spec->arch == ARCH_CONTAINER)
+  {
+    // one plan per submodel (a slimmable submodel stays at its full size: ContainerModel never forwards
+    // SetSlimmableSize to its children); a fresh container has the last submodel active (container.cpp:49)
+    for (const auto& sm : m->spec->submodels)
+    {
+      m->plans.push_back(build_plan(*sm));
+      m->width_channels.push_back({});
+    }
+    m->full_width = (int)m->plans.size() - 1;
+  }
   else
   {
     m->plans.push_back(build_plan(*m->spec));
@@ -412,7 +428,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
   std::memset(info, 0, sizeof(*info));
   const ModelSpec& s = *model->spec;
   const Plan& p = model->plans[model->full_width];
-  info->architecture = s.arch == ARCH_WAVENET ? NAM_HIP_ARCH_WAVENET : NAM_HIP_ARCH_LSTM;
+  info->architecture = s.arch == ARCH_WAVENET ? NAM_HIP_ARCH_WAVENET : s.arch == ARCH_LSTM ? NAM_HIP_ARCH_LSTM : NAM_HIP_ARCH_CONTAINER;
   info->in_channels = s.in_channels();
   info->out_channels = s.out_channels();
   info->prewarm_samples = p.prewarm_samples;
@@ -420,11 +436,13 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
   info->has_loudness = s.has_loudness;
   info->has_input_level = s.has_input_level;
   info->has_output_level = s.has_output_level;
-  info->is_slimmable = (s.arch == ARCH_WAVENET && s.wavenet.slimmable) ? 1 : 0;
+  info->is_slimmable = model->slimmable() ? 1 : 0;
   info->loudness = s.loudness;
   info->input_level = s.input_level;
   info->output_level = s.output_level;
-  info->num_weights = s.arch == ARCH_WAVENET ? (int64_t)s.wavenet.weights.size() : (int64_t)s.lstm.weights.size();
+  info->num_weights = s.arch == ARCH_WAVENET ? (int64_t)s.wavenet.weights.size()
+                      : s.arch == ARCH_LSTM  ? (int64_t)s.lstm.weights.size()
+                                             : 0; // a container has no weights of its own
   info->fast_tanh = s.fast_tanh ? 1 : 0;
   info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && p.a1.ws_ok) ? 2 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
@@ -436,9 +454,13 @@ int nam_hip_model_slimmable_breakpoints(const nam_hip_model* model, double* out,
 {
   if (!model)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_slimmable_breakpoints: null model");
-  if (model->spec->arch != ARCH_WAVENET || !model->spec->wavenet.slimmable)
+  if (!model->slimmable())
     return 0;
-  const std::vector<double> bp = slimmable_breakpoints(model->spec->wavenet);
+  std::vector<double> bp;
+  if (model->spec->arch == ARCH_CONTAINER) // every max_value but the last (container.cpp:127-136)
+    bp.assign(model->spec->sub_max_value.begin(), model->spec->sub_max_value.end() - 1);
+  else
+    bp = slimmable_breakpoints(model->spec->wavenet);
   for (int i = 0; i < (int)bp.size() && i < capacity && out; i++)
     out[i] = bp[i];
   return (int)bp.size();
@@ -477,9 +499,6 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   int rc = ensure_state(b.get(), g);
   if (rc != NAM_HIP_OK)
     return rc;
-  if (g.plan->arch == ARCH_LSTM)
-    NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, nullptr, n_streams, g.d_init,
-                                    (int)g.plan->lstm.init_state.size(), g.plan->state_floats, b->stream));
   const size_t in_floats = (size_t)n_streams * model->spec->in_channels() * max_frames;
   const size_t out_floats = (size_t)n_streams * model->spec->out_channels() * max_frames;
   NAM_HIP_CHECK(hipMalloc(&b->d_in, in_floats * sizeof(float)));
@@ -535,7 +554,7 @@ int nam_hip_batch_set_slimmable_size(nam_hip_batch* batch, const int* stream_ids
   if (!batch)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_slimmable_size: null batch");
   const nam_hip_model* m = batch->model;
-  if (m->spec->arch != ARCH_WAVENET || !m->spec->wavenet.slimmable)
+  if (!m->slimmable())
     return NAM_HIP_OK; // not a SlimmableModel: the reference's dynamic_cast fails and callers skip
   NAM_HIP_CHECK(hipSetDevice(batch->device));
   const int w = m->width_for_ratio(ratio);

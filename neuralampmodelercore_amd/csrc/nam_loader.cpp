@@ -445,10 +445,20 @@ long WaveNetSpec::expected_weight_count() const
   return n + 1; // head_scale
 }
 
+int ModelSpec::container_index(double val) const
+{
+  for (size_t i = 0; i < sub_max_value.size(); i++)
+    if (val < sub_max_value[i])
+      return (int)i;
+  return (int)sub_max_value.size() - 1;
+}
+
 int ModelSpec::prewarm_samples() const
 {
   if (arch == ARCH_WAVENET)
     return wavenet.prewarm_samples();
+  if (arch == ARCH_CONTAINER) // of the active submodel; a fresh container has the last one active (container.cpp:49,139-144)
+    return submodels.back()->prewarm_samples();
   // LSTM::GetPrewarmSamples lstm.cpp:127-134
   const int r = (int)(0.5 * sample_rate);
   return r <= 0 ? 1 : r;
@@ -706,6 +716,35 @@ static std::shared_ptr<ModelSpec> build_model(const Value& root, bool fast_tanh)
     if (c.expected_weight_count() != (long)c.weights.size())
       throw std::runtime_error("LSTM weight mismatch: model expects " + std::to_string(c.expected_weight_count())
                                + " weights, but " + std::to_string(c.weights.size()) + " were provided.");
+  }
+  else if (arch == "SlimmableContainer")
+  {
+    // ContainerConfig::create + ContainerModel ctor (container.cpp:17-50,150-171)
+    m->arch = ARCH_CONTAINER;
+    const Value* subs = config.find("submodels");
+    if (!subs || !subs->is_array() || subs->arr.empty())
+      throw std::runtime_error("SlimmableContainer: 'submodels' must be a non-empty array");
+    for (const Value& entry : subs->arr)
+    {
+      m->sub_max_value.push_back(entry.at("max_value").as_double());
+      m->submodels.push_back(build_model(entry.at("model"), fast_tanh)); // each one is a full .nam document
+    }
+    for (size_t i = 1; i < m->sub_max_value.size(); i++)
+      if (m->sub_max_value[i] <= m->sub_max_value[i - 1])
+        throw std::runtime_error("ContainerModel: submodels must be sorted by ascending max_value");
+    if (m->sub_max_value.back() < 1.0)
+      throw std::runtime_error("ContainerModel: last submodel max_value must be >= 1.0");
+    for (const auto& sm : m->submodels)
+    {
+      if (sm->sample_rate != m->sample_rate && sm->sample_rate != -1.0 && m->sample_rate != -1.0)
+      {
+        std::stringstream ss;
+        ss << "ContainerModel: submodel sample rate mismatch (expected " << m->sample_rate << ", got " << sm->sample_rate << ")";
+        throw std::runtime_error(ss.str());
+      }
+      if (sm->in_channels() != 1 || sm->out_channels() != 1)
+        throw std::runtime_error("SlimmableContainer: the device path needs mono submodels (the container is 1-in / 1-out)");
+    }
   }
   else
     throw std::runtime_error("No config parser registered for architecture: " + arch);

@@ -835,6 +835,67 @@ class OracleLSTM(OracleDSP):
         return out
 
 
+class OracleContainer(OracleDSP):
+    """SlimmableContainer — NAM/container.cpp:17-144. Submodels are whole .nam documents; one is active at a time
+    (the last one on construction), chosen by SetSlimmableSize: first max_value with val < max_value, else last."""
+
+    def __init__(self, config: dict, sample_rate: float, fast_tanh: bool):
+        subs = config.get("submodels")
+        if not isinstance(subs, list) or not subs:
+            raise RuntimeError("SlimmableContainer: 'submodels' must be a non-empty array")
+        self.expected_sample_rate = sample_rate
+        self._max = [float(e["max_value"]) for e in subs]
+        self._models = [load_nam_json(e["model"], fast_tanh=fast_tanh) for e in subs]
+        for i in range(1, len(self._max)):  # container.cpp:26-30
+            if self._max[i] <= self._max[i - 1]:
+                raise RuntimeError("ContainerModel: submodels must be sorted by ascending max_value")
+        if self._max[-1] < 1.0:  # :31-32
+            raise RuntimeError("ContainerModel: last submodel max_value must be >= 1.0")
+        for m in self._models:  # :35-46
+            sr = m.expected_sample_rate
+            if sr != sample_rate and sr != -1.0 and sample_rate != -1.0:
+                raise RuntimeError(f"ContainerModel: submodel sample rate mismatch (expected {sample_rate:g}, got {sr:g})")
+        self._active = len(self._models) - 1  # :49
+        self._reset_args = None
+
+    def index_for(self, val: float) -> int:  # container.cpp:103-115
+        for i, mx in enumerate(self._max):
+            if val < mx:
+                return i
+        return len(self._max) - 1
+
+    def SetSlimmableSize(self, val: float):  # :117-139: a change of submodel Resets the newly active one
+        i = self.index_for(val)
+        if i == self._active:
+            return
+        if self._reset_args is not None:
+            self._models[i].Reset(*self._reset_args)
+        self._active = i
+
+    def GetSlimmableSizeBreakpoints(self) -> List[float]:
+        return list(self._max[:-1])
+
+    def NumInputChannels(self):
+        return 1  # container.cpp:19
+
+    def NumOutputChannels(self):
+        return 1
+
+    def GetPrewarmSamples(self):
+        return self._models[self._active].GetPrewarmSamples()
+
+    def Reset(self, sample_rate, max_buffer_size, prewarm=True):  # :85-101: only the active submodel
+        self.max_buffer_size = max_buffer_size
+        self._reset_args = (sample_rate, max_buffer_size, prewarm)
+        self._models[self._active].Reset(sample_rate, max_buffer_size, prewarm)
+
+    def process(self, x):
+        return self._models[self._active].process(x)
+
+    def process_stream(self, x, block):
+        return self._models[self._active].process_stream(x, block)
+
+
 # ---------------------------------------------------------------------------
 # get_dsp — get_dsp.cpp:141-273
 # ---------------------------------------------------------------------------
@@ -854,6 +915,8 @@ def load_nam_json(j: dict, fast_tanh: bool = False) -> OracleDSP:
             dsp = OracleWaveNet(parse_wavenet_config(config), weights, sample_rate, fast_tanh)
     elif arch == "LSTM":
         dsp = OracleLSTM(config, weights, sample_rate, fast_tanh)
+    elif arch == "SlimmableContainer":
+        dsp = OracleContainer(config, sample_rate, fast_tanh)
     else:
         raise RuntimeError("No config parser registered for architecture: " + str(arch))
     md = j.get("metadata")

@@ -21,7 +21,10 @@ import nam_oracle  # noqa: E402
 from signals import two_tone  # noqa: E402
 
 MODELS = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable_wavenet", "wavenet_condition_dsp",
-          "synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed"]  # synth_*: make_synthetic_models.py
+          "synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed",  # synth_*: make_synthetic_models.py
+          "A2", "slimmable_container"]  # SlimmableContainer files: the default (last) submodel
+# container submodels below the top one: (file, SetSlimmableSize value)
+CONTAINER_RATIOS = [("A2", 0.2), ("slimmable_container", 0.1), ("slimmable_container", 0.5)]
 
 
 def main():
@@ -37,6 +40,11 @@ def main():
         m.SetSlimmableSize(ratio)
         m.Reset(48000.0, 64)
         out[f"slimmable_wavenet__{tag}"] = m.process_stream(x, 64).astype(np.float32)
+    for name, ratio in CONTAINER_RATIOS:
+        m = nam_oracle.get_dsp(os.path.join(HERE, "models", name + ".nam"), fast_tanh=True)
+        m.SetSlimmableSize(ratio)
+        m.Reset(48000.0, 64)
+        out[f"{name}__c{ratio}"] = m.process_stream(x, 64).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "outputs.npz"), **out)
     print("wrote", os.path.join(HERE, "outputs.npz"), {k: v.shape for k, v in out.items()})
 

@@ -266,7 +266,7 @@ def test_cpp_adapter_benchmodel_runs(nam_lib):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "cpp")])
     for args in ([model_path("wavenet")], [model_path("lstm")], [model_path("slimmable_wavenet"), "--slim", "0.5"],
-                 [model_path("wavenet_a1_standard"), "--streams", "64"]):
+                 [model_path("wavenet_a1_standard"), "--streams", "64"], [model_path("A2")], [model_path("A2"), "--slim", "0.2"]):
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         assert "ms" in out.stdout
@@ -362,3 +362,54 @@ def _read_f32_wav_any(path):
     v = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
     v = np.where(v >= 1 << 23, v - (1 << 24), v)
     return (v / 8388608.0).astype(np.float32), sr
+
+
+@pytest.mark.parametrize("name", ["A2", "slimmable_container"])
+def test_container_mixed_submodels_per_stream(nam_lib, oracle, name):
+    """SlimmableContainer on the device: streams of one batch run different submodels (LSTM / small WaveNet /
+    A1-standard WaveNet for slimmable_container.nam; A2-Lite / A2-Full for A2.nam), chosen per stream with the
+    container's max_value rule (container.cpp:103-115)."""
+    nam = nam_lib
+    ratios = [1.0, 0.0, 0.4, 0.7, 0.2, 0.9]
+    n = 64 * 4
+    x = stream_bank(len(ratios), n, seed=51)
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    assert model.architecture == "SlimmableContainer"
+    b = model.batch(len(ratios), 64)
+    b.Reset(prewarm=True)
+    for r in sorted(set(ratios)):
+        b.SetSlimmableSize(r, [s for s, v in enumerate(ratios) if v == r])
+    y = b.process_stream(x, 64)
+    for s, r in enumerate(ratios):
+        ref = _oracle_run(oracle, name, x[s], 64, True, ratio=r)
+        assert float(np.max(np.abs(ref - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(ref)))), (name, s, r)
+    b.close()
+
+
+def test_container_switching_back_and_forth(nam_lib, oracle):
+    """A stream that leaves a submodel and comes back: WaveNet submodels restart from Reset + prewarm, the LSTM
+    submodel keeps the state it had (the reference's LSTM has no buffers to clear) and is prewarmed again —
+    container.cpp:117-139 with each submodel's own Reset."""
+    nam = nam_lib
+    name = "slimmable_container"
+    schedule = [1.0, 0.1, 0.5, 0.1, 1.0, 0.1]
+    seg = 64 * 2
+    x = stream_bank(2, seg * len(schedule), seed=52)
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    b = model.batch(2, 64)
+    b.Reset(prewarm=True)
+    ref = oracle.get_dsp(model_path(name), fast_tanh=True)
+    ref.Reset(48000.0, 64)
+    for i, r in enumerate(schedule):
+        b.SetSlimmableSize(r, [1])  # stream 0 stays on the default submodel throughout
+        ref.SetSlimmableSize(r)
+        xs = x[:, i * seg:(i + 1) * seg]
+        y = b.process_stream(xs, 64)
+        want = ref.process_stream(xs[1], 64)
+        assert float(np.max(np.abs(want - y[1]))) <= 5e-5, (i, r)
+    full = _oracle_run(oracle, name, x[0], 64, True)
+    b2 = model.batch(1, 64)
+    b2.Reset(prewarm=True)
+    np.testing.assert_allclose(b2.process_stream(x[:1], 64)[0], full, atol=5e-5)
+    b.close()
+    b2.close()
