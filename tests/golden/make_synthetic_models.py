@@ -62,6 +62,62 @@ def build(name, arrays, seed):
     return len(weights)
 
 
+def build_general(name, in_channels, arrays, post_head, seed):
+    """Plain (ungated, no FiLM) WaveNet with an optional post-stack head and any channel counts.
+    arrays: (channels, dilations, activation, head_size, head_bias); post_head: dict or None
+    (model.cpp:21-103: repeat activation -> Conv1D(kernel_sizes[i]) with bias, `channels` wide inside)."""
+    rng = np.random.default_rng(seed)
+    layers, weights = [], []
+
+    def w(shape, fan_in):
+        v = rng.standard_normal(shape).astype(np.float32) * np.float32(0.9 / np.sqrt(fan_in))
+        weights.extend(v.reshape(-1).tolist())
+
+    K = 3
+    for i, (C, dil, act, head, hb) in enumerate(arrays):
+        in_size = in_channels if i == 0 else arrays[i - 1][0]
+        layers.append(dict(input_size=in_size, condition_size=in_channels, head_size=head, channels=C, kernel_size=K,
+                           dilations=dil, activation=act, gated=False, head_bias=hb))
+        w((C, in_size), in_size)
+        for _ in dil:
+            w((C, C, K), C * K)
+            w((C,), 4.0)
+            w((C, in_channels), in_channels)
+            w((C, C), C)
+            w((C,), 4.0)
+        w((head, C), C * len(dil))
+        if hb:
+            w((head,), 4.0)
+    if post_head is not None:
+        cin = arrays[-1][3]
+        ks = post_head["kernel_sizes"]
+        for i, k in enumerate(ks):
+            cout = post_head["out_channels"] if i + 1 == len(ks) else post_head["channels"]
+            w((cout, cin, k), cin * k)
+            w((cout,), 4.0)
+            cin = cout
+    weights.append(0.1)
+    config = dict(layers=layers, head=post_head, head_scale=0.1)
+    if in_channels != 1:
+        config["in_channels"] = in_channels
+    model = dict(version="0.5.4", architecture="WaveNet", config=config,
+                 metadata=dict(name=name, note="synthetic test fixture (seeded random weights)"), weights=weights, sample_rate=48000)
+    with open(os.path.join(HERE, "models", name + ".nam"), "w") as f:
+        json.dump(model, f)
+    return len(weights)
+
+
+GENERAL = {
+    # post-stack head (SURVEY 8f rank 3): ReLU -> Conv1D(K=3) -> ReLU -> Conv1D(K=2), 3 -> 5 -> 2 channels: two outputs
+    "synth_posthead": dict(in_channels=1, arrays=[(4, [1, 2, 4], "Tanh", 3, True)],
+                           post_head=dict(channels=5, out_channels=2, kernel_sizes=[3, 2], activation="ReLU"), seed=21),
+    # 3 inputs / 2 outputs (the shape tools/test/test_real_time_safe.cpp:1069 uses), no post-stack head
+    "synth_multich": dict(in_channels=3, arrays=[(4, [1, 3], "ReLU", 2, False), (2, [2, 5], "Tanh", 2, True)], post_head=None, seed=22),
+}
+
+
 if __name__ == "__main__":
     for name, spec in SPECS.items():
         print(name, build(name, **spec), "weights")
+    for name, spec in GENERAL.items():
+        print(name, build_general(name, **spec), "weights")

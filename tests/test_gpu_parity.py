@@ -413,3 +413,36 @@ def test_container_switching_back_and_forth(nam_lib, oracle):
     np.testing.assert_allclose(b2.process_stream(x[:1], 64)[0], full, atol=5e-5)
     b.close()
     b2.close()
+
+
+@pytest.mark.parametrize("name,in_ch", [("synth_posthead", 1), ("synth_multich", 3)])
+@pytest.mark.parametrize("fast_tanh", [True, False])
+def test_post_stack_head_and_multichannel_io(nam_lib, oracle, name, in_ch, fast_tanh):
+    """a post-stack head (activation -> Conv1D chain after the layer arrays, model.cpp:21-103,
+    854-883; two output channels) and a 3-in / 2-out model (test_real_time_safe.cpp:1069). Planar
+    [stream][channel][frame] I/O through process(), the f64 API, and the ragged render."""
+    nam = nam_lib
+    n_streams, n = 4, 64 * 3 + 9
+    rng = np.random.default_rng(61)
+    x = rng.uniform(-0.5, 0.5, (n_streams, in_ch, n)).astype(np.float32)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    assert (model.NumInputChannels(), model.NumOutputChannels()) == (in_ch, 2)
+    refs = []
+    for s in range(n_streams):
+        r = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+        r.Reset(48000.0, 64)
+        refs.append(r.process_stream(x[s], 64))
+    b = model.batch(n_streams, 64)
+    b.Reset(prewarm=True)
+    y = b.process_stream(x, 64)
+    b.Reset(prewarm=True)
+    y64 = b.process_stream(x.astype(np.float64), 64)
+    b.Reset(prewarm=True)
+    lens = [n, 100, 64, 1]
+    yr = b.render([x[s, :, :m] for s, m in enumerate(lens)])
+    for s in range(n_streams):
+        assert y[s].shape == refs[s].shape == (2, n)
+        assert float(np.max(np.abs(refs[s] - y[s]))) <= _tol(fast_tanh)
+        assert float(np.max(np.abs(refs[s] - y64[s]))) <= _tol(fast_tanh)
+        assert float(np.max(np.abs(refs[s][:, :lens[s]] - yr[s]))) <= _tol(fast_tanh)
+    b.close()
