@@ -66,12 +66,17 @@ struct LSTMArgs
   int head_w, head_b;
   int layer_w[16];
   int layer_b[16];
+  // nam_lstm_mfma_kernel (plan.h: LSTMPlan::mf_*)
+  int mf_off, mf_floats, mf_nt, mf_head_tiles, mf_head_bias, mf_lds_bytes;
+  int mf_layer_tiles[16];
+  int mf_layer_bias[16];
 };
 
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);
+hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream);
 int lstm_lds_bytes(const LSTMArgs& a);
 hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,
                              int n_init, int state_floats, hipStream_t stream);

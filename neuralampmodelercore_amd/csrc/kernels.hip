@@ -826,6 +826,277 @@ __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM on the matrix cores: 16 streams per wavefront, the per-sample [4H x (I + H)] . [x; h] of all 16 streams
+// is a handful of v_mfma_f32_16x16x4_f32 (columns = streams). Weight rows are permuted (plan.h) so that lane
+// group u of a unit tile receives the i, f, g, o pre-activations of ONE hidden unit: the gate math and the c / h
+// update stay in that lane, and the lane's new h is exactly the B operand it feeds into the next time step /
+// next layer. Everything (tiles, h, c, I/O tiles) lives in LDS; one wavefront per workgroup, no barriers.
+// lstm.nam (H = 3): 2 MFMAs + one head MFMA per sample instead of 60 scalar-weight FMAs with exposed latency.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void nam_lstm_mfma_kernel(const float* __restrict__ blob, const LSTMArgs a)
+{
+  using mf::f4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, j = lane & 15;
+  const int s0 = blockIdx.x * 16;
+  const bool live = s0 + j < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + j] : s0 + j) : 0;
+  const int H = a.hidden, NL = a.n_layers, I0 = a.input_size, NT = a.mf_nt;
+  const int in_ch = a.in_ch, out_ch = a.out_ch;
+  const int KI0 = (I0 + 3) / 4;
+  float* region = lds; // tiles, biases (plan.h)
+  float* hbuf = region + a.mf_floats; // [2][NL][4 NT][16]
+  float* cbuf = hbuf + 2 * NL * 4 * NT * 16; // [NL][4 NT][16]
+  float* xin = cbuf + NL * 4 * NT * 16; // [in_ch][16][65]
+  float* yout = xin + in_ch * 16 * 65; // [out_ch][16][65]
+  const int hstride = NL * 4 * NT * 16; // one time parity of hbuf
+
+  for (int i = lane; i < a.mf_floats; i += 64)
+    region[i] = blob[a.mf_off + i];
+  // recurrent state: lane (grp, j) owns unit 4T + grp of stream j
+  float* st = a.state + (size_t)stream * a.state_stride;
+  for (int l = 0; l < NL; l++)
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      const bool ok = live && u < H;
+      hbuf[hstride + (l * 4 * NT + u) * 16 + j] = ok ? st[(l * 2 + 0) * H + u] : 0.0f; // parity 1 = "time -1"
+      cbuf[(l * 4 * NT + u) * 16 + j] = ok ? st[(l * 2 + 1) * H + u] : 0.0f;
+    }
+  int par = 0; // parity of the time step being computed
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    // coalesced input tile: row r = stream of position s0 + r, lane = frame
+    for (int c = 0; c < in_ch; c++)
+      for (int r = 0; r < 16; r++)
+      {
+        const int s = __shfl(stream, r);
+        float v = 0.0f;
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
+          v = a.in[((size_t)s * in_ch + c) * a.io_stride + f0 + lane];
+        xin[(c * 16 + r) * 65 + lane] = v;
+      }
+    for (int t = 0; t < nvalid; t++)
+    {
+      const float* hprev = hbuf + (par ^ 1) * hstride; // h(t - 1)
+      float* hcur = hbuf + par * hstride; // h(t)
+      for (int l = 0; l < NL; l++)
+      {
+        const int KI = l == 0 ? KI0 : NT;
+        const float* tiles = region + a.mf_layer_tiles[l];
+        const float* bias = region + a.mf_layer_bias[l];
+        for (int T = 0; T < NT; T++)
+        {
+          f4 acc = *reinterpret_cast<const f4*>(bias + (T * 4 + grp) * 4); // i, f, g, o biases of unit 4T + grp
+          const float* tl = tiles + (size_t)T * (KI + NT) * 64 + lane;
+          for (int s = 0; s < KI; s++) // layer input: x(t) or the layer below's h(t)
+          {
+            const int e = 4 * s + grp;
+            const float b = l == 0 ? (e < I0 ? xin[(e * 16 + j) * 65 + t] : 0.0f) : hcur[((l - 1) * 4 * NT + e) * 16 + j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[s * 64], b, acc, 0, 0, 0);
+          }
+          for (int s = 0; s < NT; s++) // this layer's h(t - 1)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[(KI + s) * 64], hprev[(l * 4 * NT + 4 * s + grp) * 16 + j], acc, 0, 0, 0);
+          const int u = 4 * T + grp;
+          const float cprev = cbuf[(l * 4 * NT + u) * 16 + j];
+          float cn, hn;
+          if (a.fast)
+          {
+            cn = d_fast_sigmoid(acc[1]) * cprev + d_fast_sigmoid(acc[0]) * d_fast_tanh(acc[2]);
+            hn = d_fast_sigmoid(acc[3]) * d_fast_tanh(cn);
+          }
+          else
+          {
+            cn = d_sigmoid(acc[1]) * cprev + d_sigmoid(acc[0]) * tanhf(acc[2]);
+            hn = d_sigmoid(acc[3]) * tanhf(cn);
+          }
+          cbuf[(l * 4 * NT + u) * 16 + j] = cn;
+          hcur[(l * 4 * NT + u) * 16 + j] = hn;
+        }
+      }
+      // head: y = Wh . h_top(t) + bh; lane group g receives output channels 4g..4g+3
+      {
+        f4 acc = *reinterpret_cast<const f4*>(region + a.mf_head_bias + grp * 4);
+        const float* tl = region + a.mf_head_tiles + lane;
+        for (int s = 0; s < NT; s++)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[s * 64], hcur[((NL - 1) * 4 * NT + 4 * s + grp) * 16 + j], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (4 * grp + e < out_ch)
+            yout[((4 * grp + e) * 16 + j) * 65 + t] = acc[e];
+      }
+      par ^= 1;
+    }
+    if (a.out)
+      for (int c = 0; c < out_ch; c++)
+        for (int r = 0; r < 16; r++)
+        {
+          const int s = __shfl(stream, r);
+          if (s0 + r < a.n_streams && lane < nvalid)
+            a.out[((size_t)s * out_ch + c) * a.io_stride + f0 + lane] = yout[(c * 16 + r) * 65 + lane];
+        }
+  }
+  // the last computed step has parity par ^ 1
+  const float* hlast = hbuf + (par ^ 1) * hstride;
+  for (int l = 0; l < NL; l++)
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      if (live && u < H)
+      {
+        st[(l * 2 + 0) * H + u] = hlast[(l * 4 * NT + u) * 16 + j];
+        st[(l * 2 + 1) * H + u] = cbuf[(l * 4 * NT + u) * 16 + j];
+      }
+    }
+}
+
+// The same kernel for small models (<= 2 layers, <= 16 hidden units, <= 4 inputs), fully unrolled: every A
+// tile value, bias, h and c of the lane stays in registers for the whole launch; per sample only the input is
+// read from LDS and the output written to it. lstm.nam: ~0.2 us per sample step instead of ~0.9.
+template <int NL, int NT>
+__global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __restrict__ blob, const LSTMArgs a)
+{
+  using mf::f4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, j = lane & 15;
+  const int s0 = blockIdx.x * 16;
+  const bool live = s0 + j < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + j] : s0 + j) : 0;
+  const int H = a.hidden, I0 = a.input_size;
+  const int in_ch = a.in_ch, out_ch = a.out_ch;
+  float* xin = lds; // [in_ch][16][65]
+  float* yout = xin + in_ch * 16 * 65; // [out_ch][16][65]
+  const float* region = blob + a.mf_off;
+
+  float wi[NL][NT][NT], wr[NL][NT][NT], h[NL][NT], c[NL][NT], wh[NT];
+  f4 bias[NL][NT];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    const int KI = l == 0 ? 1 : NT; // input_size <= 4: one k-step
+    const float* tiles = region + a.mf_layer_tiles[l];
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+    {
+#pragma unroll
+      for (int s = 0; s < NT; s++)
+      {
+        wi[l][T][s] = s < KI ? tiles[(T * (KI + NT) + s) * 64 + lane] : 0.0f;
+        wr[l][T][s] = tiles[(T * (KI + NT) + KI + s) * 64 + lane];
+      }
+      bias[l][T] = *reinterpret_cast<const f4*>(region + a.mf_layer_bias[l] + (T * 4 + grp) * 4);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NT; s++)
+    wh[s] = region[a.mf_head_tiles + s * 64 + lane];
+  const f4 hbias = *reinterpret_cast<const f4*>(region + a.mf_head_bias + grp * 4);
+  float* st = a.state + (size_t)stream * a.state_stride;
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      const bool ok = live && u < H;
+      h[l][T] = ok ? st[(l * 2 + 0) * H + u] : 0.0f;
+      c[l][T] = ok ? st[(l * 2 + 1) * H + u] : 0.0f;
+    }
+  const bool fast = a.fast != 0;
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    for (int ch = 0; ch < in_ch; ch++)
+      for (int r = 0; r < 16; r++)
+      {
+        const int s = __shfl(stream, r);
+        float v = 0.0f;
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
+          v = a.in[((size_t)s * in_ch + ch) * a.io_stride + f0 + lane];
+        xin[(ch * 16 + r) * 65 + lane] = v;
+      }
+    const int xrow = (min(grp, in_ch - 1) * 16 + j) * 65; // lane group g feeds input element g (zero weights beyond I0)
+    float xv = xin[xrow];
+    for (int t = 0; t < nvalid; t++)
+    {
+      const float xnext = xin[xrow + min(t + 1, kBlock - 1)]; // next step's input, off the critical path
+      const float x0 = grp < I0 ? xv : 0.0f;
+      float hn[NL][NT];
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+      {
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+        {
+          f4 acc = bias[l][T];
+          if (l == 0)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], x0, acc, 0, 0, 0);
+          else
+          {
+#pragma unroll
+            for (int s = 0; s < NT; s++)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[l][T][s], hn[l > 0 ? l - 1 : 0][s], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int s = 0; s < NT; s++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l][T][s], h[l][s], acc, 0, 0, 0);
+          float cn, hv;
+          if (fast)
+          {
+            cn = d_fast_sigmoid(acc[1]) * c[l][T] + d_fast_sigmoid(acc[0]) * d_fast_tanh(acc[2]);
+            hv = d_fast_sigmoid(acc[3]) * d_fast_tanh(cn);
+          }
+          else
+          {
+            cn = d_sigmoid(acc[1]) * c[l][T] + d_sigmoid(acc[0]) * tanhf(acc[2]);
+            hv = d_sigmoid(acc[3]) * tanhf(cn);
+          }
+          c[l][T] = cn;
+          hn[l][T] = hv;
+        }
+      }
+      f4 acc = hbias;
+#pragma unroll
+      for (int s = 0; s < NT; s++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], hn[NL - 1][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (4 * grp + e < out_ch)
+          yout[((4 * grp + e) * 16 + j) * 65 + t] = acc[e];
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+          h[l][T] = hn[l][T];
+      xv = xnext;
+    }
+    if (a.out)
+      for (int ch = 0; ch < out_ch; ch++)
+        for (int r = 0; r < 16; r++)
+        {
+          const int s = __shfl(stream, r);
+          if (s0 + r < a.n_streams && lane < nvalid)
+            a.out[((size_t)s * out_ch + ch) * a.io_stride + f0 + lane] = yout[(ch * 16 + r) * 65 + lane];
+        }
+  }
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      if (live && u < H)
+      {
+        st[(l * 2 + 0) * H + u] = h[l][T];
+        st[(l * 2 + 1) * H + u] = c[l][T];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // State initialisation
 // ------------------------------------------------------------------------------------------------
 __global__ void nam_fill_state_kernel(float* state, long state_stride, const int* stream_map, int n_streams,
@@ -1329,6 +1600,43 @@ hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream)
   }
   const int n_blocks = (a.n_streams + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(nam_lstm_kernel, dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
+{
+  static int lds_limit = 0;
+  if (a.mf_lds_bytes > lds_limit)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nam_lstm_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, a.mf_lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    lds_limit = a.mf_lds_bytes;
+  }
+  const int n_blocks = (a.n_streams + 15) / 16;
+  // small models: everything in registers (only the I/O tiles in LDS)
+  if (a.input_size <= 4 && a.n_layers <= 2 && a.mf_nt <= 4)
+  {
+    const int io_bytes = (a.in_ch + a.out_ch) * 16 * 65 * (int)sizeof(float);
+#define NAM_LSTM_REG(NL, NT) \
+  hipLaunchKernelGGL((nam_lstm_mfma_reg_kernel<NL, NT>), dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a)
+    const int key = a.n_layers * 10 + a.mf_nt;
+    switch (key)
+    {
+      case 11: NAM_LSTM_REG(1, 1); break;
+      case 12: NAM_LSTM_REG(1, 2); break;
+      case 13: NAM_LSTM_REG(1, 3); break;
+      case 14: NAM_LSTM_REG(1, 4); break;
+      case 21: NAM_LSTM_REG(2, 1); break;
+      case 22: NAM_LSTM_REG(2, 2); break;
+      case 23: NAM_LSTM_REG(2, 3); break;
+      default: NAM_LSTM_REG(2, 4); break;
+    }
+#undef NAM_LSTM_REG
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(nam_lstm_mfma_kernel, dim3(n_blocks), dim3(64), a.mf_lds_bytes, stream, a.blob, a);
   return hipGetLastError();
 }
 

@@ -287,9 +287,26 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.layer_w[i] = L.layer_w[i];
       a.layer_b[i] = L.layer_b[i];
     }
-    if (lstm_lds_bytes(a) > 160 * 1024)
-      return fail(NAM_HIP_ERR_UNSUPPORTED, "LSTM too large for the LDS-resident kernel");
-    NAM_HIP_CHECK(launch_lstm(a, s));
+    a.mf_off = L.mf_off;
+    a.mf_floats = L.mf_floats;
+    a.mf_nt = L.mf_nt;
+    a.mf_head_tiles = L.mf_head_tiles;
+    a.mf_head_bias = L.mf_head_bias;
+    a.mf_lds_bytes = L.mf_lds_bytes;
+    for (int i = 0; i < 16; i++)
+    {
+      a.mf_layer_tiles[i] = L.mf_layer_tiles[i];
+      a.mf_layer_bias[i] = L.mf_layer_bias[i];
+    }
+    // AUTO: the matrix-core kernel (16 streams per wavefront); NAM_HIP_KERNEL_GENERIC: lanes = streams
+    if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
+      NAM_HIP_CHECK(launch_lstm_mfma(a, s));
+    else
+    {
+      if (lstm_lds_bytes(a) > 160 * 1024)
+        return fail(NAM_HIP_ERR_UNSUPPORTED, "LSTM too large for the LDS-resident kernel");
+      NAM_HIP_CHECK(launch_lstm(a, s));
+    }
   }
   return NAM_HIP_OK;
 }

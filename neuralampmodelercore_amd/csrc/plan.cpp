@@ -851,6 +851,60 @@ static Plan build_lstm_plan(const ModelSpec& model)
     throw std::runtime_error("plan: LSTM weight stream not fully consumed");
   L.valid = 1;
   plan.state_floats = (c.num_layers * 2 * H + kBlock - 1) / kBlock * kBlock;
+
+  // ---- MFMA tiles (plan.h) ----
+  if (c.out_channels <= 16)
+  {
+    const int NT = (H + 3) / 4;
+    while (plan.blob.size() % 64)
+      plan.blob.push_back(0.0f);
+    L.mf_off = (int)plan.blob.size();
+    L.mf_nt = NT;
+    std::vector<float> R;
+    for (int l = 0; l < c.num_layers; l++)
+    {
+      const int I = l == 0 ? c.input_size : H;
+      const int KI = (I + 3) / 4;
+      const float* W = plan.blob.data() + L.layer_w[l]; // [4H][I + H] row-major (lstm.cpp:9-29)
+      const float* B = plan.blob.data() + L.layer_b[l];
+      L.mf_layer_tiles[l] = (int)R.size();
+      for (int T = 0; T < NT; T++)
+        for (int s = 0; s < KI + NT; s++)
+          for (int lane = 0; lane < 64; lane++)
+          {
+            const int k = lane >> 4, i = lane & 15;
+            const int unit = 4 * T + (i >> 2), gate = i & 3;
+            const int e = 4 * (s < KI ? s : s - KI) + k; // input element this lane group feeds in this k-step
+            const int col = s < KI ? (e < I ? e : -1) : (e < H ? I + e : -1);
+            R.push_back((unit < H && col >= 0) ? W[(size_t)(gate * H + unit) * (I + H) + col] : 0.0f);
+          }
+      L.mf_layer_bias[l] = (int)R.size();
+      for (int T = 0; T < NT; T++)
+        for (int u = 0; u < 4; u++)
+          for (int gate = 0; gate < 4; gate++)
+            R.push_back(4 * T + u < H ? B[gate * H + 4 * T + u] : 0.0f);
+    }
+    const float* Wh = plan.blob.data() + L.head_w; // [out][H]
+    const float* Bh = plan.blob.data() + L.head_b;
+    L.mf_head_tiles = (int)R.size();
+    for (int s = 0; s < NT; s++)
+      for (int lane = 0; lane < 64; lane++)
+      {
+        const int k = lane >> 4, o = lane & 15, e = 4 * s + k;
+        R.push_back((o < c.out_channels && e < H) ? Wh[(size_t)o * H + e] : 0.0f);
+      }
+    L.mf_head_bias = (int)R.size();
+    for (int o = 0; o < 16; o++)
+      R.push_back(o < c.out_channels ? Bh[o] : 0.0f);
+    while (R.size() % 64)
+      R.push_back(0.0f);
+    L.mf_floats = (int)R.size();
+    plan.blob.insert(plan.blob.end(), R.begin(), R.end());
+    // LDS: region | h [2][layers][4 NT][16] | c [layers][4 NT][16] | in [in_ch][16][65] | out [out_ch][16][65]
+    const long lds_floats = (long)L.mf_floats + 3L * c.num_layers * 4 * NT * 16 + (long)(c.in_channels + c.out_channels) * 16 * 65;
+    L.mf_lds_bytes = (int)(lds_floats * 4);
+    L.mf_ok = lds_floats * 4 <= 150 * 1024 ? 1 : 0;
+  }
   return plan;
 }
 

@@ -188,6 +188,20 @@ struct LSTMPlan
   int32_t layer_w[16] = {0};
   int32_t layer_b[16] = {0};
   std::vector<float> init_state; // [n_layers][2][H]
+  // nam_lstm_mfma_kernel (16 streams per wavefront, one v_mfma_f32_16x16x4_f32 per 4 units x 4 inputs):
+  // one contiguous blob region [mf_off, mf_off + mf_floats) that the kernel copies to LDS verbatim:
+  //   per layer l, per unit tile T (4 units), per k-step s: a 64-float A tile, lane (k = lane >> 4, i = lane & 15)
+  //     = W[gate(i & 3) * H + 4T + (i >> 2)][column of input element 4s + k]   (rows permuted so that one lane
+  //     group receives the i, f, g, o pre-activations of ONE unit); k-steps: ceil(I_l / 4) over the layer input,
+  //     then ceil(H / 4) over the recurrent state;
+  //   per layer, per tile: 16 bias floats [unit][gate]; head: ceil(H / 4) A tiles (row = output channel), 16 biases.
+  int32_t mf_ok = 0;
+  int32_t mf_off = 0, mf_floats = 0;
+  int32_t mf_nt = 0; // unit tiles = ceil(H / 4)
+  int32_t mf_layer_tiles[16] = {0}; // float offset (inside the region) of layer l's A tiles
+  int32_t mf_layer_bias[16] = {0}; // ... of layer l's bias table [NT][16]
+  int32_t mf_head_tiles = 0, mf_head_bias = 0;
+  int32_t mf_lds_bytes = 0; // region + h (double buffered) + c + I/O tiles
 };
 
 struct Plan

@@ -116,7 +116,48 @@ GENERAL = {
 }
 
 
+def build_lstm(name, num_layers, input_size, hidden, out_channels, seed):
+    """LSTM weight stream (lstm.cpp:9-29, 70-101): per layer W [4H][I+H] row-major, b [4H], h0 [H], c0 [H];
+    then head W [out][H], b [out]."""
+    rng = np.random.default_rng(seed)
+    weights = []
+
+    def w(shape, scale):
+        weights.extend((rng.standard_normal(shape).astype(np.float32) * np.float32(scale)).reshape(-1).tolist())
+
+    for l in range(num_layers):
+        I = input_size if l == 0 else hidden
+        w((4 * hidden, I + hidden), 0.6 / np.sqrt(I + hidden))
+        w((4 * hidden,), 0.2)
+        w((hidden,), 0.1)
+        w((hidden,), 0.1)
+    w((out_channels, hidden), 1.0 / np.sqrt(hidden))
+    w((out_channels,), 0.1)
+    config = dict(input_size=input_size, hidden_size=hidden, num_layers=num_layers)
+    if input_size != 1:
+        config["in_channels"] = input_size
+    if out_channels != 1:
+        config["out_channels"] = out_channels
+    model = dict(version="0.5.4", architecture="LSTM", config=config,
+                 metadata=dict(name=name, note="synthetic test fixture (seeded random weights)"), weights=weights, sample_rate=48000)
+    with open(os.path.join(HERE, "models", name + ".nam"), "w") as f:
+        json.dump(model, f)
+    return len(weights)
+
+
+LSTMS = {
+    # 18 hidden units = 5 unit tiles with a partial one, two layers: exercises the layer-to-layer k-steps
+    "synth_lstm_h18x2": dict(num_layers=2, input_size=1, hidden=18, out_channels=1, seed=31),
+    # 2 inputs / 3 outputs, one layer of 8
+    "synth_lstm_io": dict(num_layers=1, input_size=2, hidden=8, out_channels=3, seed=32),
+    # two layers of 10 (3 unit tiles): the register-resident kernel's layer-to-layer path
+    "synth_lstm_h10x2": dict(num_layers=2, input_size=1, hidden=10, out_channels=1, seed=33),
+}
+
+
 if __name__ == "__main__":
+    for name, spec in LSTMS.items():
+        print(name, build_lstm(name, **spec), "weights")
     for name, spec in SPECS.items():
         print(name, build(name, **spec), "weights")
     for name, spec in GENERAL.items():

@@ -446,3 +446,27 @@ def test_post_stack_head_and_multichannel_io(nam_lib, oracle, name, in_ch, fast_
         assert float(np.max(np.abs(refs[s] - y64[s]))) <= _tol(fast_tanh)
         assert float(np.max(np.abs(refs[s][:, :lens[s]] - yr[s]))) <= _tol(fast_tanh)
     b.close()
+
+
+@pytest.mark.parametrize("name,in_ch", [("lstm", 1), ("synth_lstm_h18x2", 1), ("synth_lstm_io", 2), ("synth_lstm_h10x2", 1)])
+@pytest.mark.parametrize("kernel", ["mfma", "lanes"])
+def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
+    """Both LSTM kernels — matrix-core (16 streams per wavefront; AUTO) and lanes-are-streams (GENERIC) —
+    against the oracle: partial wavefronts, several unit tiles with a ragged last one, two layers, 2-in / 3-out."""
+    nam = nam_lib
+    n_streams, n = 37, 64 * 3 + 11
+    rng = np.random.default_rng(71)
+    x = rng.uniform(-0.5, 0.5, (n_streams, in_ch, n)).astype(np.float32)
+    for fast_tanh in (True, False):
+        model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+        b = model.batch(n_streams, 64)
+        if kernel == "lanes":
+            b.set_kernel(nam.KERNEL_GENERIC)
+        b.Reset(prewarm=True)
+        y = b.process_stream(x, 64)
+        for s in (0, 1, 15, 16, 31, 32, 36):
+            r = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+            r.Reset(48000.0, 64)
+            ref = r.process_stream(x[s], 64)
+            assert float(np.max(np.abs(ref - y[s]))) <= _tol(fast_tanh) * max(1.0, float(np.max(np.abs(ref)))), (name, kernel, s)
+        b.close()
