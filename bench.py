@@ -107,9 +107,17 @@ def wavenet_macs_per_sample(cfg: dict) -> int:
     return macs
 
 
-def model_macs(path: str) -> int:
+def active_model_json(path: str) -> dict:
+    """The .nam document that actually runs: a SlimmableContainer starts on its last submodel (container.cpp:49)."""
     with open(path) as f:
         j = json.load(f)
+    while j["architecture"] == "SlimmableContainer":
+        j = j["config"]["submodels"][-1]["model"]
+    return j
+
+
+def model_macs(path: str) -> int:
+    j = active_model_json(path)
     if j["architecture"] == "WaveNet":
         return wavenet_macs_per_sample(j["config"])
     c = j["config"]
@@ -285,8 +293,7 @@ def main():
         samples_per_launch = samples_per_step_gpu * (1 if args.launch == "block" else K)
         flops_per_launch = flops_per_sample * samples_per_launch
         achieved_tf = flops_per_launch / avg_launch_s / 1e12
-        with open(model_path) as f:
-            mj = json.load(f)
+        mj = active_model_json(model_path)
         hist = wavenet_history_bytes_per_sample(mj["config"]) if mj["architecture"] == "WaveNet" else 0
         bytes_per_sample = hist + 4 * (ic + oc)
         achieved_gbs = bytes_per_sample * samples_per_launch / avg_launch_s / 1e9
