@@ -155,11 +155,27 @@ def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: f
         os.remove(fast_so)
     except OSError:
         pass
-    return {
+    out = {
         "value": round(len(x) / SR / dt, 3), "unit": "xRT (48 kHz real-time streams)", "cores": 1, "kind": "port",
         "sample": f"1 stream x {secs_audio:.1f} s of two-tone audio in {block}-frame blocks after Reset+prewarm, "
                   f"oracle/nam_oracle.c built {kind_flags}, {dt:.2f} s of CPU",
     }
+    # alongside: the reference's own sources (oracle/_ref, prebuilt where /root/reference exists). Their Eigen calls
+    # run on a scalar stand-in, so this is a floor for the reference, not its real speed; the faster of the two
+    # (the port) stays the reported baseline.
+    try:
+        import nam_ref
+        if os.path.exists(nam_ref.LIB):
+            r = nam_ref.get_dsp(model_path, fast_tanh)
+            r.Reset(SR, block)
+            xr = two_tone(int(min(secs_audio, 20.0) * SR))
+            t0 = time.perf_counter()
+            r.process_stream(xr, block)
+            out["reference_sources_on_eigen_stand_in"] = {"value": round(len(xr) / SR / (time.perf_counter() - t0), 3), "cores": 1,
+                                                            "note": "oracle/_ref/libnam_ref.so, -O2, scalar Eigen stand-in"}
+    except Exception as e:  # the checker library is optional
+        out["reference_sources_on_eigen_stand_in"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():

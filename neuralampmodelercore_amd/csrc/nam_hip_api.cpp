@@ -448,7 +448,9 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
   info->architecture = s.arch == ARCH_WAVENET ? NAM_HIP_ARCH_WAVENET : s.arch == ARCH_LSTM ? NAM_HIP_ARCH_LSTM : NAM_HIP_ARCH_CONTAINER;
   info->in_channels = s.in_channels();
   info->out_channels = s.out_channels();
-  info->prewarm_samples = p.prewarm_samples;
+  // what GetPrewarmSamples() of the reference object returns: a SlimmableWavenet answers 0 (slimmable.h:66 — its
+  // inner WaveNet prewarms inside its own Reset); everything else its own count (container: the active submodel)
+  info->prewarm_samples = (s.arch == ARCH_WAVENET && s.wavenet.slimmable) ? 0 : p.prewarm_samples;
   info->expected_sample_rate = s.sample_rate;
   info->has_loudness = s.has_loudness;
   info->has_input_level = s.has_input_level;

@@ -654,7 +654,18 @@ static void check_wavenet_weights(const WaveNetSpec& wc)
     // model.cpp:671-682 — the reference reports either direction as "Weight mismatch"
     std::stringstream ss;
     if (got > expect)
-      ss << "Weight mismatch: assigned " << expect << " weights, but " << got << " were provided.";
+    {
+      // the reference reports the position of the first weight whose VALUE equals the first unassigned one
+      // (model.cpp:674-679), which is `expect + 1` unless that value also occurs earlier in the stream
+      long pos = expect;
+      for (long i = 0; i < got; i++)
+        if (wc.weights[(size_t)i] == wc.weights[(size_t)expect])
+        {
+          pos = i;
+          break;
+        }
+      ss << "Weight mismatch: assigned " << pos + 1 << " weights, but " << got << " were provided.";
+    }
     else
       ss << "Weight mismatch: provided " << got << " weights, but the model expects more.";
     throw std::runtime_error(ss.str());

@@ -654,8 +654,11 @@ class OracleWaveNet(OracleDSP):
         w = np.ascontiguousarray(weights, dtype=np.float32)
         self.expected_weights = int(L.orc_wavenet_expected_weights(self._h))
         if L.orc_wavenet_finalize(self._h, _fptr(w), len(w)) != 0:
-            raise RuntimeError(f"Weight mismatch: model expects {self.expected_weights} weights, "
-                               f"but {len(w)} were provided.")
+            # model.cpp:671-682 (the "assigned" position is found by VALUE: first weight equal to the first unassigned one)
+            if len(w) > self.expected_weights:
+                pos = int(np.flatnonzero(w == w[self.expected_weights])[0])
+                raise RuntimeError(f"Weight mismatch: assigned {pos + 1} weights, but {len(w)} were provided.")
+            raise RuntimeError(f"Weight mismatch: provided {len(w)} weights, but the model expects more.")
 
     def __del__(self):
         if getattr(self, "_owned", False) and getattr(self, "_h", None):
@@ -773,7 +776,7 @@ class OracleSlimmableWaveNet(OracleDSP):
         return self._active.NumOutputChannels()
 
     def GetPrewarmSamples(self):
-        return self._active.GetPrewarmSamples()
+        return 0  # slimmable.h:66 — the wrapper itself never prewarms; the active inner WaveNet does in its Reset
 
     def Reset(self, sample_rate, max_buffer_size, prewarm=True):
         self.max_buffer_size = max_buffer_size

@@ -470,3 +470,29 @@ def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
             ref = r.process_stream(x[s], 64)
             assert float(np.max(np.abs(ref - y[s]))) <= _tol(fast_tanh) * max(1.0, float(np.max(np.abs(ref)))), (name, kernel, s)
         b.close()
+
+
+def test_device_matches_the_reference_library(nam_lib):
+    """The HIP path against the reference's own sources (oracle/_ref/libnam_ref.so, built from /root/reference
+    where it exists and shipped prebuilt to the GPU box) — no restatement in between."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nam_ref
+    if not os.path.exists(nam_ref.LIB):
+        pytest.skip("oracle/_ref/libnam_ref.so was not built (needs /root/reference at build time)")
+    nam = nam_lib
+    x = stream_bank(3, 64 * 5 + 3, seed=81)
+    for name, ft in (("wavenet_a1_standard", True), ("wavenet_a1_standard", False), ("wavenet_a2_max", False), ("A2", True),
+                     ("slimmable_container", True), ("lstm", True), ("synth_a1_c8", True)):
+        model = nam.get_dsp(model_path(name), fast_tanh=ft)
+        b = model.batch(3, 64)
+        b.Reset(prewarm=True)
+        y = b.process_stream(x, 64)
+        for s in range(3):
+            ref = nam_ref.get_dsp(model_path(name), ft)
+            ref.Reset(48000.0, 64)
+            r = ref.process_stream(x[s], 64)
+            assert float(np.max(np.abs(r - y[s]))) <= _tol(ft) * max(1.0, float(np.max(np.abs(r)))), (name, ft, s)
+        b.close()

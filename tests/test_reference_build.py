@@ -1,0 +1,100 @@
+"""Pins the oracle to the REFERENCE ITSELF: oracle/_ref/libnam_ref.so is the reference's own, unmodified C++
+sources (NAM/{activations,conv1d,dsp,get_dsp,lstm,nam_file,ring_buffer,util,container}.cpp,
+NAM/wavenet/{model,slimmable}.cpp) compiled where they lie against the self-written Eigen stand-in of
+oracle/eigen_shim (the real Eigen is absent here). The oracle restatement must reproduce it exactly — the two
+sum every dot product in the same order and both are built without FMA contraction — on every fixture, both tanh
+modes, every slimmable width / container submodel, for ragged buffer sizes, and the committed golden vectors must
+be the reference's outputs. Skipped where neither /root/reference nor a prebuilt library exists."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, ROOT, model_path
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import nam_ref  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not nam_ref.available(), reason="reference sources / prebuilt oracle/_ref not available")
+
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(MODELS, "*.nam")))
+G = np.load(os.path.join(ROOT, "tests", "golden", "outputs.npz"))
+
+
+def _signal(in_ch, n, seed=7):
+    if in_ch == 1:
+        return G["input"][:n] if n <= len(G["input"]) else np.resize(G["input"], n)
+    return np.random.default_rng(seed).uniform(-0.5, 0.5, (in_ch, n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("fast_tanh", [False, True])
+def test_oracle_is_bit_exact_with_the_reference(oracle, name, fast_tanh):
+    ref = nam_ref.get_dsp(model_path(name), fast_tanh)
+    orc = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    assert (ref.NumInputChannels(), ref.NumOutputChannels()) == (orc.NumInputChannels(), orc.NumOutputChannels())
+    assert ref.GetPrewarmSamples() == orc.GetPrewarmSamples()
+    x = _signal(ref.NumInputChannels(), 640)
+    for block, n in ((64, 640), (37, 500), (256, 640)):  # Reset(…, block) fixes the prewarm length, then ragged calls
+        ref.Reset(48000.0, block)
+        orc.Reset(48000.0, block)
+        xs = x[..., :n]
+        np.testing.assert_array_equal(ref.process_stream(xs, block), orc.process_stream(xs, block))
+
+
+@pytest.mark.parametrize("name,ratios", [("slimmable_wavenet", (0.0, 0.34, 0.5, 0.67, 1.0)), ("A2", (0.0, 0.49, 0.5, 1.0)),
+                                          ("slimmable_container", (0.0, 0.32, 0.33, 0.5, 0.66, 0.9))])
+def test_slimmable_sizes_bit_exact(oracle, name, ratios):
+    x = _signal(1, 400)
+    for fast_tanh in (False, True):
+        ref = nam_ref.get_dsp(model_path(name), fast_tanh)
+        orc = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+        ref.Reset(48000.0, 64)
+        orc.Reset(48000.0, 64)
+        for r in ratios:  # switching an initialised model: the newly selected size is Reset + prewarmed
+            ref.SetSlimmableSize(r)
+            orc.SetSlimmableSize(r)
+            assert ref.GetPrewarmSamples() == orc.GetPrewarmSamples()
+            np.testing.assert_array_equal(ref.process_stream(x, 64), orc.process_stream(x, 64))
+
+
+@pytest.mark.parametrize("key", [k for k in G.files if "__ft" in k])
+def test_committed_goldens_are_the_reference_outputs(key):
+    name, ft = key.split("__ft")
+    ref = nam_ref.get_dsp(model_path(name), bool(int(ft)))
+    ref.Reset(48000.0, 64)
+    y = ref.process_stream(G["input"], 64)
+    # exact where no libm transcendental is involved; a couple of ulp of slack otherwise (golden files are
+    # generated on one glibc, replayed on another)
+    np.testing.assert_allclose(y, G[key], rtol=0, atol=2e-6 * max(1.0, float(np.max(np.abs(G[key])))))
+
+
+def test_reference_error_messages_match_the_loader(nam_lib, tmp_path):
+    """The product's loader reports what the reference's get_dsp reports for the same bad files."""
+    import json
+    with open(model_path("wavenet")) as f:
+        good = json.load(f)
+    cases = {}
+    bad = json.loads(json.dumps(good))
+    bad["weights"] = bad["weights"][:-3]
+    cases["short"] = bad
+    bad = json.loads(json.dumps(good))
+    bad["weights"] = bad["weights"] + [0.0, 0.0]
+    cases["long"] = bad
+    bad = json.loads(json.dumps(good))
+    bad["architecture"] = "Transformer"
+    cases["arch"] = bad
+    bad = json.loads(json.dumps(good))
+    bad["version"] = "0.4.0"
+    cases["version"] = bad
+    for tag, j in cases.items():
+        p = str(tmp_path / f"{tag}.nam")
+        with open(p, "w") as f:
+            json.dump(j, f)
+        with pytest.raises(RuntimeError) as ref_err:
+            nam_ref.get_dsp(p)
+        with pytest.raises(Exception) as our_err:
+            nam_lib.get_dsp(p)
+        assert str(ref_err.value) in str(our_err.value), (tag, str(ref_err.value), str(our_err.value))
