@@ -1314,10 +1314,13 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
             head = ((flags & CD_PREV_HALF) ? mfma_n<2>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f})
                                            : mfma_n<4>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}))
                    + O.ev;
-          // dilated conv: 3 taps x NK k-steps; tap 2 (current frame) multiplies the lane's own x. Three
-          // independent accumulator chains, interleaved so that no MFMA waits for its predecessor; the conv
-          // bias and the input mixin ride in as initial accumulators.
-          f4 acc0 = O.bv, acc1 = O.mv * cond, acc2 = {0.f, 0.f, 0.f, 0.f};
+          // dilated conv: 3 taps x NK k-steps. Tap 2 (the current frame) multiplies the lane's own x and needs
+          // nothing from LDS, so its chain goes first and covers the latency of the two shifted-tap reads; the
+          // conv bias and the input mixin ride in as initial accumulators. The next job's operands (its tiles
+          // were dropped one job ago) are requested behind the taps, in the shadow of the MFMAs.
+          if (!(NAM_WS_ABL & (16 | 128)))
+            load_ops(ops[u ^ 1], Dn, u ^ 1);
+          f4 acc0 = O.mv * cond, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = O.bv;
           if (NAM_WS_ABL & 8)
           {
             acc0 = bt0 * O.t[0] + x * O.t[2];
@@ -1327,15 +1330,14 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
           {
 #pragma unroll
             for (int s = 0; s < NK; s++)
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NK; s++)
             {
               acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
             }
           }
-          // in the shadow of the MFMAs: next job's operands (its tiles were dropped one job ago)
-          if (!(NAM_WS_ABL & (16 | 128)))
-            load_ops(ops[u ^ 1], Dn, u ^ 1);
           const f4 pre = (acc0 + acc1) + acc2;
           NAM_WS_STAMP(1, "v"(pre))
           if (flags & CD_LAYER)
@@ -1498,7 +1500,7 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
           ring_store<WT>(stb, __umul24(widx, (unsigned)J.q16max + 16u) + v_hq16 + (unsigned)J.ring_b, xin);
         }
         // successor's history and the tiles of the job after it -> LDS (the halves of the double buffers
-        // nobody reads during this job), then refill the slot
+        // nobody reads during this job), then refill the slot (the other order — refill first — measured 6 % slower)
         drop(slot[un], J, blk + 1, (q0 + u) & 1);
         {
           const bool valid = fblk < n_blocks;
