@@ -371,7 +371,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
                                          float* win, float* hbuf, const bool first, const float cond, const int wposv,
                                          const int lane, const int nvalid, const float act_p0)
 {
-  const int K = A->kernel, NL = A->n_layers, H = A->head_size, in_size = A->in_size, act = A->act;
+  const int NL = A->n_layers, H = A->head_size, in_size = A->in_size, act = A->act;
   const float* __restrict__ w = blob + A->w_base;
 
   float x[C], head[C];
@@ -390,48 +390,11 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
 #pragma unroll
   for (int c = 0; c < C; c++)
     head[c] = first ? 0.0f : hbuf[c * kBlock + lane];
-  w += in_size * C;
 
-  for (int l = 0; l < NL; l++)
-  {
-    const int d = A->dil[l];
-    const int R = A->ring_len[l];
-    const int rid = A->ring_id[l];
-    float* ring = st + A->ring_off[l];
-    const float* __restrict__ cw = w;
-    const float* __restrict__ cb = cw + K * C * C;
-    const float* __restrict__ mx = cb + C;
-    const float* __restrict__ w1 = mx + C;
-    const float* __restrict__ b1 = w1 + C * C;
-    w += A->layer_stride;
-
-    const int wp = rid >= 0 ? __builtin_amdgcn_readlane(wposv, rid) : 0;
-
-    // publish the layer input to the in-block window (LDS) and append it to the history ring (HBM)
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < C; c++)
-      win[c * kBlock + lane] = x[c];
-    if (rid >= 0)
-    {
-      int widx = wp + lane;
-      if (widx >= R)
-        widx -= R;
-      if (lane < nvalid)
-      {
-#pragma unroll
-        for (int c = 0; c < C; c++)
-          ring[(size_t)widx * C + c] = x[c];
-      }
-    }
-    __syncthreads();
-
-    float acc[C];
-#pragma unroll
-    for (int c = 0; c < C; c++)
-      acc[c] = 0.0f;
-
-    // taps k = 0 .. K-2 look back L = (K-1-k)*d frames
+  // taps k = 0 .. K-2 of a dilated causal conv over `cur` (this lane's frame, in registers; already published to
+  // LDS rows `lw` and appended to `ring`): acc[co] += sum_k sum_ci wk[k][ci][co] * in[ci][t - (K-1-k) d]
+  auto shifted_taps = [&](float (&acc)[C], const float* __restrict__ cw, int K, int d, const float* lw, const float* ring,
+                          int R, int wp) {
     for (int k = 0; k < K - 1; k++)
     {
       const int L = (K - 1 - k) * d;
@@ -459,7 +422,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
 #pragma unroll
         for (int c = 0; c < C; c++)
         {
-          const float xl = win[c * kBlock + lidx];
+          const float xl = lw[c * kBlock + lidx];
           const float xr = ring[(size_t)idx * C + c];
           xt[c] = in_block ? xl : xr;
         }
@@ -470,6 +433,51 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
         for (int co = 0; co < C; co++)
           acc[co] = fmaf(wk[ci * C + co], xt[ci], acc[co]);
     }
+  };
+  // publish this lane's frame of `v` to LDS rows `lw` and append it to the history ring
+  auto publish = [&](const float (&v)[C], float* lw, float* ring, int R, int wp, bool has_ring) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; c++)
+      lw[c * kBlock + lane] = v[c];
+    if (has_ring)
+    {
+      int widx = wp + lane;
+      if (widx >= R)
+        widx -= R;
+      if (lane < nvalid)
+      {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          ring[(size_t)widx * C + c] = v[c];
+      }
+    }
+    __syncthreads();
+  };
+
+  for (int l = 0; l < NL; l++)
+  {
+    const int K = A->ksize[l];
+    const int d = A->dil[l];
+    const int R = A->ring_len[l];
+    const int rid = A->ring_id[l];
+    float* ring = st + A->ring_off[l];
+    const float* __restrict__ cw = w + A->layer_off[l];
+    const float* __restrict__ cb = cw + K * C * C;
+    const float* __restrict__ mx = cb + C;
+    const float* __restrict__ w1 = mx + C;
+    const float* __restrict__ b1 = w1 + C * C;
+
+    const int wp = rid >= 0 ? __builtin_amdgcn_readlane(wposv, rid) : 0;
+
+    // publish the layer input to the in-block window (LDS) and append it to the history ring (HBM)
+    publish(x, win, ring, R, wp, rid >= 0);
+
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+      acc[c] = 0.0f;
+    shifted_taps(acc, cw, K, d, win, ring, R, wp);
     // tap K-1: the current frame, straight from registers
     {
       const float* __restrict__ wk = cw + (K - 1) * C * C;
@@ -483,7 +491,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
 #pragma unroll
     for (int c = 0; c < C; c++)
       acc[c] = fmaf(mx[c], cond, acc[c] + cb[c]);
-    a1_activate_rt<C>(acc, act, act_p0);
+    a1_activate_rt<C>(acc, act, A->act_p0);
     // head accumulate — model.cpp:513-531
 #pragma unroll
     for (int c = 0; c < C; c++)
@@ -503,21 +511,59 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
       x[c] = x[c] + (y[c] + b1[c]);
   }
 
-  // last-layer output for the next array (model.cpp:536-545) and head rechannel (K = 1) (model.cpp:547-548)
+  // head rechannel: a Conv1D over the head accumulator (model.cpp:399-400, 547-548). K = 1: a plain 1x1 into any
+  // number of output channels. K > 1 (A2: 16 taps): a single output channel (plan.cpp); the accumulator goes
+  // through hbuf / its own ring exactly like a layer input.
+  const int KH = A->head_k;
+  const float* __restrict__ wh = w + A->head_off;
+  const float* __restrict__ bh = wh + KH * C * H;
+  float hout0 = 0.0f;
+  if (KH > 1)
+  {
+    const int hrid = A->head_ring_id;
+    const int hwp = hrid >= 0 ? __builtin_amdgcn_readlane(wposv, hrid) : 0;
+    float* hring = st + A->head_ring_off;
+    publish(head, hbuf, hring, A->head_ring_len, hwp, hrid >= 0);
+    // with H == 1 the packed taps [k][c][1] are [k][c]: reuse the C-wide tap routine on a C x C view whose column 0
+    // is the real one would waste C x the FMAs; do the single output directly
+    float s = 0.0f;
+    for (int k = 0; k < KH; k++)
+    {
+      const int L = (KH - 1 - k) * A->head_dil;
+      const int tl = lane - L;
+      const bool in_block = tl >= 0;
+      int idx = hwp + tl;
+      if (idx < 0)
+        idx += A->head_ring_len;
+      if (in_block)
+        idx = 0;
+      const int lidx = in_block ? tl : 0;
+#pragma unroll
+      for (int c = 0; c < C; c++)
+      {
+        const float xl = hbuf[c * kBlock + lidx];
+        const float xr = (L > 0) ? hring[(size_t)idx * C + c] : 0.0f;
+        s = fmaf(wh[k * C + c], (in_block || L == 0) ? xl : xr, s);
+      }
+    }
+    hout0 = s + bh[0];
+  }
+  // last-layer output for the next array (model.cpp:536-545)
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < C; c++)
     win[c * kBlock + lane] = x[c];
-  const float* __restrict__ wh = w;
-  const float* __restrict__ bh = wh + C * H;
-  for (int h = 0; h < H; h++)
-  {
-    float s = 0.0f;
+  if (KH > 1)
+    hbuf[lane] = hout0;
+  else
+    for (int h = 0; h < H; h++)
+    {
+      float s = 0.0f;
 #pragma unroll
-    for (int c = 0; c < C; c++)
-      s = fmaf(wh[c * H + h], head[c], s);
-    hbuf[h * kBlock + lane] = s + bh[h];
-  }
+      for (int c = 0; c < C; c++)
+        s = fmaf(wh[c * H + h], head[c], s);
+      hbuf[h * kBlock + lane] = s + bh[h];
+    }
   __syncthreads();
 }
 

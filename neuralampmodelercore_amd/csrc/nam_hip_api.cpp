@@ -215,7 +215,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.out = d_out;
       a.io_stride = io_stride;
       a.n_frames = n_frames;
-      a.act_p0 = 0.01f;
+      a.act_p0 = p.a1.arr[0].act_p0; // uniform across arrays and layers for the A1 kernels (plan.cpp)
       a.dbg = b->dbg;
       a.n_rings = p.a1.n_rings;
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];

@@ -394,8 +394,11 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   for (size_t ai = 0; ai < wn.arrays.size(); ai++)
   {
     const LayerArraySpec& A = wn.arrays[ai];
-    if (A.channels % 4 != 0 || A.channels > 16 || A.kernel_sizes[0] != 3 || A.head_size > 16)
+    if (A.channels % 4 != 0 || A.channels > 16 || A.head_size > 16 || A.head_kernel_size != 1)
       return;
+    for (int k : A.kernel_sizes)
+      if (k != 3)
+        return;
     if (ai > 0 && (A.input_size % 4 != 0 || A.input_size > 16))
       return;
   }
@@ -642,7 +645,10 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
   {
     const LayerArraySpec& A = wn.arrays[ai];
     if (A.condition_size != 1 || A.groups_input != 1 || A.groups_input_mixin != 1 || !A.layer1x1_active
-        || A.layer1x1_groups != 1 || A.head1x1_active || A.bottleneck != A.channels || A.head_kernel_size != 1)
+        || A.layer1x1_groups != 1 || A.head1x1_active || A.bottleneck != A.channels)
+      return;
+    // a head rechannel with taps (A2: K = 16) is handled for a single output channel
+    if (A.head_kernel_size < 1 || A.head_kernel_size > 16 || (A.head_kernel_size > 1 && A.head_size != 1))
       return;
     if (!a1_channel_supported(A.channels) || A.num_layers() < 1 || A.num_layers() > kA1MaxLayers)
       return;
@@ -653,8 +659,7 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
         return;
     for (int l = 0; l < A.num_layers(); l++)
     {
-      if (A.gating_modes[l] != GATING_NONE || A.kernel_sizes[l] != A.kernel_sizes[0] || A.kernel_sizes[l] < 1
-          || A.kernel_sizes[l] > 8)
+      if (A.gating_modes[l] != GATING_NONE || A.kernel_sizes[l] < 1 || A.kernel_sizes[l] > 16)
         return;
       const ActSpec& a = A.activations[l];
       const ActSpec& a0 = A.activations[0];
@@ -672,27 +677,53 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
     const LayerArraySpec& A = wn.arrays[ai];
     A1Array& out = a1.arr[ai];
     std::memset(&out, 0, sizeof(out));
-    const int C = A.channels, K = A.kernel_sizes[0], H = A.head_size;
+    const int C = A.channels, H = A.head_size, KH = A.head_kernel_size;
     out.in_size = A.input_size;
     out.channels = C;
-    out.kernel = K;
+    out.kernel = A.kernel_sizes[0];
     out.n_layers = A.num_layers();
     out.head_size = H;
     out.act = A.activations[0].type;
-    out.layer_stride = K * C * C + C + C + C * C + C;
-    const size_t total = (size_t)A.input_size * C + (size_t)out.n_layers * out.layer_stride + (size_t)C * H + H + 1;
+    out.act_p0 = A.activations[0].p[0];
+    size_t total = (size_t)A.input_size * C;
+    for (int l = 0; l < out.n_layers; l++)
+      total += (size_t)A.kernel_sizes[l] * C * C + C + C + (size_t)C * C + C;
+    out.layer_stride = 0; // per-layer kernel sizes: see layer_off
+    total += (size_t)KH * C * H + H + 1;
     while (plan.blob.size() % 16)
       plan.blob.push_back(0.0f);
     out.w_base = (int)plan.blob.size();
     plan.blob.resize(plan.blob.size() + total + 16, 0.0f);
-    float* dst = plan.blob.data() + out.w_base;
+    float* const base = plan.blob.data() + out.w_base;
+    float* dst = base;
     // rechannel: stream [co][ci] -> packed [ci][co]
     for (int co = 0; co < C; co++)
       for (int ci = 0; ci < A.input_size; ci++)
         dst[(size_t)ci * C + co] = *(w++);
     dst += (size_t)A.input_size * C;
+    auto add_ring = [&](int lookback, int& off, int& len, int& id) {
+      if (lookback > 0)
+      {
+        len = lookback + kBlock;
+        off = state_off;
+        id = ring_id;
+        if (ring_id < 64)
+          a1.ring_len_by_id[ring_id] = len;
+        ring_id++;
+        state_off += C * len;
+      }
+      else
+      {
+        len = 0;
+        off = 0;
+        id = -1;
+      }
+    };
     for (int l = 0; l < out.n_layers; l++)
     {
+      const int K = A.kernel_sizes[l];
+      out.ksize[l] = K;
+      out.layer_off[l] = (int)(dst - base);
       float* cw = dst;
       for (int co = 0; co < C; co++)
         for (int ci = 0; ci < C; ci++)
@@ -711,33 +742,22 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
       float* b1 = w1 + (size_t)C * C;
       for (int co = 0; co < C; co++)
         b1[co] = *(w++);
-      dst += out.layer_stride;
+      dst = b1 + C;
       out.dil[l] = A.dilations[l];
-      const int lookback = (K - 1) * A.dilations[l];
-      if (lookback > 0)
-      {
-        out.ring_len[l] = lookback + kBlock;
-        out.ring_off[l] = state_off;
-        out.ring_id[l] = ring_id;
-        if (ring_id < 64)
-          a1.ring_len_by_id[ring_id] = out.ring_len[l];
-        ring_id++;
-        state_off += C * out.ring_len[l];
-      }
-      else
-      {
-        out.ring_len[l] = 0;
-        out.ring_off[l] = 0;
-        out.ring_id[l] = -1;
-      }
+      add_ring((K - 1) * A.dilations[l], out.ring_off[l], out.ring_len[l], out.ring_id[l]);
     }
-    // head rechannel: stream [h][c] (+ bias[h]) -> packed [c][h], bias[h]
+    // head rechannel (a Conv1D, model.cpp:399-400): stream [h][c][k] (+ bias[h]) -> packed [k][c][h], bias[h]
+    out.head_k = KH;
+    out.head_dil = A.head_dilation;
+    out.head_off = (int)(dst - base);
     for (int h = 0; h < H; h++)
       for (int c = 0; c < C; c++)
-        dst[(size_t)c * H + h] = *(w++);
-    float* hb = dst + (size_t)C * H;
+        for (int k = 0; k < KH; k++)
+          dst[((size_t)k * C + c) * H + h] = *(w++);
+    float* hb = dst + (size_t)KH * C * H;
     for (int h = 0; h < H; h++)
       hb[h] = A.head_bias ? *(w++) : 0.0f;
+    add_ring((KH - 1) * A.head_dilation, out.head_ring_off, out.head_ring_len, out.head_ring_id);
   }
   a1.n_arrays = (int)wn.arrays.size();
   a1.n_rings = ring_id;
@@ -792,6 +812,9 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
       for (int l = 0; l < plan.a1.arr[a].n_layers; l++)
         if (plan.a1.arr[a].ring_id[l] >= 0)
           plan.a1.arr[a].ring_off[l] += table;
+    for (int a = 0; a < plan.a1.n_arrays; a++)
+      if (plan.a1.arr[a].head_ring_id >= 0)
+        plan.a1.arr[a].head_ring_off += table;
     for (int j = 0; j < plan.a1.ws_jobs; j++)
     {
       // (an idle job has ring_b == 0 and never appends; its prefetch geometry points at the table, harmless)

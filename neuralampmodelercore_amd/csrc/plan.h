@@ -66,9 +66,9 @@ static_assert(sizeof(NamOp) == 64, "NamOp must stay 64 bytes");
 // ---- A1-family fast path -------------------------------------------------------------------
 // Per layer-array description for the specialised kernel; weights live in `blob` at `w_base`:
 //   rechannel  [in_size][C]                           (no bias)
-//   per layer: conv W [K][C][C] (tap-major, ci, co), conv bias [C], mixin [C], W1x1 [C][C] (ci, co),
+//   per layer: conv W [K_l][C][C] (tap-major, ci, co), conv bias [C], mixin [C], W1x1 [C][C] (ci, co),
 //              b1x1 [C]
-//   head rechannel [C][H] (ci, co), head bias [H] (zeros if absent)
+//   head rechannel [K_h][C][H] (tap-major, ci, co), head bias [H] (zeros if absent)
 constexpr int kA1MaxArrays = 4;
 constexpr int kA1MaxLayers = 32;
 
@@ -87,6 +87,15 @@ struct A1Array
   int32_t ring_off[kA1MaxLayers]; // float offset (from stream state base) of each layer's ring
   int32_t ring_len[kA1MaxLayers]; // R = (K-1)*d + 64
   int32_t ring_id[kA1MaxLayers];
+  // per-layer kernel sizes (A2 mixes K = 6 and 15) and where each layer's packed weights start (floats from w_base)
+  int32_t ksize[kA1MaxLayers];
+  int32_t layer_off[kA1MaxLayers];
+  // head rechannel = Conv1D(K = head_k, dilation head_dil) over the head accumulator: packed [k][c][h] at head_off
+  // (floats from w_base), bias [H] behind it; with head_k > 1 it has its own history ring (A2: K = 16)
+  int32_t head_k, head_dil, head_off;
+  int32_t head_ring_off, head_ring_len, head_ring_id; // id -1: no ring
+  float act_p0; // first activation parameter (LeakyReLU slope)
+  int32_t pad0;
 };
 
 // LDS geometry of nam_a1_mfma_kernel's history buffers (shared with the host, which precomputes every

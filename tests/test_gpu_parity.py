@@ -122,7 +122,7 @@ def test_block_partition_independence(nam_lib):
 def test_generic_and_a1_kernels_agree(nam_lib):
     nam = nam_lib
     x = stream_bank(4, 64 * 5, seed=9)
-    for name in ("wavenet", "wavenet_a1_standard", "slimmable_wavenet"):
+    for name in ("wavenet", "wavenet_a1_standard", "slimmable_wavenet", "A2"):  # A2: K = 6 / 15 taps, head K = 16
         model = nam.get_dsp(model_path(name), fast_tanh=True)
         assert model.info.has_a1_kernel & 1
         ys = []
