@@ -395,43 +395,44 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
   // LDS rows `lw` and appended to `ring`): acc[co] += sum_k sum_ci wk[k][ci][co] * in[ci][t - (K-1-k) d]
   auto shifted_taps = [&](float (&acc)[C], const float* __restrict__ cw, int K, int d, const float* lw, const float* ring,
                           int R, int wp) {
-    for (int k = 0; k < K - 1; k++)
+    // kTapChunk taps at a time: every load of the chunk (ring rows in HBM / L2, window rows in LDS) is issued
+    // before the first FMA needs one, so a chunk costs one memory round trip instead of one per tap
+    constexpr int kTapChunk = 4;
+    for (int k0 = 0; k0 < K - 1; k0 += kTapChunk)
     {
-      const int L = (K - 1 - k) * d;
-      const float* __restrict__ wk = cw + k * C * C;
-      float xt[C];
-      if (L >= kBlock)
-      {
-        int idx = wp + lane - L;
-        if (idx < 0)
-          idx += R;
+      float xt[kTapChunk][C];
 #pragma unroll
-        for (int c = 0; c < C; c++)
-          xt[c] = ring[(size_t)idx * C + c];
-      }
-      else
+      for (int u = 0; u < kTapChunk; u++)
       {
+        const int k = min(k0 + u, K - 2);
+        const int L = (K - 1 - k) * d;
         const int tl = lane - L;
         const bool in_block = tl >= 0;
         int idx = wp + tl;
         if (idx < 0)
           idx += R;
         if (in_block)
-          idx = 0;
+          idx = 0; // keep the masked-off address in range
         const int lidx = in_block ? tl : 0;
 #pragma unroll
         for (int c = 0; c < C; c++)
         {
           const float xl = lw[c * kBlock + lidx];
           const float xr = ring[(size_t)idx * C + c];
-          xt[c] = in_block ? xl : xr;
+          xt[u][c] = in_block ? xl : xr;
         }
       }
 #pragma unroll
-      for (int ci = 0; ci < C; ci++)
+      for (int u = 0; u < kTapChunk; u++)
+        if (k0 + u < K - 1)
+        {
+          const float* __restrict__ wk = cw + (k0 + u) * C * C;
 #pragma unroll
-        for (int co = 0; co < C; co++)
-          acc[co] = fmaf(wk[ci * C + co], xt[ci], acc[co]);
+          for (int ci = 0; ci < C; ci++)
+#pragma unroll
+            for (int co = 0; co < C; co++)
+              acc[co] = fmaf(wk[ci * C + co], xt[u][ci], acc[co]);
+        }
     }
   };
   // publish this lane's frame of `v` to LDS rows `lw` and append it to the history ring

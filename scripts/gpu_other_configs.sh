@@ -16,3 +16,5 @@ for l in block resident; do
   run --model A2 --streams 256 --launch $l --steps 300 --warmup 30
   run --model A2 --streams 2048 --launch $l --steps 100 --warmup 10
 done
+run --model wavenet_a1_standard --streams 256 --kernel a1 --launch block --steps 500 --warmup 50
+run --model wavenet_a1_standard --streams 4096 --kernel a1 --launch resident --steps 100 --warmup 10
