@@ -154,8 +154,9 @@ NAM_HIP_API int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel);
 NAM_HIP_API int nam_hip_batch_get_kernel(const nam_hip_batch* batch);
 NAM_HIP_API int nam_hip_batch_n_streams(const nam_hip_batch* batch);
 
-/* Developer tool, not part of the drop-in surface: runs n_frames of silence with the MFMA kernel's
- * per-job phase timestamps enabled; out_stamps receives 96 x 8 int64 shader-clock stamps. */
+/* Developer tool, not part of the drop-in surface: runs n_frames of silence through the MFMA kernel's profiling
+ * instantiation; out_stamps (96 x 8 int64) receives, per wavefront w of workgroup 0 (row w): barrier cycles, total
+ * cycles, and for compute waves five per-job segment sums (tools/mfma_barrier_profile.py). */
 NAM_HIP_API int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* out_stamps);
 
 /* Library identification: "nam_hip <version> gfx950". */

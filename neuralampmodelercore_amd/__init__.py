@@ -256,7 +256,8 @@ class Batch:
         _check(self._L.nam_hip_batch_synchronize(self._h))
 
     def debug_timeline(self, n_frames: int) -> np.ndarray:
-        """Developer tool: [96, 8] shader-clock stamps of workgroup 0's first 96 jobs (MFMA kernel)."""
+        """Developer tool: [96, 8] int64; row w = wavefront w of workgroup 0 of the MFMA kernel's profiling build:
+        barrier cycles, total cycles, then (compute waves) five per-job segment sums."""
         out = np.zeros((96, 8), dtype=np.int64)
         _check(self._L.nam_hip_batch_debug_timeline(self._h, int(n_frames), out.ctypes.data_as(ctypes.c_void_p)))
         return out

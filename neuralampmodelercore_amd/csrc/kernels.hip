@@ -1193,9 +1193,6 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream)
 // fill the issue slots the compute wave leaves between dependent MFMA / VALU instructions.
 // Rechannel and head-rechannel steps ride on the neighbouring layer jobs (plan.h: CDesc / VDesc).
 // ================================================================================================
-#ifndef NAM_WS_ABL
-#define NAM_WS_ABL 0
-#endif
 namespace ws
 {
 using mf::f4;
@@ -1328,28 +1325,27 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
         const int flags = active ? J.flags : 0;
         const Ops& O = ops[u];
         job_barrier();
+        if constexpr (PROF)
+          t_seg = __builtin_readcyclecounter();
         const float cond = *reinterpret_cast<const float*>(lds + (v_cond + (unsigned)(blk & 1) * (kBlock * 4u)));
         // everything between the barrier and the publish, for NK k-steps per matrix (4: full layout, 2: half)
         auto job_body = [&](auto nk_tag) {
           constexpr int NK = decltype(nk_tag)::value;
           // critical-path operand reads: the two shifted taps. Full layout: the lane's channel quad (16 B);
           // half layout: the two channels this lane feeds to the MFMAs (8 B).
-          f4 bt0 = x, bt1 = x;
-          if (!(NAM_WS_ABL & 32))
+          f4 bt0, bt1;
+          if constexpr (NK == 4)
           {
-            if constexpr (NK == 4)
-            {
-              const unsigned a_tap = v_tap + min(v_g16, (unsigned)(J.gp & 0xff));
-              bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
-              bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
-            }
-            else
-            {
-              const f2 p0 = *reinterpret_cast<const f2*>(lds + (v_tap + v_gh8 + (unsigned)J.tap0_b));
-              const f2 p1 = *reinterpret_cast<const f2*>(lds + (v_tap + v_gh8 + (unsigned)J.tap1_b));
-              bt0 = f4{p0[0], p0[1], 0.f, 0.f};
-              bt1 = f4{p1[0], p1[1], 0.f, 0.f};
-            }
+            const unsigned a_tap = v_tap + min(v_g16, (unsigned)(J.gp & 0xff));
+            bt0 = lds_ld4(lds, a_tap + (unsigned)J.tap0_b);
+            bt1 = lds_ld4(lds, a_tap + (unsigned)J.tap1_b);
+          }
+          else
+          {
+            const f2 p0 = *reinterpret_cast<const f2*>(lds + (v_tap + v_gh8 + (unsigned)J.tap0_b));
+            const f2 p1 = *reinterpret_cast<const f2*>(lds + (v_tap + v_gh8 + (unsigned)J.tap1_b));
+            bt0 = f4{p0[0], p0[1], 0.f, 0.f};
+            bt1 = f4{p1[0], p1[1], 0.f, 0.f};
           }
           NAM_WS_STAMP(0, "v"(bt0), "v"(bt1), "v"(cond))
           if (flags & CD_X0)
@@ -1365,44 +1361,30 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
           // nothing from LDS, so its chain goes first and covers the latency of the two shifted-tap reads; the
           // conv bias and the input mixin ride in as initial accumulators. The next job's operands (its tiles
           // were dropped one job ago) are requested behind the taps, in the shadow of the MFMAs.
-          if (!(NAM_WS_ABL & (16 | 128)))
-            load_ops(ops[u ^ 1], Dn, u ^ 1);
+          load_ops(ops[u ^ 1], Dn, u ^ 1);
           f4 acc0 = O.mv * cond, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = O.bv;
-          if (NAM_WS_ABL & 8)
-          {
-            acc0 = bt0 * O.t[0] + x * O.t[2];
-            acc1 = bt1 * O.t[1];
-          }
-          else
-          {
 #pragma unroll
-            for (int s = 0; s < NK; s++)
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
+          for (int s = 0; s < NK; s++)
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < NK; s++)
-            {
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
-            }
+          for (int s = 0; s < NK; s++)
+          {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
           }
           const f4 pre = (acc0 + acc1) + acc2;
           NAM_WS_STAMP(1, "v"(pre))
           if (flags & CD_LAYER)
           {
-            const f4 z = (NAM_WS_ABL & 4) ? pre : act4<ACT_T>(J.act, pre, act_p0);
+            const f4 z = act4<ACT_T>(J.act, pre, act_p0);
             head += z;
             // layer1x1 as two chains; the residual and the 1x1 bias are the initial accumulator
             f4 y0 = x + O.b1v, y1 = {0.f, 0.f, 0.f, 0.f};
-            if (NAM_WS_ABL & 64)
-              y0 += z * O.t[3];
-            else
-            {
 #pragma unroll
-              for (int s = 0; s < NK; s += 2)
-              {
-                y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s], z[s], y0, 0, 0, 0);
-                y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s + 1], z[s + 1], y1, 0, 0, 0);
-              }
+            for (int s = 0; s < NK; s += 2)
+            {
+              y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s], z[s], y0, 0, 0, 0);
+              y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s + 1], z[s + 1], y1, 0, 0, 0);
             }
             x = y0 + y1;
             NAM_WS_STAMP(2, "v"(x))
@@ -1425,8 +1407,6 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
           job_body(std::integral_constant<int, 2>{});
         else
           job_body(std::integral_constant<int, 4>{});
-        if (NAM_WS_ABL & 128)
-          load_ops(ops[u ^ 1], Dn, u ^ 1);
         NAM_WS_STAMP(3, "v"(x))
         if (active && ++ji == NJ)
         {
@@ -1457,8 +1437,6 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
     // history of one job + the tiles of job `tjob`
     auto fetch = [&](HSlot& s, int f_rbase, int f_R, int f_LA, int f_LB, int f_ring_id, int f_q16max, bool next_block,
                      int jblk, int tjob) {
-      if (NAM_WS_ABL & 1)
-        return;
       int wp = __builtin_amdgcn_readlane(wposv, f_ring_id);
       if (next_block)
       {
@@ -1489,8 +1467,6 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
     };
     // drop a job's history (+ the following job's tiles) into LDS; for a block's first job also x0 and the inputs
     auto drop = [&](const HSlot& s, const VDesc& J, int succ_blk, int tbuf) {
-      if (NAM_WS_ABL & 2)
-        return;
       lds_st4(lds, v_hist + (unsigned)J.st_a_b, s.h[0]);
       if (J.flags & MV_SUCC_B)
         lds_st4(lds, v_hist + (unsigned)J.st_b_b, s.h[1]);
@@ -1539,7 +1515,7 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
         const int un = (u + 1) % D;
         job_barrier();
         // this job's input rows (published by the previous job / dropped as x0) -> history ring
-        if (!(NAM_WS_ABL & 2) && (flags & MV_RING) && hfr < nvalid && v_hq16 <= (unsigned)J.q16max)
+        if ((flags & MV_RING) && hfr < nvalid && v_hq16 <= (unsigned)J.q16max)
         {
           const f4 xin = lds_ld4(lds, v_hist + (unsigned)J.ap_src_b);
           const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + hfr);

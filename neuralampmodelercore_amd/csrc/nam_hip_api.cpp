@@ -113,7 +113,7 @@ struct nam_hip_batch
   float* d_out = nullptr;
   float* h_stage = nullptr; // pinned, used by the f64 path
   int kernel = NAM_HIP_KERNEL_AUTO;
-  long long* dbg = nullptr; // device buffer for kernel phase timestamps (nam_hip_batch_debug_timeline)
+  long long* dbg = nullptr; // device buffer of the profiling instantiation (nam_hip_batch_debug_timeline)
   bool was_reset = false;
   bool reset_with_prewarm = true; // thread_local gPrewarmOnResetDefault = true (NAM/dsp.cpp:20)
 };
@@ -782,9 +782,8 @@ int nam_hip_batch_get_kernel(const nam_hip_batch* batch)
   return pick_kernel(batch, g);
 }
 
-// Developer tool (not part of the drop-in surface): run `n_frames` of silence through the batch with
-// the MFMA kernel's phase timestamps enabled and copy out 96 jobs x 8 cycle-counter stamps of
-// workgroup 0 / lane 0.
+// Developer tool (not part of the drop-in surface): run `n_frames` of silence through the MFMA kernel's
+// profiling instantiation and copy out its per-wavefront counters (include/nam_hip.h).
 int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* out_stamps)
 {
   if (!batch || !out_stamps)
