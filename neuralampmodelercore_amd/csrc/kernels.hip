@@ -1322,15 +1322,18 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
         const bool active = q0 + u < total;
         const CDesc J = Dn;
         Dn = P->cdesc[ji + 1 == NJ ? 0 : ji + 1];
-        const int flags = active ? J.flags : 0;
+        const int flags_rt = active ? J.flags : 0;
         const Ops& O = ops[u];
         job_barrier();
         if constexpr (PROF)
           t_seg = __builtin_readcyclecounter();
         const float cond = *reinterpret_cast<const float*>(lds + (v_cond + (unsigned)(blk & 1) * (kBlock * 4u)));
         // everything between the barrier and the publish, for NK k-steps per matrix (4: full layout, 2: half)
-        auto job_body = [&](auto nk_tag) {
+        // PLAIN: an ordinary layer (no array entry / exit work): the flag tests below fold away at compile time
+        auto job_body = [&](auto nk_tag, auto plain_tag) {
           constexpr int NK = decltype(nk_tag)::value;
+          constexpr bool PLAIN = decltype(plain_tag)::value;
+          const int flags = PLAIN ? (int)CD_LAYER : flags_rt;
           // critical-path operand reads: the two shifted taps. Full layout: the lane's channel quad (16 B);
           // half layout: the two channels this lane feeds to the MFMAs (8 B).
           f4 bt0, bt1;
@@ -1403,10 +1406,21 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
             }
           }
         };
-        if (flags & CD_HALF)
-          job_body(std::integral_constant<int, 2>{});
+        const bool plain = (flags_rt & ~CD_HALF) == CD_LAYER;
+        if (flags_rt & CD_HALF)
+        {
+          if (plain)
+            job_body(std::integral_constant<int, 2>{}, std::true_type{});
+          else
+            job_body(std::integral_constant<int, 2>{}, std::false_type{});
+        }
         else
-          job_body(std::integral_constant<int, 4>{});
+        {
+          if (plain)
+            job_body(std::integral_constant<int, 4>{}, std::true_type{});
+          else
+            job_body(std::integral_constant<int, 4>{}, std::false_type{});
+        }
         NAM_WS_STAMP(3, "v"(x))
         if (active && ++ji == NJ)
         {
