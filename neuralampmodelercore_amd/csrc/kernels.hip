@@ -662,6 +662,11 @@ __device__ __forceinline__ float sigmoid_hw(float x)
 {
   return rcp(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+// fast_sigmoid of the reference's LSTM (lstm.cpp:48-58: 0.5 (fast_tanh(x / 2) + 1)) on the hardware rcp
+__device__ __forceinline__ float fast_sigmoid_hw(const float x)
+{
+  return 0.5f * (fast_tanh_hw(x * 0.5f) + 1.0f);
+}
 __device__ __forceinline__ float act_hw(int type, float x, float p0)
 {
   switch (type)
@@ -951,13 +956,13 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_kernel(const float* __restri
           float cn, hn;
           if (a.fast)
           {
-            cn = d_fast_sigmoid(acc[1]) * cprev + d_fast_sigmoid(acc[0]) * d_fast_tanh(acc[2]);
-            hn = d_fast_sigmoid(acc[3]) * d_fast_tanh(cn);
+            cn = mf::fast_sigmoid_hw(acc[1]) * cprev + mf::fast_sigmoid_hw(acc[0]) * mf::fast_tanh_hw(acc[2]);
+            hn = mf::fast_sigmoid_hw(acc[3]) * mf::fast_tanh_hw(cn);
           }
           else
           {
-            cn = d_sigmoid(acc[1]) * cprev + d_sigmoid(acc[0]) * tanhf(acc[2]);
-            hn = d_sigmoid(acc[3]) * tanhf(cn);
+            cn = mf::sigmoid_hw(acc[1]) * cprev + mf::sigmoid_hw(acc[0]) * mf::tanh_hw(acc[2]);
+            hn = mf::sigmoid_hw(acc[3]) * mf::tanh_hw(cn);
           }
           cbuf[(l * 4 * NT + u) * 16 + j] = cn;
           hcur[(l * 4 * NT + u) * 16 + j] = hn;
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_kernel(const float* __restri
     }
 }
 
-// The same kernel for small models (<= 2 layers, <= 16 hidden units, <= 4 inputs), fully unrolled: every A
+// The same kernel for small models (<= 2 layers, <= 24 hidden units, <= 4 inputs), fully unrolled: every A
 // tile value, bias, h and c of the lane stays in registers for the whole launch; per sample only the input is
 // read from LDS and the output written to it. lstm.nam: ~0.2 us per sample step instead of ~0.9.
 template <int NL, int NT>
@@ -1075,31 +1080,44 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
 #pragma unroll
       for (int l = 0; l < NL; l++)
       {
+        // the NT unit tiles of a layer are independent: their MFMA chains are issued interleaved (k-step outer,
+        // tile inner) so no MFMA waits on its predecessor, then the gate math of all tiles follows
+        f4 acc[NT];
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+          acc[T] = bias[l][T];
+        if (l == 0)
+        {
+#pragma unroll
+          for (int T = 0; T < NT; T++)
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], x0, acc[T], 0, 0, 0);
+        }
+        else
+        {
+#pragma unroll
+          for (int s = 0; s < NT; s++)
+#pragma unroll
+            for (int T = 0; T < NT; T++)
+              acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[l][T][s], hn[l > 0 ? l - 1 : 0][s], acc[T], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < NT; s++)
+#pragma unroll
+          for (int T = 0; T < NT; T++)
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l][T][s], h[l][s], acc[T], 0, 0, 0);
 #pragma unroll
         for (int T = 0; T < NT; T++)
         {
-          f4 acc = bias[l][T];
-          if (l == 0)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], x0, acc, 0, 0, 0);
-          else
-          {
-#pragma unroll
-            for (int s = 0; s < NT; s++)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[l][T][s], hn[l > 0 ? l - 1 : 0][s], acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int s = 0; s < NT; s++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l][T][s], h[l][s], acc, 0, 0, 0);
           float cn, hv;
           if (fast)
           {
-            cn = d_fast_sigmoid(acc[1]) * c[l][T] + d_fast_sigmoid(acc[0]) * d_fast_tanh(acc[2]);
-            hv = d_fast_sigmoid(acc[3]) * d_fast_tanh(cn);
+            cn = mf::fast_sigmoid_hw(acc[T][1]) * c[l][T] + mf::fast_sigmoid_hw(acc[T][0]) * mf::fast_tanh_hw(acc[T][2]);
+            hv = mf::fast_sigmoid_hw(acc[T][3]) * mf::fast_tanh_hw(cn);
           }
           else
           {
-            cn = d_sigmoid(acc[1]) * c[l][T] + d_sigmoid(acc[0]) * tanhf(acc[2]);
-            hv = d_sigmoid(acc[3]) * tanhf(cn);
+            cn = mf::sigmoid_hw(acc[T][1]) * c[l][T] + mf::sigmoid_hw(acc[T][0]) * mf::tanh_hw(acc[T][2]);
+            hv = mf::sigmoid_hw(acc[T][3]) * mf::tanh_hw(cn);
           }
           c[l][T] = cn;
           hn[l][T] = hv;
@@ -1655,7 +1673,7 @@ hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
   }
   const int n_blocks = (a.n_streams + 15) / 16;
   // small models: everything in registers (only the I/O tiles in LDS)
-  if (a.input_size <= 4 && a.n_layers <= 2 && a.mf_nt <= 4)
+  if (a.input_size <= 4 && a.n_layers <= 2 && a.mf_nt <= 6)
   {
     const int io_bytes = (a.in_ch + a.out_ch) * 16 * 65 * (int)sizeof(float);
 #define NAM_LSTM_REG(NL, NT) \
@@ -1670,7 +1688,11 @@ hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
       case 21: NAM_LSTM_REG(2, 1); break;
       case 22: NAM_LSTM_REG(2, 2); break;
       case 23: NAM_LSTM_REG(2, 3); break;
-      default: NAM_LSTM_REG(2, 4); break;
+      case 24: NAM_LSTM_REG(2, 4); break;
+      case 15: NAM_LSTM_REG(1, 5); break;
+      case 16: NAM_LSTM_REG(1, 6); break;
+      case 25: NAM_LSTM_REG(2, 5); break;
+      default: NAM_LSTM_REG(2, 6); break;
     }
 #undef NAM_LSTM_REG
     return hipGetLastError();
