@@ -496,3 +496,52 @@ def test_device_matches_the_reference_library(nam_lib):
             r = ref.process_stream(x[s], 64)
             assert float(np.max(np.abs(r - y[s]))) <= _tol(ft) * max(1.0, float(np.max(np.abs(r)))), (name, ft, s)
         b.close()
+
+
+def test_edge_cases_of_the_abi(nam_lib, oracle):
+    """Empty calls, big buffers, repeated resets, two batches on one model, many streams, zero-length signals."""
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    x = stream_bank(2, 4096, seed=91)
+    # (a) zero frames is a no-op; max_frames 4096 in one call == 64-frame calls (prewarm lengths differ, the
+    #     silence steady state does not)
+    b = model.batch(2, 4096)
+    b.Reset(prewarm=True)
+    assert b.process(x[:, :0]).shape == (2, 1, 0)
+    y_big = b.process(x)
+    # (b) a second batch on the same model is independent of the first
+    b2 = model.batch(2, 64)
+    b2.Reset(prewarm=True)
+    y_small = b2.process_stream(x, 64)
+    assert float(np.max(np.abs(y_big - y_small))) <= 1e-5
+    # (c) Reset again restores the same start state; Reset without prewarm starts from silence-free zero state
+    b2.Reset(prewarm=True)
+    np.testing.assert_array_equal(b2.process_stream(x[:, :256], 64), y_small[:, :, :256])
+    b2.Reset(prewarm=False)
+    y_np = b2.process_stream(x[:, :256], 64)
+    ref = oracle.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    ref.Reset(48000.0, 64, prewarm=False)
+    assert float(np.max(np.abs(ref.process_stream(x[0, :256], 64) - y_np[0]))) <= 5e-5
+    b.close()
+    b2.close()
+    # (d) more streams than CUs x 16, odd count, tiny model on every kernel family
+    for name in ("wavenet", "lstm", "synth_a1_c8"):
+        m = nam.get_dsp(model_path(name), fast_tanh=True)
+        n = 5003
+        xs = stream_bank(n, 130, seed=92)
+        bb = m.batch(n, 64)
+        bb.Reset(prewarm=True)
+        ys = bb.process_stream(xs, 64)
+        for s in (0, 2501, n - 1):
+            r = _oracle_run(oracle, name, xs[s], 64, True)
+            assert float(np.max(np.abs(r - ys[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), (name, s)
+        bb.close()
+    # (e) render: a zero-length signal next to real ones
+    m = nam.get_dsp(model_path("wavenet"), fast_tanh=False)
+    bb = m.batch(3, 64)
+    bb.Reset(prewarm=True)
+    outs = bb.render([x[0, :100], x[0, :0], x[1, :7]])
+    assert [o.shape for o in outs] == [(1, 100), (1, 0), (1, 7)]
+    r = _oracle_run(oracle, "wavenet", x[1, :7], 64, False)
+    assert float(np.max(np.abs(r - outs[2]))) <= 1e-4
+    bb.close()
