@@ -1327,7 +1327,10 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
     f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f};
     int ji = 0, blk = 0;
     int nvalid = min(kBlock, a.n_frames);
+    // descriptors: J (this job) <- Dn (next job: its operands are prefetched during this job) <- Dnn (the job after,
+    // scalar-loaded in the shadow of this job's MFMAs so that no barrier's lgkmcnt(0) ever waits for it)
     CDesc Dn = P->cdesc[0];
+    CDesc Dnn = P->cdesc[1];
     Ops ops[2];
     job_barrier(); // prologue barrier: consts, extra tiles, job 0's tiles / history / x0 are in LDS
     load_ops(ops[0], Dn, 0);
@@ -1339,7 +1342,7 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
       {
         const bool active = q0 + u < total;
         const CDesc J = Dn;
-        Dn = P->cdesc[ji + 1 == NJ ? 0 : ji + 1];
+        Dn = Dnn;
         const int flags_rt = active ? J.flags : 0;
         const Ops& O = ops[u];
         job_barrier();
@@ -1383,6 +1386,12 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
           // conv bias and the input mixin ride in as initial accumulators. The next job's operands (its tiles
           // were dropped one job ago) are requested behind the taps, in the shadow of the MFMAs.
           load_ops(ops[u ^ 1], Dn, u ^ 1);
+          {
+            int jn = ji + 2;
+            if (jn >= NJ)
+              jn -= NJ;
+            Dnn = P->cdesc[jn];
+          }
           f4 acc0 = O.mv * cond, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = O.bv;
 #pragma unroll
           for (int s = 0; s < NK; s++)
@@ -1542,10 +1551,10 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
       {
         const bool active = q0 + u < total;
         const VDesc J = Dn;
-        Dn = P->vdesc[ji + 1 == NJ ? 0 : ji + 1];
         const int flags = active ? J.flags : 0;
         const int un = (u + 1) % D;
         job_barrier();
+        Dn = P->vdesc[ji + 1 == NJ ? 0 : ji + 1]; // after the barrier: its lgkmcnt(0) must not wait for this load
         // this job's input rows (published by the previous job / dropped as x0) -> history ring
         if ((flags & MV_RING) && hfr < nvalid && v_hq16 <= (unsigned)J.q16max)
         {
