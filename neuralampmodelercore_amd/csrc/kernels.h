@@ -25,6 +25,10 @@ struct GenericArgs
   long io_stride;
   int n_frames;
   int in_ch, out_ch;
+  // weights in LDS: the first blob_floats floats of the blob are copied behind the activation rows (float offset
+  // w_lds_off) once per launch and conv weights are read from there (broadcast ds_reads: ~64 cycles, pipelined in
+  // order) instead of through scalar loads (~200+ cycles each, not pipelinable across uses); 0 = keep scalar loads
+  int w_lds_off, blob_floats;
 };
 
 struct A1Args

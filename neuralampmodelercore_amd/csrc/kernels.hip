@@ -118,12 +118,14 @@ __device__ __forceinline__ int uni(int v)
 // ------------------------------------------------------------------------------------------------
 // Generic interpreter
 // ------------------------------------------------------------------------------------------------
+using mf_f4 = __attribute__((ext_vector_type(4))) float;
+
 // One OP_CONV: dst[co][t] = (bias[co]) + sum_k sum_ci W[k][ci][co] * tap_k[ci][t]
 // tap_k[ci][t] = src frame (t - L), L = (K-1-k)*dil: from the LDS block when t-L >= 0, else from the
 // stream's history ring in HBM (frames of earlier blocks). Afterwards the block is appended to the ring.
-template <int CB>
-__device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float* __restrict__ blob, float* st,
-                                        int* wpos_tbl, const int lane, const int nvalid)
+template <int CB, bool WLDS>
+__device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float* __restrict__ blob, const float* wlds,
+                                        float* st, int* wpos_tbl, const int lane, const int nvalid)
 {
   const float* src = lds + op.src;
   float* dst = lds + op.dst;
@@ -147,15 +149,34 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
     {
       const int L = (K - 1 - k) * op.dil;
       const float* __restrict__ wk = blob + op.w + (size_t)k * cin * cpad + co0;
-      if (L == 0)
-      {
-        for (int ci = 0; ci < cin; ci++)
+      const float* wkl = wlds + op.w + (size_t)k * cin * cpad + co0; // the same weights in LDS (WLDS)
+      // acc[j] += W[k][ci][co0 + j] * x: weights as SGPR operands (scalar loads) or, with WLDS, as broadcast
+      // 16-byte LDS reads
+      auto fma_row = [&](int ci, float x) {
+        if constexpr (WLDS)
         {
-          const float x = src[ci * kBlock + lane];
+          float wv[CB];
+#pragma unroll
+          for (int j = 0; j < CB; j += 4)
+          {
+            const mf_f4 q = *reinterpret_cast<const mf_f4*>(wkl + (size_t)ci * cpad + j);
+            wv[j] = q[0], wv[j + 1] = q[1], wv[j + 2] = q[2], wv[j + 3] = q[3];
+          }
+#pragma unroll
+          for (int j = 0; j < CB; j++)
+            acc[j] = fmaf(wv[j], x, acc[j]);
+        }
+        else
+        {
 #pragma unroll
           for (int j = 0; j < CB; j++)
             acc[j] = fmaf(wk[(size_t)ci * cpad + j], x, acc[j]);
         }
+      };
+      if (L == 0)
+      {
+        for (int ci = 0; ci < cin; ci++)
+          fma_row(ci, src[ci * kBlock + lane]);
       }
       else if (L >= kBlock)
       {
@@ -163,12 +184,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
         if (idx < 0)
           idx += R;
         for (int ci = 0; ci < cin; ci++)
-        {
-          const float x = ring[(size_t)idx * cin + ci];
-#pragma unroll
-          for (int j = 0; j < CB; j++)
-            acc[j] = fmaf(wk[(size_t)ci * cpad + j], x, acc[j]);
-        }
+          fma_row(ci, ring[(size_t)idx * cin + ci]);
       }
       else
       {
@@ -184,10 +200,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
         {
           const float xl = src[ci * kBlock + lidx];
           const float xr = ring[(size_t)idx * cin + ci];
-          const float x = in_block ? xl : xr;
-#pragma unroll
-          for (int j = 0; j < CB; j++)
-            acc[j] = fmaf(wk[(size_t)ci * cpad + j], x, acc[j]);
+          fma_row(ci, in_block ? xl : xr);
         }
       }
     }
@@ -196,7 +209,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
       const float* __restrict__ bias = blob + op.b + co0;
 #pragma unroll
       for (int j = 0; j < CB; j++)
-        acc[j] += bias[j];
+        acc[j] += WLDS ? wlds[op.b + co0 + j] : bias[j];
     }
 #pragma unroll
     for (int j = 0; j < CB; j++)
@@ -222,11 +235,20 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
 // `ops` and `blob` are separate `const __restrict__` kernel parameters (not struct members) so that
 // the compiler can prove their loads are never clobbered by the state stores and lower the
 // wave-uniform ones to scalar (s_load) instructions: weights then arrive as SGPR operands.
+template <bool WLDS>
 __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict__ ops,
                                                          const float* __restrict__ blob, const GenericArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
+  const float* wlds = lds + a.w_lds_off;
+  if constexpr (WLDS)
+  {
+    float* wdst = lds + a.w_lds_off;
+    for (int i = lane * 4; i < a.blob_floats; i += 64 * 4)
+      *reinterpret_cast<mf_f4*>(wdst + i) = *reinterpret_cast<const mf_f4*>(blob + i);
+    __syncthreads();
+  }
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
   float* st = a.state + (size_t)stream * a.state_stride;
   int* wpos_tbl = reinterpret_cast<int*>(st);
@@ -254,9 +276,9 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
           break;
         case OP_CONV:
           if (op.cb == 8)
-            op_conv<8>(op, lds, blob, st, wpos_tbl, lane, nvalid);
+            op_conv<8, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
           else
-            op_conv<4>(op, lds, blob, st, wpos_tbl, lane, nvalid);
+            op_conv<4, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
           break;
         case OP_FILM:
           for (int c = 0; c < op.cout; c++)
@@ -1179,14 +1201,19 @@ __global__ void nam_fill_state_kernel(float* state, long state_stride, const int
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream)
 {
+  const bool wlds = a.blob_floats > 0;
   if (lds_bytes > 64 * 1024)
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nam_generic_kernel),
+    hipError_t e = hipFuncSetAttribute(wlds ? reinterpret_cast<const void*>(nam_generic_kernel<true>)
+                                            : reinterpret_cast<const void*>(nam_generic_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess)
       return e;
   }
-  hipLaunchKernelGGL(nam_generic_kernel, dim3(n_blocks), dim3(64), lds_bytes, stream, a.ops, a.blob, a);
+  if (wlds)
+    hipLaunchKernelGGL(nam_generic_kernel<true>, dim3(n_blocks), dim3(64), lds_bytes, stream, a.ops, a.blob, a);
+  else
+    hipLaunchKernelGGL(nam_generic_kernel<false>, dim3(n_blocks), dim3(64), lds_bytes, stream, a.ops, a.blob, a);
   return hipGetLastError();
 }
 

@@ -258,7 +258,16 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.n_frames = n_frames;
       a.in_ch = p.in_channels;
       a.out_ch = p.out_channels;
-      NAM_HIP_CHECK(launch_generic(a, n, p.lds_rows * kBlock * (int)sizeof(float), s));
+      // conv weights from LDS when the model's weights fit next to the activation rows (kernels.h)
+      int lds_bytes = p.lds_rows * kBlock * (int)sizeof(float);
+      a.w_lds_off = p.lds_rows * kBlock;
+      a.blob_floats = 0;
+      if (lds_bytes + p.generic_blob_floats * (int)sizeof(float) <= 96 * 1024)
+      {
+        a.blob_floats = p.generic_blob_floats;
+        lds_bytes += p.generic_blob_floats * (int)sizeof(float);
+      }
+      NAM_HIP_CHECK(launch_generic(a, n, lds_bytes, s));
     }
   }
   else

@@ -797,6 +797,9 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
   }
   b.push(OP_END);
   plan.lds_rows = b.rows.high;
+  while (plan.blob.size() % 4)
+    plan.blob.push_back(0.0f);
+  plan.generic_blob_floats = (int)plan.blob.size();
   // per-stream state: [write positions: n_rings ints, padded to 64 words][rings...]
   const int table = (plan.n_rings + kBlock - 1) / kBlock * kBlock;
   for (auto& op : plan.ops)

@@ -221,6 +221,7 @@ struct Plan
   std::vector<NamOp> ops;
   std::vector<float> blob;
   int lds_rows = 0; // LDS rows (x 64 floats) the generic kernel needs per wavefront
+  int generic_blob_floats = 0; // leading part of `blob` the op program reads (weights, biases, activation parameters)
   int n_rings = 0;
   int state_floats = 0; // per-stream state size (floats), multiple of 64; first n_rings words = write positions
   A1Plan a1;
