@@ -258,11 +258,15 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
   for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
   {
     const int nvalid = min(kBlock, a.n_frames - f0);
+    // the descriptor of the op after this one is requested before this op runs (the program ends with OP_END and
+    // plan.cpp pads it with one more so that pc + 1 is always readable)
+    NamOp next_op = ops[0];
     for (int pc = 0;; pc++)
     {
-      const NamOp op = ops[pc];
+      const NamOp op = next_op;
       if (op.type == OP_END)
         break;
+      next_op = ops[pc + 1];
       switch (op.type)
       {
         case OP_LOAD_IN:

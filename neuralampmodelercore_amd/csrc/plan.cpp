@@ -796,6 +796,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
     op.cin = plan.out_channels;
   }
   b.push(OP_END);
+  b.push(OP_END); // the interpreter reads one descriptor ahead
   plan.lds_rows = b.rows.high;
   while (plan.blob.size() % 4)
     plan.blob.push_back(0.0f);
