@@ -282,6 +282,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall_max, gpu_s_max = float(tmax[0]), float(tmax[1])
 
+    # alongside (not `value`): the same K blocks as ONE resident launch — the offline re-amp shape, no per-block
+    # kernel boundary — timed the same way after the primary region; the input window is re-read, the state runs on
+    other = None
+    n_chk = min(T, 64 * 40)
+    got_dev = y[0, 0, :n_chk].clone()  # parity sample of the primary pass (the re-run below overwrites its window)
+    if args.launch == "block":
+        fence()
+        t1 = time.perf_counter()
+        batch.process_device(xp + W * block * 4, yp + W * block * 4, K * block, T, sh)
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        t_res = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t_res, op=dist.ReduceOp.MAX)
+        other = float(t_res[0])
+
     # after the timed region: gather the last rendered block of every stream back to rank 0 over RCCL
     tail = y[:, :, (total_steps - 1) * block:].contiguous()
     gathered = sharding.gather_streams(tail, n_total, dst=0) if distributed else tail
@@ -291,11 +309,10 @@ def main():
     if rank == 0 and args.check:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nam_oracle
-        n_chk = min(T, 64 * 40)
         ref = nam_oracle.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
         ref.Reset(SR, block)
         r = ref.process_stream(bank[0, :n_chk], block)[0]
-        got = y[0, 0, :n_chk].cpu().numpy()
+        got = got_dev.cpu().numpy()
         parity = float(np.max(np.abs(r - got)))
 
     if rank == 0:
@@ -353,6 +370,9 @@ def main():
                             "note": f"{flops_per_sample} FLOP/stream-sample; fp32 MFMA peak == fp32 vector peak"},
             },
             "gpu_ms_total": round(gpu_s_max * 1e3, 3),
+            "resident_launch": (None if other is None else {
+                "value": round(n_streams * block * K * world / SR / other, 1), "ms_per_step": round(other / K * 1e3, 6),
+                "note": "same K blocks as one launch walking device-resident audio (offline re-amp shape); not `value`"}),
             "finite": finite,
             "max_abs_err_vs_oracle": parity,
         }
