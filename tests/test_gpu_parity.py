@@ -545,3 +545,22 @@ def test_edge_cases_of_the_abi(nam_lib, oracle):
     r = _oracle_run(oracle, "wavenet", x[1, :7], 64, False)
     assert float(np.max(np.abs(r - outs[2]))) <= 1e-4
     bb.close()
+
+
+def test_mfma_kernel_is_deterministic_and_launch_shape_independent(nam_lib):
+    """The same audio rendered twice with one launch per block and twice as one resident launch: all four results
+    bit-identical (any unsynchronised LDS / ring traffic between the compute and mover wavefronts would show up as
+    run-to-run differences); 700 streams = several workgroups per CU."""
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    n_streams = 700
+    x = stream_bank(n_streams, 64 * 30 + 13, seed=123)
+    outs = []
+    for rep in range(4):
+        b = model.batch(n_streams, 64)
+        b.set_kernel(nam.KERNEL_A1_MFMA)
+        b.Reset(prewarm=True)
+        outs.append(b.process_stream(x, 64) if rep % 2 == 0 else np.stack(b.render(list(x))))
+        b.close()
+    for y in outs[1:]:
+        np.testing.assert_array_equal(outs[0], y)
