@@ -1098,10 +1098,16 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
       }
     const int xrow = (min(grp, in_ch - 1) * 16 + j) * 65; // lane group g feeds input element g (zero weights beyond I0)
     float xv = xin[xrow];
+    // Off the recurrence's critical path: the input half of layer 0 (bias + Wi . x_t) is issued one step ahead, and a
+    // step's output is stored one step later (the store would otherwise sit, in order, behind the head MFMA's result)
+    f4 pre0[NT];
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+      pre0[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], grp < I0 ? xv : 0.0f, bias[0][T], 0, 0, 0);
+    f4 ypend = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nvalid; t++)
     {
-      const float xnext = xin[xrow + min(t + 1, kBlock - 1)]; // next step's input, off the critical path
-      const float x0 = grp < I0 ? xv : 0.0f;
+      const float xnext = xin[xrow + min(t + 1, kBlock - 1)]; // next step's input
       float hn[NL][NT];
 #pragma unroll
       for (int l = 0; l < NL; l++)
@@ -1111,14 +1117,8 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
         f4 acc[NT];
 #pragma unroll
         for (int T = 0; T < NT; T++)
-          acc[T] = bias[l][T];
-        if (l == 0)
-        {
-#pragma unroll
-          for (int T = 0; T < NT; T++)
-            acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], x0, acc[T], 0, 0, 0);
-        }
-        else
+          acc[T] = l == 0 ? pre0[T] : bias[l][T];
+        if (l > 0)
         {
 #pragma unroll
           for (int s = 0; s < NT; s++)
@@ -1131,6 +1131,21 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
 #pragma unroll
           for (int T = 0; T < NT; T++)
             acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l][T][s], h[l][s], acc[T], 0, 0, 0);
+        if (l == 0)
+        {
+          // next step's input half and the previous step's output store, in the shadow of the MFMAs above
+          const float xn = grp < I0 ? xnext : 0.0f;
+#pragma unroll
+          for (int T = 0; T < NT; T++)
+            pre0[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], xn, bias[0][T], 0, 0, 0);
+          if (t > 0)
+          {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (4 * grp + e < out_ch)
+                yout[((4 * grp + e) * 16 + j) * 65 + t - 1] = ypend[e];
+          }
+        }
 #pragma unroll
         for (int T = 0; T < NT; T++)
         {
@@ -1149,20 +1164,23 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
           hn[l][T] = hv;
         }
       }
-      f4 acc = hbias;
+      ypend = hbias;
 #pragma unroll
       for (int s = 0; s < NT; s++)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], hn[NL - 1][s], acc, 0, 0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        if (4 * grp + e < out_ch)
-          yout[((4 * grp + e) * 16 + j) * 65 + t] = acc[e];
+        ypend = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], hn[NL - 1][s], ypend, 0, 0, 0);
 #pragma unroll
       for (int l = 0; l < NL; l++)
 #pragma unroll
         for (int T = 0; T < NT; T++)
           h[l][T] = hn[l][T];
       xv = xnext;
+    }
+    if (nvalid > 0)
+    {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (4 * grp + e < out_ch)
+          yout[((4 * grp + e) * 16 + j) * 65 + nvalid - 1] = ypend[e];
     }
     if (a.out)
       for (int ch = 0; ch < out_ch; ch++)
