@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--launch", choices=["block", "resident"], default="block")
     ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slim-mix", action="store_true",
+                    help="slimmable models: stream s runs at ratio (0.0, 0.34, 0.67, 1.0)[s %% 4] (BASELINE.json configs[4])")
     ap.add_argument("--check", type=int, default=1, help="verify stream 0 of rank 0 against the oracle after timing")
     args = ap.parse_args()
 
@@ -239,6 +241,9 @@ def main():
     if args.kernel != "auto":
         batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[args.kernel])
     batch.Reset(prewarm=True)
+    if args.slim_mix:
+        for i, ratio in enumerate((0.0, 0.34, 0.67, 1.0)):
+            batch.SetSlimmableSize(ratio, list(range(i, n_streams, 4)))
     # a dedicated (non-null) HIP stream: the kernels are launched on it through the C ABI and the
     # HIP events that time them are recorded on the same stream
     stream = torch.cuda.Stream(dev)
@@ -310,6 +315,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nam_oracle
         ref = nam_oracle.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
+        if args.slim_mix:
+            ref.SetSlimmableSize(0.0)  # stream 0's size
         ref.Reset(SR, block)
         r = ref.process_stream(bank[0, :n_chk], block)[0]
         got = got_dev.cpu().numpy()
