@@ -751,7 +751,11 @@ __device__ __forceinline__ f4 act4(int type, const f4& v, float p0)
 // workgroup barrier that orders LDS traffic only: outstanding global loads stay in flight
 __device__ __forceinline__ void lds_barrier()
 {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // the builtin, not inline asm: hipcc's waitcnt pass then knows nothing is outstanding on lgkmcnt after the
+  // barrier; with an asm wait it re-waits (lgkmcnt(0)) before the first use of any register loaded in the previous job,
+  // i.e. in front of the own-tap MFMA chain that is there to cover the latency of the shifted-tap reads
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0); vmcnt / expcnt untouched
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
@@ -1455,7 +1459,9 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
           NAM_WS_STAMP(1, "v"(pre))
           if (flags & CD_LAYER)
           {
-            const f4 z = act4<ACT_T>(J.act, pre, act_p0);
+            // half layout: only elements 0, 1 of a lane ever feed an MFMA (z into the 1x1, head into the head
+            // rechannel), elements 2, 3 are the partner lane group's copies: two activations per lane, not four
+            const f4 z = act4<ACT_T>(J.act, NK == 2 ? f4{pre[0], pre[1], pre[0], pre[1]} : pre, act_p0);
             head += z;
             // layer1x1 as two chains; the residual and the 1x1 bias are the initial accumulator
             f4 y0 = x + O.b1v, y1 = {0.f, 0.f, 0.f, 0.f};
@@ -1481,6 +1487,12 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
                 lds_st4(lds, v_tap + v_g16 + (unsigned)J.pub_b, x);
             }
           }
+          // What the job barrier waits for anyway, stated at the end of every variant: the four variants are
+          // laid out one after the other behind flag tests, so without it the waitcnt pass carries one variant's
+          // outstanding operand reads into the entry of the next and puts an lgkmcnt(0) in front of its first MFMA.
+          // (the per-variant asm comment keeps the optimiser from sinking the four waits into one at the join.)
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          asm volatile("; end of job body nk=%0 plain=%1" ::"n"(NK), "n"((int)PLAIN));
         };
         const bool plain = (flags_rt & ~CD_HALF) == CD_LAYER;
         if (flags_rt & CD_HALF)
