@@ -1102,6 +1102,13 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
       }
     const int xrow = (min(grp, in_ch - 1) * 16 + j) * 65; // lane group g feeds input element g (zero weights beyond I0)
     float xv = xin[xrow];
+    float x1 = xin[xrow + 1]; // the inputs are read two steps ahead: an LDS round trip per step is not on the chain
+    // where this lane's four head outputs go (rows 4 grp + e of the output tile); lanes without a row write to a pad
+    int yrow[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      yrow[e] = 4 * grp + e < out_ch ? ((4 * grp + e) * 16 + j) * 65 : out_ch * 16 * 65 + lane;
+    const int n_store = min(4, out_ch); // rows 0..n_store-1 exist in lane group 0 (uniform: skips whole stores)
     // Off the recurrence's critical path: the input half of layer 0 (bias + Wi . x_t) is issued one step ahead, and a
     // step's output is stored one step later (the store would otherwise sit, in order, behind the head MFMA's result)
     f4 pre0[NT];
@@ -1111,7 +1118,8 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
     f4 ypend = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nvalid; t++)
     {
-      const float xnext = xin[xrow + min(t + 1, kBlock - 1)]; // next step's input
+      const float xnext = x1; // next step's input
+      x1 = xin[xrow + min(t + 2, kBlock - 1)];
       float hn[NL][NT];
 #pragma unroll
       for (int l = 0; l < NL; l++)
@@ -1146,8 +1154,8 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
           {
 #pragma unroll
             for (int e = 0; e < 4; e++)
-              if (4 * grp + e < out_ch)
-                yout[((4 * grp + e) * 16 + j) * 65 + t - 1] = ypend[e];
+              if (e < n_store)
+                yout[yrow[e] + t - 1] = ypend[e];
           }
         }
 #pragma unroll
@@ -1183,8 +1191,8 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
     {
 #pragma unroll
       for (int e = 0; e < 4; e++)
-        if (4 * grp + e < out_ch)
-          yout[((4 * grp + e) * 16 + j) * 65 + nvalid - 1] = ypend[e];
+        if (e < n_store)
+          yout[yrow[e] + nvalid - 1] = ypend[e];
     }
     if (a.out)
       for (int ch = 0; ch < out_ch; ch++)
@@ -1745,7 +1753,8 @@ hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
   // small models: everything in registers (only the I/O tiles in LDS)
   if (a.input_size <= 4 && a.n_layers <= 2 && a.mf_nt <= 6)
   {
-    const int io_bytes = (a.in_ch + a.out_ch) * 16 * 65 * (int)sizeof(float);
+    // I/O tiles + a pad row that lanes without an output row store to (64 lanes + 64 steps)
+    const int io_bytes = ((a.in_ch + a.out_ch) * 16 * 65 + 128) * (int)sizeof(float);
 #define NAM_LSTM_REG(NL, NT) \
   hipLaunchKernelGGL((nam_lstm_mfma_reg_kernel<NL, NT>), dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a)
     const int key = a.n_layers * 10 + a.mf_nt;
