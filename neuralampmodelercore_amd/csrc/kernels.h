@@ -79,6 +79,8 @@ struct LSTMArgs
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
+hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,
+                          hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);
 hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream);
 int lstm_lds_bytes(const LSTMArgs& a);

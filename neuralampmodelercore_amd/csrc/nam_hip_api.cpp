@@ -180,16 +180,26 @@ int refresh_map(nam_hip_batch* b, WidthGroup& g)
 }
 
 // Which kernel a WaveNet group runs: explicit choice if possible, otherwise the fastest available.
+constexpr size_t kKtAutoMaxStreams = 1024;
+
 int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 {
   const bool a1 = g.plan->a1.valid && g.d_a1;
-  const bool mfma = a1 && g.plan->a1.ws_ok;
+  const bool mfma = a1 && (g.plan->a1.ws_ok || g.plan->a1.kt_ok);
   const int fallback = a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
   switch (b->kernel)
   {
     case NAM_HIP_KERNEL_GENERIC: return NAM_HIP_KERNEL_GENERIC;
     case NAM_HIP_KERNEL_A1: return fallback;
-    default: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback; // AUTO or A1_MFMA
+    case NAM_HIP_KERNEL_A1_MFMA: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback;
+    default: // AUTO
+      if (!mfma)
+        return fallback;
+      // The K-tap kernel (A2 shapes) spreads a stream over four wavefronts: 2.3x the VALU kernel while the chip has
+      // idle SIMDs, level with it at ~1,000 streams per GPU, behind it beyond (it issues more instructions per tap).
+      if (!g.plan->a1.ws_ok && g.streams.size() > kKtAutoMaxStreams)
+        return fallback;
+      return NAM_HIP_KERNEL_A1_MFMA;
   }
 }
 
@@ -221,7 +231,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
       a.n_mjobs = a.tiles_off = a.consts_off = 0;
       a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = a.prefetch = 0;
-      if (kernel == NAM_HIP_KERNEL_A1_MFMA)
+      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok)
+        // single-array models with other kernel sizes than 3 (A2): the K-tap MFMA kernel
+        NAM_HIP_CHECK(launch_kt_mfma(a, n, p.a1.kt_nk, p.a1.arr[0].channels, p.a1.kt_lds_floats, p.a1.arr[0].act, s));
+      else if (kernel == NAM_HIP_KERNEL_A1_MFMA)
       {
         // uniform activation across arrays -> compile-time specialised kernel, else run-time dispatch
         int act = p.a1.arr[0].act;
@@ -472,7 +485,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
                       : s.arch == ARCH_LSTM  ? (int64_t)s.lstm.weights.size()
                                              : 0; // a container has no weights of its own
   info->fast_tanh = s.fast_tanh ? 1 : 0;
-  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && p.a1.ws_ok) ? 2 : 0);
+  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -770,13 +783,16 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
   if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_MFMA)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
   if (kernel >= NAM_HIP_KERNEL_A1)
+  {
+    // every submodel must have an A1 plan; the MFMA kernels must exist for the full-width submodel (narrower
+    // submodels of a container fall back to the VALU kernel: A2-Lite has 3 channels)
     for (const auto& g : batch->groups)
-    {
       if (g.plan->arch != ARCH_WAVENET || !g.plan->a1.valid)
         return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 kernels cannot run this model");
-      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !g.plan->a1.ws_ok)
-        return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 MFMA kernel cannot run this model");
-    }
+    const A1Plan& full = batch->groups[batch->model->full_width].plan->a1;
+    if (kernel == NAM_HIP_KERNEL_A1_MFMA && !full.ws_ok && !full.kt_ok)
+      return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 MFMA kernel cannot run this model");
+  }
   batch->kernel = kernel;
   return NAM_HIP_OK;
 }

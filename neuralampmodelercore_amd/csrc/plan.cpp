@@ -773,6 +773,145 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
   build_a1_ws(wn, plan);
 }
 
+// Chunk table and MFMA operand tiles of nam_kt_mfma_kernel (plan.h: KtDesc), derived from the packed A1 weights and
+// ring geometry that build_a1 has already laid down (ring offsets final, i.e. behind the write-position table).
+// Requires a single layer array with channels % 4 == 0 (<= 16), a mono input and a single head output channel; any
+// per-layer kernel size and head kernel size up to 16.
+void build_a1_kt(Plan& plan)
+{
+  A1Plan& a1 = plan.a1;
+  a1.kt_ok = 0;
+  if (!a1.valid || a1.n_arrays != 1)
+    return;
+  const A1Array A = a1.arr[0]; // by value: the blob grows below
+  const int C = A.channels, NL = A.n_layers;
+  if (A.in_size != 1 || C % 4 != 0 || C > 16 || A.head_size != 1)
+    return;
+  enum { FULL = 0, HALF = 1 };
+  const int mode = C == 8 ? HALF : FULL;
+  const int NK = mode == HALF ? 2 : 4;
+  auto out_chan = [&](int g, int e) { return mode == HALF ? 4 * (g % 2) + (e + 2 * (g / 2)) % 4 : 4 * g + e; };
+  auto in_chan = [&](int g, int m) { return mode == HALF ? 4 * (g % 2) + 2 * (g / 2) + m : 4 * g + m; };
+  auto chunks_of = [](int K) { return (K + kKtTaps - 1) / kKtTaps; };
+  int n_chunks = chunks_of(A.head_k);
+  for (int l = 0; l < NL; l++)
+    n_chunks += chunks_of(A.ksize[l]);
+  // the kernel requests operands up to 5 chunks ahead; a chunk of the NEXT block must lie well behind the current one
+  // so that the rows it reads from THIS block are long written
+  if (n_chunks > kKtChunkMax || n_chunks < 16)
+    return;
+  // blob regions: tap tiles [chunk][kKtTaps taps][64 lanes][NK] (half layout: taps paired per lane, see below),
+  // then what the kernel keeps in LDS: 1x1 tiles [layer][64 lanes][NK] | constants [layer + head][3][16]
+  const int tile_floats = 64 * NK;
+  const int chunk_floats = kKtTaps * tile_floats;
+  while (plan.blob.size() % 64)
+    plan.blob.push_back(0.0f);
+  const size_t tiles0 = plan.blob.size();
+  plan.blob.resize(tiles0 + (size_t)(n_chunks + 1) * chunk_floats, 0.0f);
+  const size_t w1_0 = plan.blob.size();
+  plan.blob.resize(w1_0 + (size_t)NL * tile_floats, 0.0f);
+  const size_t consts0 = plan.blob.size();
+  plan.blob.resize(consts0 + (size_t)(NL + 1) * 48, 0.0f);
+  const size_t lds_end = plan.blob.size();
+  const size_t rech0 = lds_end;
+  plan.blob.resize(rech0 + 16, 0.0f);
+  float* const blob = plan.blob.data();
+  const float* const base = blob + A.w_base;
+  // value m of lane (gk, i) of a tile: W[out_chan(i / 4, i % 4)][in_chan(gk, m)]
+  auto tile_value = [&](int lane, int m, auto at) {
+    const int gk = lane / 16, i = lane % 16;
+    const int co = out_chan(i / 4, i % 4), ci = in_chan(gk, m);
+    return (co < C && ci < C) ? at(co, ci) : 0.0f;
+  };
+  // tap `slot` of a chunk record. Full layout: [slot][lane][4 k-steps]. Half layout (2 k-steps): the taps are
+  // paired so that one 16-byte load per lane brings two taps: [slot / 2][lane][(slot % 2) * 2 + m].
+  auto fill_tap = [&](size_t chunk_off, int slot, auto at) {
+    for (int lane = 0; lane < 64; lane++)
+      for (int m = 0; m < NK; m++)
+      {
+        const size_t idx = NK == 2 ? (size_t)(slot / 2) * 256 + (size_t)lane * 4 + (slot % 2) * 2 + m
+                                   : (size_t)slot * 256 + (size_t)lane * 4 + m;
+        blob[chunk_off + idx] = tile_value(lane, m, at);
+      }
+  };
+  auto fill_const = [&](size_t off, auto at) {
+    for (int g = 0; g < 4; g++)
+      for (int e = 0; e < 4; e++)
+      {
+        const int c = out_chan(g, e);
+        blob[off + (size_t)g * 4 + e] = c < C ? at(c) : 0.0f;
+      }
+  };
+  fill_const(rech0, [&](int c) { return base[c]; }); // rechannel [ci = 0][co]
+  int chunk = 0;
+  // tap(k)(co, ci): weight of tap k
+  auto emit_layer = [&](int K, int d, int flags, int w1_lds_b, int consts_lds_b, int ring_off, int R, int ring_id,
+                        auto tap) {
+    for (int c0 = 0; c0 < K; c0 += kKtTaps)
+    {
+      const size_t chunk_off = tiles0 + (size_t)chunk * chunk_floats;
+      KtDesc& D = a1.kt_desc[chunk++];
+      std::memset(&D, 0, sizeof(D));
+      D.ntaps = std::min(kKtTaps, K - c0);
+      D.flags = flags | (c0 == 0 ? (int)KT_FIRST | (ring_id >= 0 ? (int)KT_RING : 0) : 0)
+                | (c0 + kKtTaps >= K ? (int)KT_LAST : 0);
+      if (!(D.flags & KT_LAST))
+        D.flags &= ~(int)KT_NEXT_HEAD;
+      D.tile_off = (int)chunk_off;
+      D.w1_off = w1_lds_b;
+      D.consts_off = consts_lds_b;
+      D.ring_b = ring_id >= 0 ? ring_off * 4 : 0;
+      D.R = ring_id >= 0 ? R : kKtNoTap;
+      D.ring_id = ring_id >= 0 ? ring_id : 0;
+      for (int i = 0; i < kKtTaps; i++)
+      {
+        D.L[i] = i < D.ntaps ? (K - 1 - (c0 + i)) * d : kKtNoTap;
+        if (i < D.ntaps)
+        {
+          const int k = c0 + i;
+          fill_tap(chunk_off, i, [&](int co, int ci) { return tap(k, co, ci); });
+        }
+      }
+    }
+  };
+  for (int l = 0; l < NL; l++)
+  {
+    const int K = A.ksize[l];
+    const float* cw = base + A.layer_off[l];
+    const float* cb = cw + (size_t)K * C * C;
+    const float* mx = cb + C;
+    const float* w1 = mx + C;
+    const float* b1 = w1 + (size_t)C * C;
+    const size_t w1_off = w1_0 + (size_t)l * tile_floats;
+    for (int lane = 0; lane < 64; lane++)
+      for (int m = 0; m < NK; m++)
+        blob[w1_off + (size_t)lane * NK + m] = tile_value(lane, m, [&](int co, int ci) { return w1[(size_t)ci * C + co]; });
+    const size_t co_off = consts0 + (size_t)l * 48;
+    fill_const(co_off, [&](int c) { return cb[c]; });
+    fill_const(co_off + 16, [&](int c) { return mx[c]; });
+    fill_const(co_off + 32, [&](int c) { return b1[c]; });
+    emit_layer(K, A.dil[l], l + 1 == NL ? (int)KT_NEXT_HEAD : 0, (int)((w1_off - w1_0) * 4), (int)((co_off - w1_0) * 4),
+               A.ring_off[l], A.ring_len[l], A.ring_id[l],
+               [&](int k, int co, int ci) { return cw[((size_t)k * C + ci) * C + co]; });
+  }
+  {
+    // head rechannel: [k][c][h = 0] -> output row 0 only; bias rides in the "conv bias" slot
+    const int K = A.head_k;
+    const float* hw = base + A.head_off;
+    const float* hb = hw + (size_t)K * C;
+    const size_t co_off = consts0 + (size_t)NL * 48;
+    fill_const(co_off, [&](int c) { return c == 0 ? hb[0] : 0.0f; });
+    emit_layer(K, A.head_dil, (int)KT_HEAD, 0, (int)((co_off - w1_0) * 4), A.head_ring_off, A.head_ring_len,
+               A.head_ring_id, [&](int k, int co, int ci) { return co == 0 ? hw[(size_t)k * C + ci] : 0.0f; });
+  }
+  a1.kt_chunks = chunk;
+  a1.kt_nk = NK;
+  a1.kt_rech_off = (int)rech0;
+  a1.kt_lds_src_off = (int)w1_0;
+  a1.kt_lds_floats = (int)(lds_end - w1_0);
+  a1.kt_ok = 1;
+}
+
 } // namespace
 
 Plan build_wavenet_plan(const WaveNetSpec& wn)
@@ -826,6 +965,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
         plan.a1.vdesc[j].ring_b += table * 4;
       plan.a1.vdesc[j].f_rbase += table * 4;
     }
+    build_a1_kt(plan);
   }
   return plan;
 }

@@ -165,6 +165,38 @@ struct VDesc // 16 x int32, one s_load_dwordx16
 };
 static_assert(sizeof(CDesc) == 32 && sizeof(VDesc) == 64, "descriptor sizes are part of the kernel ABI");
 
+// ---- K-tap MFMA kernel (nam_kt_mfma_kernel): single-array A1-family models with any per-layer kernel size ----
+// (A2: K = 6 / 15, head rechannel K = 16.) A layer is cut into CHUNKS of up to kKtTaps taps; the current frame is a
+// tap like any other (lookback 0). Only a layer's last chunk activates, applies the 1x1, publishes the layer output
+// and meets the workgroup barrier; the head rechannel is one more "layer" whose input is the head accumulator.
+// Same state (rings, write positions) and packed weights as nam_a1_kernel; the tiles below are an MFMA-operand
+// repacking of those weights.
+constexpr int kKtTaps = 6;
+constexpr int kKtChunkMax = 112;
+enum KtFlags : int32_t
+{
+  KT_FIRST = 1, // first chunk of a layer: accumulators start from bias + mixin * input sample; append the layer input to its ring
+  KT_LAST = 2, // last chunk: activation, head accumulate, 1x1 + residual, publish, barrier
+  KT_HEAD = 4, // the head rechannel (input = head accumulator; no activation / 1x1; LAST writes the output sample)
+  KT_NEXT_HEAD = 8, // LAST of the final layer: publish the head accumulator instead of x
+  KT_RING = 16 // the layer has a history ring (K > 1)
+};
+struct KtDesc // 16 x int32
+{
+  int32_t flags;
+  int32_t ntaps; // taps in this chunk (1..kKtTaps)
+  int32_t tile_off; // blob float offset of the chunk's tap tiles (plan.cpp: build_a1_kt for the record layout)
+  int32_t w1_off; // byte offset, inside the kernel's LDS copy, of the layer's 1x1 tile [64 lanes][NK]
+  int32_t consts_off; // byte offset, same region, of the layer's constants in the lane layout: bias | mixin | 1x1 bias, 16 floats each
+  int32_t ring_b; // byte offset of the layer's ring in the stream state
+  int32_t R; // ring length in frames
+  int32_t ring_id; // index into the write-position table (0 when the layer has no ring)
+  int32_t L[kKtTaps]; // lookback of each tap in frames; unused slots: kKtNoTap
+  int32_t pad[2];
+};
+constexpr int kKtNoTap = 1 << 20;
+static_assert(sizeof(KtDesc) == 64, "descriptor size is part of the kernel ABI");
+
 struct A1Plan
 {
   int32_t valid = 0;
@@ -183,6 +215,13 @@ struct A1Plan
   int32_t ws_prefetch = 6; // D
   CDesc cdesc[kWsJobMax];
   VDesc vdesc[kWsJobMax];
+  // K-tap MFMA kernel
+  int32_t kt_ok = 0; // nam_kt_mfma_kernel can run this model (plan.cpp: build_a1_kt)
+  int32_t kt_chunks = 0; // chunks per block
+  int32_t kt_nk = 4; // k-steps per matrix: 2 = half layout (C = 8), 4 = full layout
+  int32_t kt_rech_off = 0; // blob float offset: rechannel column in the lane layout (16 floats)
+  int32_t kt_lds_src_off = 0, kt_lds_floats = 0; // blob region copied to LDS at kernel start: 1x1 tiles | constants
+  KtDesc kt_desc[kKtChunkMax];
 };
 
 // ---- LSTM ------------------------------------------------------------------------------------

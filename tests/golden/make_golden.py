@@ -23,7 +23,8 @@ from signals import two_tone  # noqa: E402
 MODELS = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable_wavenet", "wavenet_condition_dsp",
           "synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed",  # synth_*: make_synthetic_models.py
           "A2", "slimmable_container",  # SlimmableContainer files: the default (last) submodel
-          "synth_posthead"]  # post-stack head, two output channels (mono input)
+          "synth_posthead",  # post-stack head, two output channels (mono input)
+          "synth_kt_c8", "synth_kt_c16", "synth_kt_c12", "synth_kt_c4"]  # per-layer kernel sizes, head rechannel with taps
 # container submodels below the top one: (file, SetSlimmableSize value)
 CONTAINER_RATIOS = [("A2", 0.2), ("slimmable_container", 0.1), ("slimmable_container", 0.5)]
 

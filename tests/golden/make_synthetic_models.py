@@ -1,7 +1,8 @@
 """Writes small synthetic A1-family WaveNet fixtures (seeded random weights) that exercise the MFMA kernel's
 variants the shipped example models do not reach: odd layer counts (idle job + padded launch), prefetch depth
 5 / 6, 12- and 4-channel arrays (full lane layout, partial quads), two 8-channel arrays (half layout end to
-end), mixed activations (run-time activation dispatch), head bias on / off.
+end), mixed activations (run-time activation dispatch), head bias on / off; and single-array models with
+per-layer kernel sizes 1..16 and a head rechannel with taps (synth_kt_*: the K-tap MFMA kernel).
 
     python tests/golden/make_synthetic_models.py      # then tests/golden/make_golden.py
 
@@ -155,7 +156,61 @@ LSTMS = {
 }
 
 
+def build_ktap(name, C, ksizes, dils, act, head_k, head_dil, head_bias, seed):
+    """Single layer array with per-layer kernel sizes and a head rechannel with taps (the A2 shape family,
+    NAM/wavenet/model.cpp:399-400, 547-548): reaches nam_kt_mfma_kernel (any kernel size <= 16, chunks of 6 taps).
+    Stream order: rechannel [C][1]; per layer conv [C][C][K], bias [C], mixin [C][1], layer1x1 [C][C], bias [C];
+    head rechannel [1][C][K_h] (+ bias [1]); head_scale."""
+    rng = np.random.default_rng(seed)
+    weights = []
+
+    def w(shape, fan_in):
+        v = rng.standard_normal(shape).astype(np.float32) * np.float32(0.9 / np.sqrt(fan_in))
+        weights.extend(v.reshape(-1).tolist())
+
+    head = dict(out_channels=1, kernel_size=head_k, bias=head_bias)
+    if head_dil != 1:
+        head["head_dilation"] = head_dil
+    layer = dict(input_size=1, condition_size=1, head=head, channels=C, kernel_sizes=ksizes, dilations=dils, activation=act,
+                 gated=False)
+    w((C, 1), 1.0)
+    for K in ksizes:
+        w((C, C, K), C * K)
+        w((C,), 4.0)
+        w((C, 1), 1.0)
+        w((C, C), C)
+        w((C,), 4.0)
+    w((1, C, head_k), C * head_k * len(ksizes))
+    if head_bias:
+        w((1,), 4.0)
+    weights.append(0.05)
+    model = dict(version="0.5.4", architecture="WaveNet", config=dict(layers=[layer], head=None, head_scale=0.05),
+                 metadata=dict(name=name, note="synthetic test fixture (seeded random weights)"), weights=weights, sample_rate=48000)
+    with open(os.path.join(HERE, "models", name + ".nam"), "w") as f:
+        json.dump(model, f)
+    return len(weights)
+
+
+KTAP = {
+    # half layout (C = 8): kernel sizes 1..16 -> 1, 2 and 3 chunks per layer, lookbacks inside / across / far beyond a
+    # block, LeakyReLU (compile-time activation), head rechannel with 5 taps at dilation 2
+    "synth_kt_c8": dict(C=8, ksizes=[6, 2, 7, 1, 13, 3, 16, 6, 4, 9, 6, 5], dils=[1, 3, 7, 2, 5, 17, 1, 41, 101, 13, 239, 2],
+                        act=dict(type="LeakyReLU", negative_slope=0.02), head_k=5, head_dil=2, head_bias=True, seed=41),
+    # full layout (C = 16), Tanh (Fasttanh when enabled), 16-tap head without bias
+    "synth_kt_c16": dict(C=16, ksizes=[3, 6, 8, 2, 15, 1, 6, 12, 4, 7], dils=[1, 2, 64, 128, 1, 9, 300, 3, 33, 11], act="Tanh",
+                         head_k=16, head_dil=1, head_bias=False, seed=42),
+    # 12 channels (full layout, partial quad), two chunks per layer, ReLU (run-time activation dispatch), 1-tap head
+    "synth_kt_c12": dict(C=12, ksizes=[7] * 9, dils=[1, 2, 4, 8, 16, 32, 64, 128, 256], act="ReLU", head_k=1, head_dil=1,
+                         head_bias=True, seed=43),
+    # 4 channels, 2 taps per layer, Sigmoid
+    "synth_kt_c4": dict(C=4, ksizes=[2] * 16, dils=[1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 1, 2, 4, 8, 16], act="Sigmoid",
+                        head_k=3, head_dil=1, head_bias=True, seed=44),
+}
+
+
 if __name__ == "__main__":
+    for name, spec in KTAP.items():
+        print(name, build_ktap(name, **spec), "weights")
     for name, spec in LSTMS.items():
         print(name, build_lstm(name, **spec), "weights")
     for name, spec in SPECS.items():

@@ -13,6 +13,8 @@ pytestmark = pytest.mark.gpu
 WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet"]
 # synthetic A1-family fixtures (tests/golden/make_synthetic_models.py) that reach the MFMA kernel's variants
 SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed"]
+# single-array fixtures with per-layer kernel sizes 1..16 and a head rechannel with taps: the K-tap MFMA kernel
+SYNTH_KT = ["synth_kt_c8", "synth_kt_c16", "synth_kt_c12", "synth_kt_c4"]
 
 
 def _oracle_run(oracle, name, x, block, fast_tanh, ratio=None):
@@ -75,6 +77,47 @@ def test_mfma_kernel_variants_match_oracle(nam_lib, oracle, name, fast_tanh):
             err = float(np.max(np.abs(refs[s] - y[s])))
             assert err <= _tol(fast_tanh) * scale, (name, mode, s, err, scale)
         batch.close()
+
+
+@pytest.mark.parametrize("name", SYNTH_KT + ["A2"])
+@pytest.mark.parametrize("fast_tanh", [True, False])
+def test_ktap_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh):
+    """nam_kt_mfma_kernel (A2 shapes): half / full lane layout, 1-3 chunks per layer, lookbacks inside, across and far
+    beyond a block, head rechannel with 1 / 3 / 5 / 16 taps (one at dilation 2), compile-time and run-time activation
+    dispatch — block launches with a ragged tail and multi-block launches; the VALU kernel on the same state layout
+    must agree, and the two must be interchangeable mid-stream."""
+    nam = nam_lib
+    n_streams, block, n = 3, 64, 64 * 7 + 23
+    x = stream_bank(n_streams, n, seed=37)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    assert model.info.has_a1_kernel & 2, "fixture must be MFMA-eligible"
+    for mode, max_frames in (("blocks", block), ("one_launch", 512)):
+        refs = [_oracle_run(oracle, name, x[s], max_frames, fast_tanh) for s in range(n_streams)]
+        ys = {}
+        for kernel in (nam.KERNEL_A1_MFMA, nam.KERNEL_A1):
+            batch = model.batch(n_streams, max_frames)
+            batch.set_kernel(kernel)
+            assert batch.get_kernel() == kernel
+            batch.Reset(prewarm=True)
+            ys[kernel] = batch.process_stream(x, max_frames)
+            batch.close()
+        for kernel, y in ys.items():
+            for s in range(n_streams):
+                scale = max(1.0, float(np.max(np.abs(refs[s]))))
+                err = float(np.max(np.abs(refs[s] - y[s])))
+                assert err <= _tol(fast_tanh) * scale, (name, mode, kernel, s, err, scale)
+    # switch kernels between blocks of one stream: same rings, same write positions
+    batch = model.batch(n_streams, block)
+    batch.Reset(prewarm=True)
+    parts = []
+    for i, k0 in enumerate(range(0, 64 * 6, 64)):
+        batch.set_kernel(nam.KERNEL_A1_MFMA if i % 2 == 0 else nam.KERNEL_A1)
+        parts.append(batch.process(x[:, k0:k0 + 64]))
+    y = np.concatenate(parts, axis=-1)
+    batch.close()
+    refs = [_oracle_run(oracle, name, x[s, :64 * 6], block, fast_tanh) for s in range(n_streams)]
+    for s in range(n_streams):
+        assert float(np.max(np.abs(refs[s] - y[s]))) <= _tol(fast_tanh) * max(1.0, float(np.max(np.abs(refs[s]))))
 
 
 def test_lstm_matches_oracle(nam_lib, oracle):
