@@ -53,7 +53,10 @@ extern "C" {
 #define NAM_HIP_KERNEL_AUTO 0
 #define NAM_HIP_KERNEL_GENERIC 1 /* op-program interpreter (every WaveNet feature) */
 #define NAM_HIP_KERNEL_A1 2 /* register-resident VALU kernel for the plain A1 family (1 wave per stream) */
-#define NAM_HIP_KERNEL_A1_MFMA 3 /* fp32-MFMA kernel for the A1 family: 4 compute + 4 mover waves per stream */
+#define NAM_HIP_KERNEL_A1_MFMA 3 /* fp32-MFMA kernels for the A1 family: kernel size 3 everywhere -> wave-specialised kernel
+                                    (4 compute + 4 mover waves per stream); a single layer array with other kernel
+                                    sizes (A2) -> K-tap kernel (4 waves per stream). Narrower submodels of a container
+                                    that neither can run use NAM_HIP_KERNEL_A1 */
 
 typedef struct nam_hip_model nam_hip_model;
 typedef struct nam_hip_batch nam_hip_batch;
@@ -75,7 +78,7 @@ typedef struct nam_hip_model_info
   double output_level; /* DSP::GetOutputLevel dsp.h:133 */
   int64_t num_weights;
   int32_t fast_tanh; /* load-time switch replacing the global Activation::enable_fast_tanh (activations.cpp:168) */
-  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: the A1 MFMA kernel can */
+  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: one of the A1 MFMA kernels can */
   int64_t state_bytes_per_stream; /* HBM history per stream */
   char version[32]; /* .nam "version" */
 } nam_hip_model_info;

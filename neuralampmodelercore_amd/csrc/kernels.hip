@@ -11,7 +11,10 @@
 //                       condition_dsp, post-stack head). Activations live in LDS rows.
 //   nam_a1_kernel       register-resident specialisation for the plain A1 family
 //                       (wavenet_a1_standard.nam): activations never leave VGPRs inside a layer array.
+//   nam_a1_mfma_kernel  the headline kernel: fp32 MFMA, 4 compute + 4 mover wavefronts per stream (kernel size 3).
+//   nam_kt_mfma_kernel  fp32 MFMA for single-array models with any per-layer kernel size (A2), 4 wavefronts per stream.
 //   nam_lstm_kernel     LSTM, lanes = streams, h/c in LDS columns, I/O tiles transposed through LDS.
+//   nam_lstm_mfma_kernel / nam_lstm_mfma_reg_kernel   LSTM on MFMA, 16 streams per wavefront.
 //
 // Reference behaviour restated (file:line relative to the reference tree):
 //   Layer::Process NAM/wavenet/model.cpp:183-393 · Conv1D::Process NAM/conv1d.cpp:163-183,666-685,768-775 ·
@@ -1695,8 +1698,8 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
 // layout and MFMA operand mapping exactly as in nam_a1_mfma_kernel (full layout, or half layout for C = 8).
 // A layer is a run of CHUNKS of up to kKtTaps taps (plan.h: KtDesc). Every tap's B operand is the lane's slice of
 // frame (t - L): from the LDS copy of the layer input when that frame is inside the block, else from the layer's
-// history ring in HBM — requested ONE CHUNK AHEAD with buffer loads whose offset is out of range for lanes that do
-// not need history (no memory traffic), together with the next chunk's weight tiles and constants. Only a layer's
+// history ring in HBM — requested D CHUNKS AHEAD with buffer loads whose offset is out of range for lanes that do
+// not need history (no memory traffic), together with that chunk's tap tiles. Only a layer's
 // last chunk activates, runs the 1x1, publishes and meets the barrier: one barrier per layer. The head rechannel
 // (A2: 16 taps over the head accumulator) is one more layer whose published input is the head accumulator.
 // State layout, ring geometry and write positions are nam_a1_kernel's (the two are interchangeable mid-stream).
@@ -1838,7 +1841,7 @@ __global__ __launch_bounds__(256) void nam_kt_mfma_kernel(const A1Plan* __restri
       for (int i = 0; i < kKtTaps; i++)
       {
         const int row = max(frame + 1 - J.L[i], 0);
-        lv[i] = *reinterpret_cast<const fN*>(lds + (par * buf_b + (unsigned)row * row_b + opnd_b));
+        lv[i] = *reinterpret_cast<const fN*>(lds + (__umul24((unsigned)row, row_b) + (par * buf_b + opnd_b)));
       }
       const unsigned a_c = aux_b + (unsigned)J.consts_off + quad_b;
       const f4 bv = mf::lds_ld4(lds, a_c), mv = mf::lds_ld4(lds, a_c + 64u), b1v = mf::lds_ld4(lds, a_c + 128u);
@@ -1858,22 +1861,39 @@ __global__ __launch_bounds__(256) void nam_kt_mfma_kernel(const A1Plan* __restri
         acc0 = bv + mv * cond;
         acc1 = f4{0.f, 0.f, 0.f, 0.f};
       }
+      // one wait for the whole set (the oldest requests in flight), not one per tap
 #pragma unroll
       for (int i = 0; i < kKtTaps; i++)
-        if (i < ntaps)
-        {
-          const fN bsum = lv[i] + s.th[i]; // exactly one of the two is the operand, the other is 0
+        asm volatile("" ::"v"(s.th[i]));
 #pragma unroll
-          for (int m = 0; m < NK; m++)
-          {
-            const float bm = bsum[m];
-            const float am = NK == 2 ? s.tt[i / 2][(i % 2) * 2 + m] : s.tt[i][m];
-            if (i & 1)
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc1, 0, 0, 0);
-            else
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc0, 0, 0, 0);
-          }
+      for (int i = 0; i < NT; i++)
+        asm volatile("" ::"v"(s.tt[i]));
+      auto tap = [&](int i) {
+        const fN bsum = lv[i] + s.th[i]; // exactly one of the two is the operand, the other is 0
+#pragma unroll
+        for (int m = 0; m < NK; m++)
+        {
+          const float bm = bsum[m];
+          const float am = NK == 2 ? s.tt[i / 2][(i % 2) * 2 + m] : s.tt[i][m];
+          if (i & 1)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc1, 0, 0, 0);
+          else
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc0, 0, 0, 0);
         }
+      };
+      if (ntaps == kKtTaps) // the common case (A2: 26 of 30 chunks) without a test per tap
+      {
+#pragma unroll
+        for (int i = 0; i < kKtTaps; i++)
+          tap(i);
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < kKtTaps; i++)
+          if (i < ntaps)
+            tap(i);
+      }
       const float cn = s.cn;
       // refill this set for chunk ci + D (beyond the end of this block it belongs to the next one, whose rings have
       // moved on by one block)
