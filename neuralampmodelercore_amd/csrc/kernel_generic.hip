@@ -1,0 +1,287 @@
+// kernel_generic.hip — the op-program interpreter. File-level notes for all kernel_*.hip: hand-written HIP for gfx950 (MI355X, CDNA4). No CUDA path, no shims.
+//
+// Mapping: the data-parallel axis is independent audio streams. For WaveNets one
+// 64-lane wavefront owns one stream and walks its audio in blocks of 64 frames with LANE = FRAME,
+// so every weight is wave-uniform (fetched by scalar loads, used as an SGPR operand of v_fma) and
+// every history read is 64 consecutive floats. For LSTMs (a true recurrence) LANE = STREAM.
+//
+// Kernels:
+//   nam_generic_kernel  interprets the op program of plan.h; covers every WaveNet feature the
+//                       reference has (FiLM, gating/blending, grouped convs, head1x1, nested
+//                       condition_dsp, post-stack head). Activations live in LDS rows.
+//   nam_a1_kernel       register-resident specialisation for the plain A1 family
+//                       (wavenet_a1_standard.nam): activations never leave VGPRs inside a layer array.
+//   nam_a1_mfma_kernel  the headline kernel: fp32 MFMA, 4 compute + 4 mover wavefronts per stream (kernel size 3).
+//   nam_kt_mfma_kernel  fp32 MFMA for single-array models with any per-layer kernel size (A2), 4 wavefronts per stream.
+//   nam_lstm_kernel     LSTM, lanes = streams, h/c in LDS columns, I/O tiles transposed through LDS.
+//   nam_lstm_mfma_kernel / nam_lstm_mfma_reg_kernel   LSTM on MFMA, 16 streams per wavefront.
+//
+// Reference behaviour restated (file:line relative to the reference tree):
+//   Layer::Process NAM/wavenet/model.cpp:183-393 · Conv1D::Process NAM/conv1d.cpp:163-183,666-685,768-775 ·
+//   Conv1x1::process_ NAM/dsp.cpp:436-449,770-836 · activations NAM/activations.h:59-133 ·
+//   gating NAM/gating_activations.h:59-228 · FiLM NAM/film.h:76-204 · LSTM NAM/lstm.cpp:31-168.
+#include "device_common.h"
+
+namespace namhip
+{
+
+// ------------------------------------------------------------------------------------------------
+// Generic interpreter
+// ------------------------------------------------------------------------------------------------
+
+// One OP_CONV: dst[co][t] = (bias[co]) + sum_k sum_ci W[k][ci][co] * tap_k[ci][t]
+// tap_k[ci][t] = src frame (t - L), L = (K-1-k)*dil: from the LDS block when t-L >= 0, else from the
+// stream's history ring in HBM (frames of earlier blocks). Afterwards the block is appended to the ring.
+template <int CB, bool WLDS>
+__device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float* __restrict__ blob, const float* wlds,
+                                        float* st, int* wpos_tbl, const int lane, const int nvalid)
+{
+  const float* src = lds + op.src;
+  float* dst = lds + op.dst;
+  const int cin = op.cin, cout = op.cout, cpad = op.cout_pad, K = op.k;
+  const bool has_ring = op.state >= 0;
+  const int R = op.ring;
+  int wp = 0;
+  float* ring = nullptr;
+  if (has_ring)
+  {
+    wp = uni(wpos_tbl[op.ring_id]);
+    ring = st + op.state;
+  }
+  for (int co0 = 0; co0 < cpad; co0 += CB)
+  {
+    float acc[CB];
+#pragma unroll
+    for (int j = 0; j < CB; j++)
+      acc[j] = 0.0f;
+    for (int k = 0; k < K; k++)
+    {
+      const int L = (K - 1 - k) * op.dil;
+      const float* __restrict__ wk = blob + op.w + (size_t)k * cin * cpad + co0;
+      const float* wkl = wlds + op.w + (size_t)k * cin * cpad + co0; // the same weights in LDS (WLDS)
+      // acc[j] += W[k][ci][co0 + j] * x: weights as SGPR operands (scalar loads) or, with WLDS, as broadcast
+      // 16-byte LDS reads
+      auto fma_row = [&](int ci, float x) {
+        if constexpr (WLDS)
+        {
+          float wv[CB];
+#pragma unroll
+          for (int j = 0; j < CB; j += 4)
+          {
+            const mf_f4 q = *reinterpret_cast<const mf_f4*>(wkl + (size_t)ci * cpad + j);
+            wv[j] = q[0], wv[j + 1] = q[1], wv[j + 2] = q[2], wv[j + 3] = q[3];
+          }
+#pragma unroll
+          for (int j = 0; j < CB; j++)
+            acc[j] = fmaf(wv[j], x, acc[j]);
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < CB; j++)
+            acc[j] = fmaf(wk[(size_t)ci * cpad + j], x, acc[j]);
+        }
+      };
+      if (L == 0)
+      {
+        for (int ci = 0; ci < cin; ci++)
+          fma_row(ci, src[ci * kBlock + lane]);
+      }
+      else if (L >= kBlock)
+      {
+        int idx = wp + lane - L;
+        if (idx < 0)
+          idx += R;
+        for (int ci = 0; ci < cin; ci++)
+          fma_row(ci, ring[(size_t)idx * cin + ci]);
+      }
+      else
+      {
+        const int tl = lane - L;
+        const bool in_block = tl >= 0;
+        int idx = wp + tl;
+        if (idx < 0)
+          idx += R;
+        if (in_block)
+          idx = 0; // keep the masked-off address in range
+        const int lidx = in_block ? tl : 0;
+        for (int ci = 0; ci < cin; ci++)
+        {
+          const float xl = src[ci * kBlock + lidx];
+          const float xr = ring[(size_t)idx * cin + ci];
+          fma_row(ci, in_block ? xl : xr);
+        }
+      }
+    }
+    if (op.b >= 0)
+    {
+      const float* __restrict__ bias = blob + op.b + co0;
+#pragma unroll
+      for (int j = 0; j < CB; j++)
+        acc[j] += WLDS ? wlds[op.b + co0 + j] : bias[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CB; j++)
+      if (co0 + j < cout)
+        dst[(co0 + j) * kBlock + lane] = acc[j];
+  }
+  if (has_ring)
+  {
+    int widx = wp + lane;
+    if (widx >= R)
+      widx -= R;
+    if (lane < nvalid)
+      for (int ci = 0; ci < cin; ci++)
+        ring[(size_t)widx * cin + ci] = src[ci * kBlock + lane];
+    int nwp = wp + nvalid;
+    if (nwp >= R)
+      nwp -= R;
+    if (lane == 0)
+      wpos_tbl[op.ring_id] = nwp;
+  }
+}
+
+// `ops` and `blob` are separate `const __restrict__` kernel parameters (not struct members) so that
+// the compiler can prove their loads are never clobbered by the state stores and lower the
+// wave-uniform ones to scalar (s_load) instructions: weights then arrive as SGPR operands.
+template <bool WLDS>
+__global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict__ ops,
+                                                         const float* __restrict__ blob, const GenericArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const float* wlds = lds + a.w_lds_off;
+  if constexpr (WLDS)
+  {
+    float* wdst = lds + a.w_lds_off;
+    for (int i = lane * 4; i < a.blob_floats; i += 64 * 4)
+      *reinterpret_cast<mf_f4*>(wdst + i) = *reinterpret_cast<const mf_f4*>(blob + i);
+    __syncthreads();
+  }
+  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  float* st = a.state + (size_t)stream * a.state_stride;
+  int* wpos_tbl = reinterpret_cast<int*>(st);
+  const float* in = a.in ? a.in + (size_t)stream * a.in_ch * a.io_stride : nullptr;
+  float* out = a.out ? a.out + (size_t)stream * a.out_ch * a.io_stride : nullptr;
+
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    // the descriptor of the op after this one is requested before this op runs (the program ends with OP_END and
+    // plan.cpp pads it with one more so that pc + 1 is always readable)
+    NamOp next_op = ops[0];
+    for (int pc = 0;; pc++)
+    {
+      const NamOp op = next_op;
+      if (op.type == OP_END)
+        break;
+      next_op = ops[pc + 1];
+      switch (op.type)
+      {
+        case OP_LOAD_IN:
+          for (int c = 0; c < op.cout; c++)
+            lds[op.dst + c * kBlock + lane] = (in && lane < nvalid) ? in[(size_t)c * a.io_stride + f0 + lane] : 0.0f;
+          break;
+        case OP_STORE_OUT:
+          if (out && lane < nvalid)
+            for (int c = 0; c < op.cin; c++)
+              out[(size_t)c * a.io_stride + f0 + lane] = lds[op.src + c * kBlock + lane];
+          break;
+        case OP_CONV:
+          if (op.cb == 8)
+            op_conv<8, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
+          else
+            op_conv<4, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
+          break;
+        case OP_FILM:
+          for (int c = 0; c < op.cout; c++)
+          {
+            const float x = lds[op.src + c * kBlock + lane];
+            const float sc = lds[op.aux + c * kBlock + lane];
+            float y = x * sc;
+            if (op.flag)
+              y += lds[op.aux + (op.cout + c) * kBlock + lane];
+            lds[op.dst + c * kBlock + lane] = y;
+          }
+          break;
+        case OP_ACT:
+        {
+          const float p0 = blob[op.w], p1 = blob[op.w + 1], p2 = blob[op.w + 2], p3 = blob[op.w + 3];
+          const int ns = op.ring;
+          for (int c = 0; c < op.cout; c++)
+          {
+            float slope = 0.0f;
+            if (op.k == ACT_PRELU)
+            {
+              // Activation::apply(float*, size) on column-major data: slopes[pos % n] (activations.h:283-297)
+              const long pos = (long)(f0 + lane) * op.cout + c;
+              slope = blob[op.w + 4 + (int)(pos % ns)];
+            }
+            const float x = lds[op.dst + c * kBlock + lane];
+            lds[op.dst + c * kBlock + lane] = d_act_rt(op.k, x, p0, p1, p2, p3, slope);
+          }
+          break;
+        }
+        case OP_GATE:
+        {
+          // gating_activations.h:59-114 (gated) / :165-228 (blended); result in the top B rows
+          const int B = op.cout;
+          const float a0 = blob[op.w], a1 = blob[op.w + 1], a2 = blob[op.w + 2], a3 = blob[op.w + 3];
+          const float g0 = blob[op.b], g1 = blob[op.b + 1], g2 = blob[op.b + 2], g3 = blob[op.b + 3];
+          for (int c = 0; c < B; c++)
+          {
+            const float pre = lds[op.dst + c * kBlock + lane];
+            const float gin = lds[op.dst + (c + B) * kBlock + lane];
+            const float s1 = (op.k == ACT_PRELU) ? blob[op.w + 4 + c % op.ring] : 0.0f;
+            const float s2 = (op.dil == ACT_PRELU) ? blob[op.b + 4 + c % op.ring_id] : 0.0f;
+            const float av = d_act_rt(op.k, pre, a0, a1, a2, a3, s1);
+            const float gv = d_act_rt(op.dil, gin, g0, g1, g2, g3, s2);
+            lds[op.dst + c * kBlock + lane] = (op.flag == GATING_GATED) ? av * gv : gv * av + (1.0f - gv) * pre;
+          }
+          break;
+        }
+        case OP_ADD:
+          for (int c = 0; c < op.cout; c++)
+            lds[op.dst + c * kBlock + lane] = lds[op.src + c * kBlock + lane] + lds[op.aux + c * kBlock + lane];
+          break;
+        case OP_COPY:
+          for (int c = 0; c < op.cout; c++)
+            lds[op.dst + c * kBlock + lane] = lds[op.src + c * kBlock + lane];
+          break;
+        case OP_ZERO:
+          for (int c = 0; c < op.cout; c++)
+            lds[op.dst + c * kBlock + lane] = 0.0f;
+          break;
+        case OP_SCALE:
+        {
+          const float s = blob[op.w];
+          for (int c = 0; c < op.cout; c++)
+            lds[op.dst + c * kBlock + lane] = s * lds[op.src + c * kBlock + lane];
+          break;
+        }
+        default: break;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream)
+{
+  const bool wlds = a.blob_floats > 0;
+  if (lds_bytes > 64 * 1024)
+  {
+    hipError_t e = hipFuncSetAttribute(wlds ? reinterpret_cast<const void*>(nam_generic_kernel<true>)
+                                            : reinterpret_cast<const void*>(nam_generic_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess)
+      return e;
+  }
+  if (wlds)
+    hipLaunchKernelGGL(nam_generic_kernel<true>, dim3(n_blocks), dim3(64), lds_bytes, stream, a.ops, a.blob, a);
+  else
+    hipLaunchKernelGGL(nam_generic_kernel<false>, dim3(n_blocks), dim3(64), lds_bytes, stream, a.ops, a.blob, a);
+  return hipGetLastError();
+}
+
+} // namespace namhip

@@ -1,0 +1,515 @@
+// kernel_lstm.hip — the LSTM kernels (lanes = streams; 16 streams per wavefront on the matrix cores) and the
+// per-stream state fill.
+#include "device_common.h"
+
+namespace namhip
+{
+
+// ------------------------------------------------------------------------------------------------
+// LSTM: lanes = streams (a true per-sample recurrence — NAM/lstm.cpp:103-168)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ blob, const LSTMArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // LDS carve-up (floats): io tile [64 streams][65] | xh [(I+H) max][64] per layer | c [H][64] per layer | ifgo [4H][64]
+  const int lane = threadIdx.x;
+  const int s0 = blockIdx.x * kBlock;
+  // position s0 + lane of this launch; the stream it stands for comes from the optional map (a batch whose
+  // streams run different submodels launches each group over its member list)
+  const bool live = s0 + lane < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + lane] : s0 + lane) : 0;
+  const int H = a.hidden, NL = a.n_layers, I0 = a.input_size;
+  const int in_ch = a.in_ch, out_ch = a.out_ch;
+  float* tile_in = lds; // [in_ch][64][65]
+  float* tile_out = tile_in + in_ch * kBlock * 65; // [out_ch][64][65]
+  float* hs = tile_out + out_ch * kBlock * 65; // [NL][H][64]
+  float* cs = hs + NL * H * kBlock; // [NL][H][64]
+  float* ifgo = cs + NL * H * kBlock; // [4H][64]
+
+  // load recurrent state
+  float* st = a.state + (size_t)stream * a.state_stride;
+  for (int l = 0; l < NL; l++)
+    for (int i = 0; i < H; i++)
+    {
+      hs[(l * H + i) * kBlock + lane] = live ? st[(l * 2 + 0) * H + i] : 0.0f;
+      cs[(l * H + i) * kBlock + lane] = live ? st[(l * 2 + 1) * H + i] : 0.0f;
+    }
+
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    __syncthreads();
+    // coalesced tile load: row r = stream s0+r, lane = frame
+    for (int c = 0; c < in_ch; c++)
+      for (int r = 0; r < kBlock; r++)
+      {
+        const int s = __shfl(stream, r); // the stream of position s0 + r
+        float v = 0.0f;
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
+          v = a.in[((size_t)s * in_ch + c) * a.io_stride + f0 + lane];
+        tile_in[(c * kBlock + r) * 65 + lane] = v;
+      }
+    __syncthreads();
+    for (int f = 0; f < nvalid; f++)
+    {
+      for (int l = 0; l < NL; l++)
+      {
+        const int I = l == 0 ? I0 : H;
+        const float* __restrict__ W = blob + a.layer_w[l];
+        const float* __restrict__ Bv = blob + a.layer_b[l];
+        for (int r = 0; r < 4 * H; r++)
+        {
+          const float* __restrict__ wr = W + (size_t)r * (I + H);
+          float sum = 0.0f;
+          for (int j = 0; j < I; j++)
+          {
+            const float xv = (l == 0) ? tile_in[(j * kBlock + lane) * 65 + f] : hs[((l - 1) * H + j) * kBlock + lane];
+            sum = fmaf(wr[j], xv, sum);
+          }
+          for (int j = 0; j < H; j++)
+            sum = fmaf(wr[I + j], hs[(l * H + j) * kBlock + lane], sum);
+          ifgo[r * kBlock + lane] = sum + Bv[r];
+        }
+        for (int i = 0; i < H; i++)
+        {
+          const float gi = ifgo[(i)*kBlock + lane], gf = ifgo[(i + H) * kBlock + lane];
+          const float gg = ifgo[(i + 2 * H) * kBlock + lane], go = ifgo[(i + 3 * H) * kBlock + lane];
+          const float cprev = cs[(l * H + i) * kBlock + lane];
+          float cn, hn;
+          if (a.fast)
+          {
+            cn = d_fast_sigmoid(gf) * cprev + d_fast_sigmoid(gi) * d_fast_tanh(gg);
+            hn = d_fast_sigmoid(go) * d_fast_tanh(cn);
+          }
+          else
+          {
+            cn = d_sigmoid(gf) * cprev + d_sigmoid(gi) * tanhf(gg);
+            hn = d_sigmoid(go) * tanhf(cn);
+          }
+          cs[(l * H + i) * kBlock + lane] = cn;
+          hs[(l * H + i) * kBlock + lane] = hn;
+        }
+      }
+      for (int o = 0; o < out_ch; o++)
+      {
+        const float* __restrict__ wr = blob + a.head_w + (size_t)o * H;
+        float sum = 0.0f;
+        for (int j = 0; j < H; j++)
+          sum = fmaf(wr[j], hs[((NL - 1) * H + j) * kBlock + lane], sum);
+        tile_out[(o * kBlock + lane) * 65 + f] = sum + blob[a.head_b + o];
+      }
+    }
+    __syncthreads();
+    if (a.out)
+      for (int c = 0; c < out_ch; c++)
+        for (int r = 0; r < kBlock; r++)
+        {
+          const int s = __shfl(stream, r);
+          if (s0 + r < a.n_streams && lane < nvalid)
+            a.out[((size_t)s * out_ch + c) * a.io_stride + f0 + lane] = tile_out[(c * kBlock + r) * 65 + lane];
+        }
+  }
+  if (live)
+    for (int l = 0; l < NL; l++)
+      for (int i = 0; i < H; i++)
+      {
+        st[(l * 2 + 0) * H + i] = hs[(l * H + i) * kBlock + lane];
+        st[(l * 2 + 1) * H + i] = cs[(l * H + i) * kBlock + lane];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSTM on the matrix cores: 16 streams per wavefront, the per-sample [4H x (I + H)] . [x; h] of all 16 streams
+// is a handful of v_mfma_f32_16x16x4_f32 (columns = streams). Weight rows are permuted (plan.h) so that lane
+// group u of a unit tile receives the i, f, g, o pre-activations of ONE hidden unit: the gate math and the c / h
+// update stay in that lane, and the lane's new h is exactly the B operand it feeds into the next time step /
+// next layer. Everything (tiles, h, c, I/O tiles) lives in LDS; one wavefront per workgroup, no barriers.
+// lstm.nam (H = 3): 2 MFMAs + one head MFMA per sample instead of 60 scalar-weight FMAs with exposed latency.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void nam_lstm_mfma_kernel(const float* __restrict__ blob, const LSTMArgs a)
+{
+  using mf::f4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, j = lane & 15;
+  const int s0 = blockIdx.x * 16;
+  const bool live = s0 + j < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + j] : s0 + j) : 0;
+  const int H = a.hidden, NL = a.n_layers, I0 = a.input_size, NT = a.mf_nt;
+  const int in_ch = a.in_ch, out_ch = a.out_ch;
+  const int KI0 = (I0 + 3) / 4;
+  float* region = lds; // tiles, biases (plan.h)
+  float* hbuf = region + a.mf_floats; // [2][NL][4 NT][16]
+  float* cbuf = hbuf + 2 * NL * 4 * NT * 16; // [NL][4 NT][16]
+  float* xin = cbuf + NL * 4 * NT * 16; // [in_ch][16][65]
+  float* yout = xin + in_ch * 16 * 65; // [out_ch][16][65]
+  const int hstride = NL * 4 * NT * 16; // one time parity of hbuf
+
+  for (int i = lane; i < a.mf_floats; i += 64)
+    region[i] = blob[a.mf_off + i];
+  // recurrent state: lane (grp, j) owns unit 4T + grp of stream j
+  float* st = a.state + (size_t)stream * a.state_stride;
+  for (int l = 0; l < NL; l++)
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      const bool ok = live && u < H;
+      hbuf[hstride + (l * 4 * NT + u) * 16 + j] = ok ? st[(l * 2 + 0) * H + u] : 0.0f; // parity 1 = "time -1"
+      cbuf[(l * 4 * NT + u) * 16 + j] = ok ? st[(l * 2 + 1) * H + u] : 0.0f;
+    }
+  int par = 0; // parity of the time step being computed
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    // coalesced input tile: row r = stream of position s0 + r, lane = frame
+    for (int c = 0; c < in_ch; c++)
+      for (int r = 0; r < 16; r++)
+      {
+        const int s = __shfl(stream, r);
+        float v = 0.0f;
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
+          v = a.in[((size_t)s * in_ch + c) * a.io_stride + f0 + lane];
+        xin[(c * 16 + r) * 65 + lane] = v;
+      }
+    for (int t = 0; t < nvalid; t++)
+    {
+      const float* hprev = hbuf + (par ^ 1) * hstride; // h(t - 1)
+      float* hcur = hbuf + par * hstride; // h(t)
+      for (int l = 0; l < NL; l++)
+      {
+        const int KI = l == 0 ? KI0 : NT;
+        const float* tiles = region + a.mf_layer_tiles[l];
+        const float* bias = region + a.mf_layer_bias[l];
+        for (int T = 0; T < NT; T++)
+        {
+          f4 acc = *reinterpret_cast<const f4*>(bias + (T * 4 + grp) * 4); // i, f, g, o biases of unit 4T + grp
+          const float* tl = tiles + (size_t)T * (KI + NT) * 64 + lane;
+          for (int s = 0; s < KI; s++) // layer input: x(t) or the layer below's h(t)
+          {
+            const int e = 4 * s + grp;
+            const float b = l == 0 ? (e < I0 ? xin[(e * 16 + j) * 65 + t] : 0.0f) : hcur[((l - 1) * 4 * NT + e) * 16 + j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[s * 64], b, acc, 0, 0, 0);
+          }
+          for (int s = 0; s < NT; s++) // this layer's h(t - 1)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[(KI + s) * 64], hprev[(l * 4 * NT + 4 * s + grp) * 16 + j], acc, 0, 0, 0);
+          const int u = 4 * T + grp;
+          const float cprev = cbuf[(l * 4 * NT + u) * 16 + j];
+          float cn, hn;
+          if (a.fast)
+          {
+            cn = mf::fast_sigmoid_hw(acc[1]) * cprev + mf::fast_sigmoid_hw(acc[0]) * mf::fast_tanh_hw(acc[2]);
+            hn = mf::fast_sigmoid_hw(acc[3]) * mf::fast_tanh_hw(cn);
+          }
+          else
+          {
+            cn = mf::sigmoid_hw(acc[1]) * cprev + mf::sigmoid_hw(acc[0]) * mf::tanh_hw(acc[2]);
+            hn = mf::sigmoid_hw(acc[3]) * mf::tanh_hw(cn);
+          }
+          cbuf[(l * 4 * NT + u) * 16 + j] = cn;
+          hcur[(l * 4 * NT + u) * 16 + j] = hn;
+        }
+      }
+      // head: y = Wh . h_top(t) + bh; lane group g receives output channels 4g..4g+3
+      {
+        f4 acc = *reinterpret_cast<const f4*>(region + a.mf_head_bias + grp * 4);
+        const float* tl = region + a.mf_head_tiles + lane;
+        for (int s = 0; s < NT; s++)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[s * 64], hcur[((NL - 1) * 4 * NT + 4 * s + grp) * 16 + j], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (4 * grp + e < out_ch)
+            yout[((4 * grp + e) * 16 + j) * 65 + t] = acc[e];
+      }
+      par ^= 1;
+    }
+    if (a.out)
+      for (int c = 0; c < out_ch; c++)
+        for (int r = 0; r < 16; r++)
+        {
+          const int s = __shfl(stream, r);
+          if (s0 + r < a.n_streams && lane < nvalid)
+            a.out[((size_t)s * out_ch + c) * a.io_stride + f0 + lane] = yout[(c * 16 + r) * 65 + lane];
+        }
+  }
+  // the last computed step has parity par ^ 1
+  const float* hlast = hbuf + (par ^ 1) * hstride;
+  for (int l = 0; l < NL; l++)
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      if (live && u < H)
+      {
+        st[(l * 2 + 0) * H + u] = hlast[(l * 4 * NT + u) * 16 + j];
+        st[(l * 2 + 1) * H + u] = cbuf[(l * 4 * NT + u) * 16 + j];
+      }
+    }
+}
+
+// The same kernel for small models (<= 2 layers, <= 24 hidden units, <= 4 inputs), fully unrolled: every A
+// tile value, bias, h and c of the lane stays in registers for the whole launch; per sample only the input is
+// read from LDS and the output written to it. lstm.nam: ~0.2 us per sample step instead of ~0.9.
+template <int NL, int NT>
+__global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __restrict__ blob, const LSTMArgs a)
+{
+  using mf::f4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, j = lane & 15;
+  const int s0 = blockIdx.x * 16;
+  const bool live = s0 + j < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + j] : s0 + j) : 0;
+  const int H = a.hidden, I0 = a.input_size;
+  const int in_ch = a.in_ch, out_ch = a.out_ch;
+  float* xin = lds; // [in_ch][16][65]
+  float* yout = xin + in_ch * 16 * 65; // [out_ch][16][65]
+  const float* region = blob + a.mf_off;
+
+  float wi[NL][NT][NT], wr[NL][NT][NT], h[NL][NT], c[NL][NT], wh[NT];
+  f4 bias[NL][NT];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    const int KI = l == 0 ? 1 : NT; // input_size <= 4: one k-step
+    const float* tiles = region + a.mf_layer_tiles[l];
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+    {
+#pragma unroll
+      for (int s = 0; s < NT; s++)
+      {
+        wi[l][T][s] = s < KI ? tiles[(T * (KI + NT) + s) * 64 + lane] : 0.0f;
+        wr[l][T][s] = tiles[(T * (KI + NT) + KI + s) * 64 + lane];
+      }
+      bias[l][T] = *reinterpret_cast<const f4*>(region + a.mf_layer_bias[l] + (T * 4 + grp) * 4);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NT; s++)
+    wh[s] = region[a.mf_head_tiles + s * 64 + lane];
+  const f4 hbias = *reinterpret_cast<const f4*>(region + a.mf_head_bias + grp * 4);
+  float* st = a.state + (size_t)stream * a.state_stride;
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      const bool ok = live && u < H;
+      h[l][T] = ok ? st[(l * 2 + 0) * H + u] : 0.0f;
+      c[l][T] = ok ? st[(l * 2 + 1) * H + u] : 0.0f;
+    }
+  const bool fast = a.fast != 0;
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    for (int ch = 0; ch < in_ch; ch++)
+      for (int r = 0; r < 16; r++)
+      {
+        const int s = __shfl(stream, r);
+        float v = 0.0f;
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
+          v = a.in[((size_t)s * in_ch + ch) * a.io_stride + f0 + lane];
+        xin[(ch * 16 + r) * 65 + lane] = v;
+      }
+    const int xrow = (min(grp, in_ch - 1) * 16 + j) * 65; // lane group g feeds input element g (zero weights beyond I0)
+    float xv = xin[xrow];
+    float x1 = xin[xrow + 1]; // the inputs are read two steps ahead: an LDS round trip per step is not on the chain
+    // where this lane's four head outputs go (rows 4 grp + e of the output tile); lanes without a row write to a pad
+    int yrow[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      yrow[e] = 4 * grp + e < out_ch ? ((4 * grp + e) * 16 + j) * 65 : out_ch * 16 * 65 + lane;
+    const int n_store = min(4, out_ch); // rows 0..n_store-1 exist in lane group 0 (uniform: skips whole stores)
+    // Off the recurrence's critical path: the input half of layer 0 (bias + Wi . x_t) is issued one step ahead, and a
+    // step's output is stored one step later (the store would otherwise sit, in order, behind the head MFMA's result)
+    f4 pre0[NT];
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+      pre0[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], grp < I0 ? xv : 0.0f, bias[0][T], 0, 0, 0);
+    f4 ypend = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nvalid; t++)
+    {
+      const float xnext = x1; // next step's input
+      x1 = xin[xrow + min(t + 2, kBlock - 1)];
+      float hn[NL][NT];
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+      {
+        // the NT unit tiles of a layer are independent: their MFMA chains are issued interleaved (k-step outer,
+        // tile inner) so no MFMA waits on its predecessor, then the gate math of all tiles follows
+        f4 acc[NT];
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+          acc[T] = l == 0 ? pre0[T] : bias[l][T];
+        if (l > 0)
+        {
+#pragma unroll
+          for (int s = 0; s < NT; s++)
+#pragma unroll
+            for (int T = 0; T < NT; T++)
+              acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[l][T][s], hn[l > 0 ? l - 1 : 0][s], acc[T], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < NT; s++)
+#pragma unroll
+          for (int T = 0; T < NT; T++)
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l][T][s], h[l][s], acc[T], 0, 0, 0);
+        if (l == 0)
+        {
+          // next step's input half and the previous step's output store, in the shadow of the MFMAs above
+          const float xn = grp < I0 ? xnext : 0.0f;
+#pragma unroll
+          for (int T = 0; T < NT; T++)
+            pre0[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][T][0], xn, bias[0][T], 0, 0, 0);
+          if (t > 0)
+          {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (e < n_store)
+                yout[yrow[e] + t - 1] = ypend[e];
+          }
+        }
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+        {
+          float cn, hv;
+          if (fast)
+          {
+            cn = mf::fast_sigmoid_hw(acc[T][1]) * c[l][T] + mf::fast_sigmoid_hw(acc[T][0]) * mf::fast_tanh_hw(acc[T][2]);
+            hv = mf::fast_sigmoid_hw(acc[T][3]) * mf::fast_tanh_hw(cn);
+          }
+          else
+          {
+            cn = mf::sigmoid_hw(acc[T][1]) * c[l][T] + mf::sigmoid_hw(acc[T][0]) * mf::tanh_hw(acc[T][2]);
+            hv = mf::sigmoid_hw(acc[T][3]) * mf::tanh_hw(cn);
+          }
+          c[l][T] = cn;
+          hn[l][T] = hv;
+        }
+      }
+      ypend = hbias;
+#pragma unroll
+      for (int s = 0; s < NT; s++)
+        ypend = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], hn[NL - 1][s], ypend, 0, 0, 0);
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+          h[l][T] = hn[l][T];
+      xv = xnext;
+    }
+    if (nvalid > 0)
+    {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (e < n_store)
+          yout[yrow[e] + nvalid - 1] = ypend[e];
+    }
+    if (a.out)
+      for (int ch = 0; ch < out_ch; ch++)
+        for (int r = 0; r < 16; r++)
+        {
+          const int s = __shfl(stream, r);
+          if (s0 + r < a.n_streams && lane < nvalid)
+            a.out[((size_t)s * out_ch + ch) * a.io_stride + f0 + lane] = yout[(ch * 16 + r) * 65 + lane];
+        }
+  }
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+#pragma unroll
+    for (int T = 0; T < NT; T++)
+    {
+      const int u = 4 * T + grp;
+      if (live && u < H)
+      {
+        st[(l * 2 + 0) * H + u] = h[l][T];
+        st[(l * 2 + 1) * H + u] = c[l][T];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// State initialisation
+// ------------------------------------------------------------------------------------------------
+__global__ void nam_fill_state_kernel(float* state, long state_stride, const int* stream_map, int n_streams,
+                                      const float* init, int n_init, int state_floats)
+{
+  // one block per stream; copies `init` (n_init floats) then zero-fills the rest
+  const int stream = stream_map ? stream_map[blockIdx.x] : (int)blockIdx.x;
+  float* st = state + (size_t)stream * state_stride;
+  for (int i = threadIdx.x; i < state_floats; i += blockDim.x)
+    st[i] = (init && i < n_init) ? init[i] : 0.0f;
+}
+
+int lstm_lds_bytes(const LSTMArgs& a)
+{
+  const int floats = (a.in_ch + a.out_ch) * kBlock * 65 + 2 * a.n_layers * a.hidden * kBlock + 4 * a.hidden * kBlock;
+  return floats * (int)sizeof(float);
+}
+
+hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream)
+{
+  const int lds_bytes = lstm_lds_bytes(a);
+  if (lds_bytes > 64 * 1024)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nam_lstm_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess)
+      return e;
+  }
+  const int n_blocks = (a.n_streams + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(nam_lstm_kernel, dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
+{
+  static int lds_limit = 0;
+  if (a.mf_lds_bytes > lds_limit)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nam_lstm_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, a.mf_lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    lds_limit = a.mf_lds_bytes;
+  }
+  const int n_blocks = (a.n_streams + 15) / 16;
+  // small models: everything in registers (only the I/O tiles in LDS)
+  if (a.input_size <= 4 && a.n_layers <= 2 && a.mf_nt <= 6)
+  {
+    // I/O tiles + a pad row that lanes without an output row store to (64 lanes + 64 steps)
+    const int io_bytes = ((a.in_ch + a.out_ch) * 16 * 65 + 128) * (int)sizeof(float);
+#define NAM_LSTM_REG(NL, NT) \
+  hipLaunchKernelGGL((nam_lstm_mfma_reg_kernel<NL, NT>), dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a)
+    const int key = a.n_layers * 10 + a.mf_nt;
+    switch (key)
+    {
+      case 11: NAM_LSTM_REG(1, 1); break;
+      case 12: NAM_LSTM_REG(1, 2); break;
+      case 13: NAM_LSTM_REG(1, 3); break;
+      case 14: NAM_LSTM_REG(1, 4); break;
+      case 21: NAM_LSTM_REG(2, 1); break;
+      case 22: NAM_LSTM_REG(2, 2); break;
+      case 23: NAM_LSTM_REG(2, 3); break;
+      case 24: NAM_LSTM_REG(2, 4); break;
+      case 15: NAM_LSTM_REG(1, 5); break;
+      case 16: NAM_LSTM_REG(1, 6); break;
+      case 25: NAM_LSTM_REG(2, 5); break;
+      default: NAM_LSTM_REG(2, 6); break;
+    }
+#undef NAM_LSTM_REG
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(nam_lstm_mfma_kernel, dim3(n_blocks), dim3(64), a.mf_lds_bytes, stream, a.blob, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,
+                             int n_init, int state_floats, hipStream_t stream)
+{
+  hipLaunchKernelGGL(nam_fill_state_kernel, dim3(n_streams), dim3(256), 0, stream, state, state_stride, stream_map,
+                     n_streams, init, n_init, state_floats);
+  return hipGetLastError();
+}
+
+} // namespace namhip

@@ -1,4 +1,4 @@
-// kernels.h — kernel argument blocks and host-side launch wrappers (kernels.hip).
+// kernels.h — kernel argument blocks and host-side launch wrappers (kernel_*.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
