@@ -61,26 +61,29 @@ __global__ __launch_bounds__(512) void nam_a1_mfma_kernel(const A1Plan* __restri
   const int total_pad = (total + kUnroll - 1) / kUnroll * kUnroll;
   const unsigned lds_tiles_b = (unsigned)a.lds_tiles_b, lds_cond_b = (unsigned)a.lds_cond_b;
 
-  // constants table and extra tiles -> LDS (all 512 threads; visible at the prologue barrier)
+  // constants table and extra tiles -> LDS, by the compute waves only (visible at the prologue barrier): the movers'
+  // prologue is two dependent memory round trips (write positions -> first history sets) and must not queue behind
+  // a third
+  if (w < 4)
   {
     const float* __restrict__ csrc = blob + a.consts_off;
     const float* __restrict__ xsrc = blob + a.xt_off;
-    constexpr int NC = kWsJobMax * 64 / 512, NX = kWsXtMax * 256 / 512;
+    constexpr int NC = kWsJobMax * 64 / 256, NX = kWsXtMax * 256 / 256;
     float cv[NC], xv[NX];
 #pragma unroll
     for (int i = 0; i < NC; i++)
-      cv[i] = csrc[tid + 512 * i]; // the blob tables are padded to their maximum sizes
+      cv[i] = csrc[tid + 256 * i]; // the blob tables are padded to their maximum sizes
 #pragma unroll
     for (int i = 0; i < NX; i++)
-      xv[i] = xsrc[tid + 512 * i];
+      xv[i] = xsrc[tid + 256 * i];
 #pragma unroll
     for (int i = 0; i < NC; i++)
-      if (tid + 512 * i < NJ * 64)
-        lds_f[kWsConstsOff + tid + 512 * i] = cv[i];
+      if (tid + 256 * i < NJ * 64)
+        lds_f[kWsConstsOff + tid + 256 * i] = cv[i];
 #pragma unroll
     for (int i = 0; i < NX; i++)
-      if (tid + 512 * i < a.n_xt * 256)
-        lds_f[a.lds_xt_b / 4 + tid + 512 * i] = xv[i];
+      if (tid + 256 * i < a.n_xt * 256)
+        lds_f[a.lds_xt_b / 4 + tid + 256 * i] = xv[i];
   }
 
   long long bar_cycles = 0, t_begin = 0; // PROF: cycles this wave spent inside barriers / total
