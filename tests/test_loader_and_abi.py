@@ -40,6 +40,18 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
         m.GetLoudness()  # dsp.cpp:121-128
 
 
+@pytest.mark.parametrize("name,bits", [
+    ("wavenet_a1_standard", 3), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
+    ("synth_a1_mixed", 3),  # kernel size 3 everywhere, several arrays: the wave-specialised MFMA kernel
+    ("slimmable_wavenet", 1),  # 3 channels: VALU kernel only
+    ("wavenet_a2_max", 0), ("wavenet_condition_dsp", 0), ("synth_posthead", 0), ("synth_multich", 0),  # generic kernel
+    ("lstm", 0)])
+def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
+    """has_a1_kernel: bit 0 = the VALU A1 kernel, bit 1 = one of the MFMA kernels (plan.cpp: build_a1 / build_a1_ws /
+    build_a1_kt). Decided on the host at load time, so it is checkable without a GPU."""
+    assert nam_lib.get_dsp(model_path(name)).info.has_a1_kernel == bits
+
+
 def test_missing_file_is_validation_error(nam_lib):
     with pytest.raises(nam_lib.NamFileValidationError):
         nam_lib.get_dsp(os.path.join(MODELS, "does_not_exist.nam"))
