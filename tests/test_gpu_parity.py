@@ -2,6 +2,8 @@
 seeded inputs. Tolerances follow the reference's own alt-implementation precedent
 (tools/test/test_a2_fast.cpp:296-298: max-abs 5e-5) — 5e-5 with fast_tanh (a pure rational
 function), 1e-4 with libm tanh / expf (device vs host transcendental ulp differences)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -118,6 +120,18 @@ def test_ktap_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh):
     refs = [_oracle_run(oracle, name, x[s, :64 * 6], block, fast_tanh) for s in range(n_streams)]
     for s in range(n_streams):
         assert float(np.max(np.abs(refs[s] - y[s]))) <= _tol(fast_tanh) * max(1.0, float(np.max(np.abs(refs[s]))))
+
+
+def test_fuzzed_models_all_kernels(nam_lib, oracle):
+    """tools/fuzz_models.py: 18 seeded random A1-family models (random kernel sizes 1..16, dilations up to 512, head
+    taps, channel counts, activations, array counts) through every kernel that accepts them, block launches and one
+    multi-block launch, against the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "18", "23"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "FUZZ OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_lstm_matches_oracle(nam_lib, oracle):
