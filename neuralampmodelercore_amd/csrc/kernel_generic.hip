@@ -208,18 +208,41 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
         {
           const float p0 = blob[op.w], p1 = blob[op.w + 1], p2 = blob[op.w + 2], p3 = blob[op.w + 3];
           const int ns = op.ring;
-          for (int c = 0; c < op.cout; c++)
-          {
-            float slope = 0.0f;
-            if (op.k == ACT_PRELU)
+          // one dispatch per op, not per channel row (the compare cascade of d_act_rt is ~25 scalar instructions)
+          auto rows = [&](auto type_tag) {
+            constexpr int T = decltype(type_tag)::value;
+            for (int c = 0; c < op.cout; c++)
             {
-              // Activation::apply(float*, size) on column-major data: slopes[pos % n] (activations.h:283-297)
-              const long pos = (long)(f0 + lane) * op.cout + c;
-              slope = blob[op.w + 4 + (int)(pos % ns)];
+              float slope = 0.0f;
+              if constexpr (T == ACT_PRELU)
+              {
+                // Activation::apply(float*, size) on column-major data: slopes[pos % n] (activations.h:283-297)
+                const long pos = (long)(f0 + lane) * op.cout + c;
+                slope = blob[op.w + 4 + (int)(pos % ns)];
+              }
+              const float x = lds[op.dst + c * kBlock + lane];
+              lds[op.dst + c * kBlock + lane] = d_act<T>(x, p0, p1, p2, p3, slope);
             }
-            const float x = lds[op.dst + c * kBlock + lane];
-            lds[op.dst + c * kBlock + lane] = d_act_rt(op.k, x, p0, p1, p2, p3, slope);
+          };
+#define NAM_ACT_ROWS(T) \
+  case T: rows(std::integral_constant<int, T>{}); break;
+          switch (op.k)
+          {
+            NAM_ACT_ROWS(ACT_TANH)
+            NAM_ACT_ROWS(ACT_HARDTANH)
+            NAM_ACT_ROWS(ACT_FASTTANH)
+            NAM_ACT_ROWS(ACT_RELU)
+            NAM_ACT_ROWS(ACT_LEAKYRELU)
+            NAM_ACT_ROWS(ACT_PRELU)
+            NAM_ACT_ROWS(ACT_SIGMOID)
+            NAM_ACT_ROWS(ACT_SILU)
+            NAM_ACT_ROWS(ACT_HARDSWISH)
+            NAM_ACT_ROWS(ACT_LEAKYHARDTANH)
+            NAM_ACT_ROWS(ACT_SOFTSIGN)
+            NAM_ACT_ROWS(ACT_FASTSIGMOID)
+            default: break; // identity
           }
+#undef NAM_ACT_ROWS
           break;
         }
         case OP_GATE:
