@@ -120,10 +120,29 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
       for (int j = 0; j < CB; j++)
         acc[j] += WLDS ? wlds[op.b + co0 + j] : bias[j];
     }
+    if (op.flag)
+    {
+      // FiLM epilogue (film.h:76-204): the block holds the scales of `per` channels, then (flag 2) their shifts
+      const int per = op.flag == 2 ? CB / 2 : CB;
+      const int c0 = co0 / CB * per;
+      const float* xs = lds + op.aux;
 #pragma unroll
-    for (int j = 0; j < CB; j++)
-      if (co0 + j < cout)
-        dst[(co0 + j) * kBlock + lane] = acc[j];
+      for (int j = 0; j < CB; j++)
+        if (j < per && c0 + j < cout)
+        {
+          float y = xs[(c0 + j) * kBlock + lane] * acc[j];
+          if (op.flag == 2)
+            y += acc[(j + CB / 2) % CB];
+          dst[(c0 + j) * kBlock + lane] = y;
+        }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < CB; j++)
+        if (co0 + j < cout)
+          dst[(co0 + j) * kBlock + lane] = acc[j];
+    }
   }
   if (has_ring)
   {

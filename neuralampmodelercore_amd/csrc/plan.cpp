@@ -106,19 +106,42 @@ struct Builder
   }
 
   // FiLM (film.h:76-204): scale/shift = Conv1x1(cond) + bias; dst = src * scale (+ shift)
+  // Emitted as ONE op: a 1x1 OP_CONV over the condition rows whose epilogue applies the scale (and shift) to the
+  // rows `src` instead of storing them (`flag` 1 = scale, 2 = scale + shift; `aux` = src). The output channels are
+  // re-ordered so that a register block of `cb` accumulators holds the scales of cb/2 channels followed by their
+  // shifts (all cb are scales without a shift): no scale/shift rows in LDS, no separate OP_FILM.
   void film(const float*& w, const FilmSpec& f, int dst, int src, int cond, int cond_dim, int dim)
   {
-    const int m = rows.mark();
-    const int ss_rows = (f.shift ? 2 : 1) * dim;
-    const int ss = rows.alloc(ss_rows);
-    conv(w, ss, cond, cond_dim, ss_rows, 1, 1, f.groups, true);
-    NamOp& op = push(OP_FILM);
+    const int cout = (f.shift ? 2 : 1) * dim;
+    const int cb = (cout >= 8) ? 8 : 4;
+    const int per = f.shift ? cb / 2 : cb; // channels per register block
+    const int cout_pad = (dim + per - 1) / per * cb;
+    auto col = [&](int o) {
+      const int c = o < dim ? o : o - dim;
+      return (c / per) * cb + (o < dim ? 0 : per) + c % per;
+    };
+    const int woff = blob_reserve((size_t)cond_dim * cout_pad);
+    const int opg = cout / f.groups, ipg = cond_dim / f.groups;
+    for (int g = 0; g < f.groups; g++)
+      for (int i = 0; i < opg; i++)
+        for (int j = 0; j < ipg; j++)
+          plan.blob[(size_t)woff + (size_t)(g * ipg + j) * cout_pad + col(g * opg + i)] = *(w++);
+    const int boff = blob_reserve((size_t)cout_pad);
+    for (int i = 0; i < cout; i++)
+      plan.blob[(size_t)boff + col(i)] = *(w++);
+    NamOp& op = push(OP_CONV);
     op.dst = dst;
-    op.src = src;
-    op.aux = ss;
-    op.cout = dim;
-    op.flag = f.shift ? 1 : 0;
-    rows.release(m);
+    op.src = cond;
+    op.aux = src;
+    op.cin = cond_dim;
+    op.cout = dim; // rows written
+    op.cout_pad = cout_pad;
+    op.cb = cb;
+    op.w = woff;
+    op.b = boff;
+    op.k = 1;
+    op.dil = 1;
+    op.flag = f.shift ? 2 : 1;
   }
 
   int act_params(const ActSpec& a)
