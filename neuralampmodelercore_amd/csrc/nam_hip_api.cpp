@@ -231,7 +231,11 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
       a.n_mjobs = a.tiles_off = a.consts_off = 0;
       a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = a.prefetch = 0;
-      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok)
+      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && n_frames > (1 << 28))
+        // the K-tap kernel addresses the launch's input through a 32-bit buffer descriptor (1 GiB of float32 audio per
+        // stream and launch): longer launches take the VALU kernel, same state layout
+        NAM_HIP_CHECK(launch_a1(a, n, s));
+      else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok)
         // single-array models with other kernel sizes than 3 (A2): the K-tap MFMA kernel
         NAM_HIP_CHECK(launch_kt_mfma(a, n, p.a1.kt_nk, p.a1.arr[0].channels, p.a1.kt_lds_floats, p.a1.arr[0].act, s));
       else if (kernel == NAM_HIP_KERNEL_A1_MFMA)
