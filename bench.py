@@ -51,6 +51,27 @@ def wavenet_history_bytes_per_sample(cfg: dict) -> int:
     return total
 
 
+LDS_PEAK_GBS = 150000.0  # MI355X_MICROARCH.md, LDS section: ~150 TB/s aggregate for ds_read_b64 / b128 at 2.4 GHz
+
+
+def mfma_lds_bytes_per_stream_block(cfg: dict) -> int:
+    """Bytes that nam_a1_mfma_kernel's LDS instructions move per stream and 64-frame block, counted from the kernel's
+    per-job structure, not from a counter. Per layer job, 256 compute lanes: two shifted-tap reads
+    (16 B full layout, 8 B half layout = 8 channels), the input sample (4 B), nine 16-byte operand reads (four weight
+    tiles, extra tile, four constant vectors), one 16-byte publish by the lanes that own a channel quad; 256 mover
+    lanes: 16-byte ring-append read, two 16-byte history-set drops, one 16-byte tile drop."""
+    total = 0
+    for lc in cfg["layers"]:
+        C = lc["channels"]
+        half = C == 8
+        quads = (C + 3) // 4
+        per_lane_compute = 2 * (8 if half else 16) + 4 + 9 * 16
+        publish = 64 * quads * 16
+        movers = 64 * quads * 16 + 256 * (2 * 16 + 16)
+        total += len(lc["dilations"]) * (256 * per_lane_compute + publish + movers)
+    return total
+
+
 def measured_traffic(kernel: str, streams: int, block: int, launch: str):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), if the
     profiled configuration matches this run."""
@@ -372,6 +393,13 @@ def main():
                 "note": f"algorithmic {bytes_per_sample} B/stream-sample ({hist} history + {4 * (ic + oc)} I/O) x "
                         f"{samples_per_launch} stream-samples per launch; avg launch {avg_launch_s * 1e6:.2f} us from HIP "
                         "events on the launch stream",
+                "lds": (None if kname != "a1_mfma" or mj["architecture"] != "WaveNet" or args.model != "wavenet_a1_standard" else {
+                    "achieved": round(mfma_lds_bytes_per_stream_block(mj["config"]) * n_streams
+                                      * (1 if args.launch == "block" else K) / avg_launch_s / 1e9, 1),
+                    "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(mfma_lds_bytes_per_stream_block(mj["config"]) * n_streams
+                                  * (1 if args.launch == "block" else K) / avg_launch_s / 1e9 / LDS_PEAK_GBS, 4),
+                    "note": "bytes moved by the kernel's LDS instructions, counted from its per-job structure (not a counter)"}),
                 "compute": {"achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
                             "note": f"{flops_per_sample} FLOP/stream-sample; fp32 MFMA peak == fp32 vector peak"},
