@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_kernel(const float* __restri
 // The same kernel for small models (<= 2 layers, <= 24 hidden units, <= 4 inputs), fully unrolled: every A
 // tile value, bias, h and c of the lane stays in registers for the whole launch; per sample only the input is
 // read from LDS and the output written to it. lstm.nam: ~0.2 us per sample step instead of ~0.9.
-template <int NL, int NT>
+template <int NL, int NT, bool FAST>
 __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __restrict__ blob, const LSTMArgs a)
 {
   using mf::f4;
@@ -298,7 +298,6 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
       h[l][T] = ok ? st[(l * 2 + 0) * H + u] : 0.0f;
       c[l][T] = ok ? st[(l * 2 + 1) * H + u] : 0.0f;
     }
-  const bool fast = a.fast != 0;
   for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
   {
     const int nvalid = min(kBlock, a.n_frames - f0);
@@ -373,10 +372,17 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
         for (int T = 0; T < NT; T++)
         {
           float cn, hv;
-          if (fast)
+          if constexpr (FAST)
           {
-            cn = mf::fast_sigmoid_hw(acc[T][1]) * c[l][T] + mf::fast_sigmoid_hw(acc[T][0]) * mf::fast_tanh_hw(acc[T][2]);
-            hv = mf::fast_sigmoid_hw(acc[T][3]) * mf::fast_tanh_hw(cn);
+            // fast_sigmoid(x) = 0.5 (fast_tanh(x / 2) + 1): the four gates are one 4-wide fast_tanh (same operations
+            // per element as the scalar forms, so the same bits; the compiler pairs them into packed instructions)
+            const f4 q = {0.5f * acc[T][0], 0.5f * acc[T][1], acc[T][2], 0.5f * acc[T][3]};
+            f4 t;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              t[e] = mf::fast_tanh_hw(q[e]);
+            cn = (0.5f * (t[1] + 1.0f)) * c[l][T] + (0.5f * (t[0] + 1.0f)) * t[2];
+            hv = (0.5f * (t[3] + 1.0f)) * mf::fast_tanh_hw(cn);
           }
           else
           {
@@ -480,7 +486,10 @@ hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
     // I/O tiles + a pad row that lanes without an output row store to (64 lanes + 64 steps)
     const int io_bytes = ((a.in_ch + a.out_ch) * 16 * 65 + 128) * (int)sizeof(float);
 #define NAM_LSTM_REG(NL, NT) \
-  hipLaunchKernelGGL((nam_lstm_mfma_reg_kernel<NL, NT>), dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a)
+  if (a.fast) \
+    hipLaunchKernelGGL((nam_lstm_mfma_reg_kernel<NL, NT, true>), dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a); \
+  else \
+    hipLaunchKernelGGL((nam_lstm_mfma_reg_kernel<NL, NT, false>), dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a)
     const int key = a.n_layers * 10 + a.mf_nt;
     switch (key)
     {
