@@ -935,6 +935,78 @@ void build_a1_kt(Plan& plan)
   a1.kt_ok = 1;
 }
 
+// The official "lite" size (12 -> 6 channels) misses the matrix-core kernel only because 6 is not a multiple of 4.
+// Zero-padding such arrays to the next multiple (weights, biases, mixin, rechannels all zero for the extra channels)
+// is exact on the real channels: the padded ones carry f(0) through the activations and meet zero weights everywhere.
+// Returns false when the model is not a plain kernel-size-3 WaveNet that padding would help.
+bool pad_channels_for_mfma(const WaveNetSpec& wn, WaveNetSpec& out)
+{
+  if (wn.condition_dsp || wn.with_head || wn.in_channels != 1 || wn.slimmable || wn.arrays.empty())
+    return false;
+  auto up4 = [](int c) { return (c + 3) / 4 * 4; };
+  bool any = false;
+  for (const LayerArraySpec& A : wn.arrays)
+  {
+    if (A.channels < 6 || A.channels > 16 || A.channels % 2 || A.bottleneck != A.channels || A.condition_size != 1
+        || A.groups_input != 1 || A.groups_input_mixin != 1 || !A.layer1x1_active || A.layer1x1_groups != 1
+        || A.head1x1_active || A.head_kernel_size != 1)
+      return false;
+    for (int k : A.kernel_sizes)
+      if (k != 3)
+        return false;
+    for (int g : A.gating_modes)
+      if (g != GATING_NONE)
+        return false;
+    for (int k = 0; k < FILM_COUNT; k++)
+      if (A.film[k].active)
+        return false;
+    any = any || A.channels % 4 != 0;
+  }
+  if (!any)
+    return false;
+  out = wn;
+  out.weights.clear();
+  const float* w = wn.weights.data();
+  const size_t n_arr = wn.arrays.size();
+  for (size_t ai = 0; ai < n_arr; ai++)
+  {
+    const LayerArraySpec& A = wn.arrays[ai];
+    LayerArraySpec& P = out.arrays[ai];
+    const int C = A.channels, Cp = up4(C);
+    const int in = A.input_size, inp = ai == 0 ? in : up4(wn.arrays[ai - 1].channels);
+    const int H = A.head_size, Hp = ai + 1 < n_arr ? up4(wn.arrays[ai + 1].channels) : H;
+    if (ai > 0 && in != wn.arrays[ai - 1].channels)
+      return false;
+    if (ai + 1 < n_arr && H != wn.arrays[ai + 1].channels)
+      return false;
+    P.channels = P.bottleneck = Cp;
+    P.input_size = inp;
+    P.head_size = Hp;
+    // tensor [rows][cols][taps] of the stream, zero-padded to [rows_p][cols_p][taps]
+    auto tensor = [&](int rows, int cols, int taps, int rows_p, int cols_p) {
+      for (int r = 0; r < rows_p; r++)
+        for (int c = 0; c < cols_p; c++)
+          for (int k = 0; k < taps; k++)
+            out.weights.push_back(r < rows && c < cols ? w[((size_t)r * cols + c) * taps + k] : 0.0f);
+      w += (size_t)rows * cols * taps;
+    };
+    tensor(C, in, 1, Cp, inp); // rechannel [C][in]
+    for (int l = 0; l < A.num_layers(); l++)
+    {
+      tensor(C, C, A.kernel_sizes[l], Cp, Cp); // conv [co][ci][k]
+      tensor(C, 1, 1, Cp, 1); // conv bias
+      tensor(C, 1, 1, Cp, 1); // input mixin [C][1]
+      tensor(C, C, 1, Cp, Cp); // layer1x1 [co][ci]
+      tensor(C, 1, 1, Cp, 1); // its bias
+    }
+    tensor(H, C, 1, Hp, Cp); // head rechannel [H][C]
+    if (A.head_bias)
+      tensor(H, 1, 1, Hp, 1);
+  }
+  out.weights.push_back(*(w++)); // head_scale
+  return w == wn.weights.data() + wn.weights.size();
+}
+
 } // namespace
 
 Plan build_wavenet_plan(const WaveNetSpec& wn)
@@ -971,7 +1043,35 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
   plan.state_floats = (table + b.state_floats + kBlock - 1) / kBlock * kBlock;
   if (plan.state_floats == 0)
     plan.state_floats = kBlock;
-  build_a1(wn, plan);
+  {
+    // matrix-core kernel through zero-padded channels (lite: 12 -> 6 becomes 12 -> 8) when that makes it eligible;
+    // the A1 kernels then share the padded ring layout, the generic kernel keeps the model's own
+    WaveNetSpec padded;
+    const size_t blob_mark = plan.blob.size();
+    bool use_padded = false;
+    if (pad_channels_for_mfma(wn, padded))
+    {
+      build_a1(padded, plan);
+      use_padded = plan.a1.valid && plan.a1.ws_ok;
+      if (!use_padded)
+      {
+        plan.blob.resize(blob_mark);
+        plan.a1 = A1Plan{};
+      }
+    }
+    if (!use_padded)
+      build_a1(wn, plan);
+    else
+    {
+      // the padded rings are longer rows: make sure the per-stream state covers them
+      int need = 0;
+      for (int a = 0; a < plan.a1.n_arrays; a++)
+        for (int l = 0; l < plan.a1.arr[a].n_layers; l++)
+          if (plan.a1.arr[a].ring_id[l] >= 0)
+            need = std::max(need, plan.a1.arr[a].ring_off[l] + plan.a1.arr[a].channels * plan.a1.arr[a].ring_len[l]);
+      plan.state_floats = std::max(plan.state_floats, (table + need + kBlock - 1) / kBlock * kBlock);
+    }
+  }
   if (plan.a1.valid)
   {
     for (int a = 0; a < plan.a1.n_arrays; a++)

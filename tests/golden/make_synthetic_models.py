@@ -25,6 +25,12 @@ SPECS = {
     # two 8-channel arrays: half layout through X0, PRE_HEAD (previous half) and POST_RECH; 10 jobs, depth 5
     "synth_a1_c8": dict(arrays=[(8, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 256, 512], "Tanh", True)], seed=13),
     # mixed activations -> run-time dispatch; three arrays (16 -> 8 -> 4); 15 layers -> 16 jobs
+    # the official "lite" shape: 12 -> 6 channels, ten layers each; 6 is not a multiple of 4 — the plan compiler
+    # zero-pads it to 8 for the A1 kernels (plan.cpp: pad_channels_for_mfma)
+    "synth_a1_lite": dict(arrays=[(12, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
+                                  (6, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=15),
+    # 14 -> 10 channels (padded to 16 -> 12), Sigmoid: the padded channels carry f(0) = 0.5 against zero weights
+    "synth_a1_c14": dict(arrays=[(14, [1, 2, 4, 8, 16, 32], "Sigmoid", True), (10, [64, 128, 256, 512, 1, 2], "Sigmoid", True)], seed=16),
     "synth_a1_mixed": dict(arrays=[(16, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 1, 2], "ReLU", True),
                                    (4, [4, 8, 16, 32, 64], "Sigmoid", True)], seed=14),
 }

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet"]
 # synthetic A1-family fixtures (tests/golden/make_synthetic_models.py) that reach the MFMA kernel's variants
-SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed"]
+SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed", "synth_a1_lite", "synth_a1_c14"]
 # single-array fixtures with per-layer kernel sizes 1..16 and a head rechannel with taps: the K-tap MFMA kernel
 SYNTH_KT = ["synth_kt_c8", "synth_kt_c16", "synth_kt_c12", "synth_kt_c4"]
 

@@ -43,6 +43,7 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
 @pytest.mark.parametrize("name,bits", [
     ("wavenet_a1_standard", 3), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
     ("synth_a1_mixed", 3),  # kernel size 3 everywhere, several arrays: the wave-specialised MFMA kernel
+    ("synth_a1_lite", 3), ("synth_a1_c14", 3),  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for it
     ("slimmable_wavenet", 1),  # 3 channels: VALU kernel only
     ("wavenet_a2_max", 0), ("wavenet_condition_dsp", 0), ("synth_posthead", 0), ("synth_multich", 0),  # generic kernel
     ("lstm", 0)])
