@@ -947,7 +947,8 @@ bool pad_channels_for_mfma(const WaveNetSpec& wn, WaveNetSpec& out)
   bool any = false;
   for (const LayerArraySpec& A : wn.arrays)
   {
-    if (A.channels < 6 || A.channels > 16 || A.channels % 2 || A.bottleneck != A.channels || A.condition_size != 1
+    // (1-3 channels stay as they are: for models that small the VALU kernel is the better one once the chip is full)
+    if ((A.channels % 4 != 0 && A.channels < 5) || A.channels > 16 || A.bottleneck != A.channels || A.condition_size != 1
         || A.groups_input != 1 || A.groups_input_mixin != 1 || !A.layer1x1_active || A.layer1x1_groups != 1
         || A.head1x1_active || A.head_kernel_size != 1)
       return false;

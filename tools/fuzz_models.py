@@ -35,7 +35,7 @@ def random_multi(rng, tmp, idx):
     n_arr = int(rng.integers(2, 4))
     arrays = []
     for a in range(n_arr):
-        C = int(rng.choice([4, 8, 12, 16]))
+        C = int(rng.choice([4, 8, 12, 16, 5, 6, 7, 10, 14]))  # not a multiple of 4: zero-padded at plan time
         n_layers = int(rng.integers(3, 8))
         dl = [int(rng.choice([1, 2, 3, 4, 8, 16, 32, 33, 64, 100, 128, 256, 512])) for _ in range(n_layers)]
         arrays.append((C, dl, ["Tanh", "ReLU", "Sigmoid"][int(rng.integers(3))], bool(rng.integers(2))))
