@@ -92,6 +92,28 @@ NAM_HIP_API const char* nam_hip_last_error(void);
  * and LSTM cells use fast_sigmoid / fast_tanh (lstm.cpp:48-58). */
 NAM_HIP_API int nam_hip_model_load(const char* nam_path, int fast_tanh, nam_hip_model** out_model);
 NAM_HIP_API int nam_hip_model_load_json(const char* json_text, int fast_tanh, nam_hip_model** out_model);
+
+/* Everything the reference keeps in process-globals around get_dsp, as explicit load options:
+ *   fast_tanh  Activation::enable_fast_tanh()                       NAM/activations.cpp:168-177
+ *   luts       Activation::enable_lut(function_name, min, max, n)   NAM/activations.cpp:189-212: "Tanh", "Sigmoid" or
+ *              "SiLU" layers of the model use FastLUTActivation (NAM/activations.h:371-422: clamp, linear
+ *              interpolation in a table of n points built with the host's libm). A table wins over fast_tanh, as it
+ *              does when enable_lut is called after enable_fast_tanh. Any other name fails with the reference's message.
+ * Exactly one of nam_path / json_text must be non-NULL; options == NULL means all defaults. */
+typedef struct nam_hip_lut
+{
+  const char* function_name;
+  float min_x, max_x;
+  int32_t n_points;
+} nam_hip_lut;
+typedef struct nam_hip_load_options
+{
+  int32_t fast_tanh;
+  int32_t n_luts;
+  const nam_hip_lut* luts;
+} nam_hip_load_options;
+NAM_HIP_API int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam_hip_load_options* options,
+                                      nam_hip_model** out_model);
 NAM_HIP_API void nam_hip_model_free(nam_hip_model* model);
 NAM_HIP_API int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info);
 

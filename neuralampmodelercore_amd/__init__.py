@@ -29,7 +29,8 @@ ERR_INVALID_ARGUMENT, ERR_FILE, ERR_MODEL, ERR_UNSUPPORTED, ERR_DEVICE, ERR_TOO_
 
 # every symbol include/nam_hip.h declares (tests check the built library exports exactly these)
 ABI_SYMBOLS = [
-    "nam_hip_last_error", "nam_hip_version", "nam_hip_model_load", "nam_hip_model_load_json", "nam_hip_model_free",
+    "nam_hip_last_error", "nam_hip_version", "nam_hip_model_load", "nam_hip_model_load_json", "nam_hip_model_load_ex",
+    "nam_hip_model_free",
     "nam_hip_model_get_info", "nam_hip_model_slimmable_breakpoints", "nam_hip_batch_create", "nam_hip_batch_destroy",
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
     "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_render_f32", "nam_hip_batch_synchronize",
@@ -59,6 +60,15 @@ class _Info(ctypes.Structure):
         ("output_level", ctypes.c_double), ("num_weights", ctypes.c_int64), ("fast_tanh", ctypes.c_int32),
         ("has_a1_kernel", ctypes.c_int32), ("state_bytes_per_stream", ctypes.c_int64), ("version", ctypes.c_char * 32),
     ]
+
+
+class _Lut(ctypes.Structure):
+    _fields_ = [("function_name", ctypes.c_char_p), ("min_x", ctypes.c_float), ("max_x", ctypes.c_float),
+                ("n_points", ctypes.c_int32)]
+
+
+class _LoadOptions(ctypes.Structure):
+    _fields_ = [("fast_tanh", ctypes.c_int32), ("n_luts", ctypes.c_int32), ("luts", ctypes.POINTER(_Lut))]
 
 
 def lib_path() -> str:
@@ -108,6 +118,7 @@ def load_library():
     L.nam_hip_version.restype = ctypes.c_char_p
     L.nam_hip_model_load.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
     L.nam_hip_model_load_json.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+    L.nam_hip_model_load_ex.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_LoadOptions), ctypes.POINTER(vp)]
     L.nam_hip_model_free.argtypes = [vp]
     L.nam_hip_model_free.restype = None
     L.nam_hip_model_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
@@ -327,16 +338,34 @@ class Batch:
         return out
 
 
-def get_dsp(path: str, fast_tanh: bool = False) -> Model:
-    """nam::get_dsp(path). ``fast_tanh`` mirrors Activation::enable_fast_tanh() before loading."""
+def _load_ex(path, text, fast_tanh, luts) -> "Model":
+    L = load_library()
+    h = ctypes.c_void_p()
+    items = list((luts or {}).items())
+    arr = (_Lut * max(len(items), 1))()
+    for i, (name, (lo, hi, n)) in enumerate(items):
+        arr[i] = _Lut(name.encode(), float(lo), float(hi), int(n))
+    opts = _LoadOptions(1 if fast_tanh else 0, len(items), arr)
+    _check(L.nam_hip_model_load_ex(os.fsencode(path) if path is not None else None,
+                                   text.encode("utf-8") if text is not None else None, ctypes.byref(opts), ctypes.byref(h)))
+    return Model(h.value)
+
+
+def get_dsp(path: str, fast_tanh: bool = False, luts=None) -> Model:
+    """nam::get_dsp(path). ``fast_tanh`` mirrors Activation::enable_fast_tanh() before loading; ``luts`` =
+    {"Tanh" | "Sigmoid" | "SiLU": (min, max, n_points)} mirrors Activation::enable_lut(...) (activations.cpp:189-212)."""
+    if luts:
+        return _load_ex(path, None, fast_tanh, luts)
     L = load_library()
     h = ctypes.c_void_p()
     _check(L.nam_hip_model_load(os.fsencode(path), 1 if fast_tanh else 0, ctypes.byref(h)))
     return Model(h.value)
 
 
-def get_dsp_json(text: str, fast_tanh: bool = False) -> Model:
+def get_dsp_json(text: str, fast_tanh: bool = False, luts=None) -> Model:
     """nam::get_dsp(json)."""
+    if luts:
+        return _load_ex(None, text, fast_tanh, luts)
     L = load_library()
     h = ctypes.c_void_p()
     _check(L.nam_hip_model_load_json(text.encode("utf-8"), 1 if fast_tanh else 0, ctypes.byref(h)))

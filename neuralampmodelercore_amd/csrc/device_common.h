@@ -73,7 +73,24 @@ __device__ __forceinline__ float d_act(float x, float p0, float p1, float p2, fl
     return x;
 }
 
-// run-time (wave-uniform) dispatch
+// FastLUTActivation::lookup (NAM/activations.h:391-409): clamp, index, linear interpolation. `tbl` points at the
+// activation's parameter block in the blob: min_x, max_x, inv_step, n_points, then the table itself.
+__device__ __forceinline__ float d_lut(const float* __restrict__ tbl, float x)
+{
+  const float min_x = tbl[0], max_x = tbl[1], inv_step = tbl[2];
+  const unsigned n = (unsigned)tbl[3];
+  x = x < min_x ? min_x : (x > max_x ? max_x : x);
+  const float f_idx = (x - min_x) * inv_step;
+  const unsigned i = (unsigned)f_idx;
+  if (i >= n - 1u)
+    return tbl[4 + n - 1u];
+  const float frac = f_idx - (float)i;
+  const float y0 = tbl[4 + i], y1 = tbl[5 + i];
+  return y0 + (y1 - y0) * frac;
+}
+
+// run-time (wave-uniform) dispatch. An activation type a kernel does not know must never fall through to identity:
+// it traps (the host-side eligibility checks in plan.cpp are the only other guard).
 __device__ __forceinline__ float d_act_rt(int type, float x, float p0, float p1, float p2, float p3, float slope)
 {
   switch (type)
@@ -90,7 +107,8 @@ __device__ __forceinline__ float d_act_rt(int type, float x, float p0, float p1,
     case ACT_LEAKYHARDTANH: return d_act<ACT_LEAKYHARDTANH>(x, p0, p1, p2, p3, slope);
     case ACT_SOFTSIGN: return d_act<ACT_SOFTSIGN>(x, p0, p1, p2, p3, slope);
     case ACT_FASTSIGMOID: return d_act<ACT_FASTSIGMOID>(x, p0, p1, p2, p3, slope);
-    default: return x;
+    case ACT_IDENTITY: return x;
+    default: __builtin_trap(); return x;
   }
 }
 
@@ -163,7 +181,8 @@ __device__ __forceinline__ float act_hw(int type, float x, float p0)
       return x * t * (1.0f / 6.0f);
     }
     case ACT_SOFTSIGN: return x * rcp(1.0f + fabsf(x));
-    default: return x;
+    case ACT_IDENTITY: return x;
+    default: __builtin_trap(); return x; // unknown type: never a silent identity (plan.cpp gates what reaches here)
   }
 }
 // whole-vector activation; ACT_T >= 0 resolves the type at compile time (the two kernels that matter:
@@ -209,7 +228,8 @@ __device__ __forceinline__ f4 act4(int type, const f4& v, float p0)
       NAM_ACT4_CASE(ACT_SILU)
       NAM_ACT4_CASE(ACT_HARDSWISH)
       NAM_ACT4_CASE(ACT_SOFTSIGN)
-      default: r = v; break;
+      case ACT_IDENTITY: r = v; break;
+      default: __builtin_trap(); r = v; break;
     }
 #undef NAM_ACT4_CASE
   }

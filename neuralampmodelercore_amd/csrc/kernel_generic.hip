@@ -259,7 +259,12 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
             NAM_ACT_ROWS(ACT_LEAKYHARDTANH)
             NAM_ACT_ROWS(ACT_SOFTSIGN)
             NAM_ACT_ROWS(ACT_FASTSIGMOID)
-            default: break; // identity
+            case ACT_LUT: // FastLUTActivation: table behind the four parameters (device_common.h: d_lut)
+              for (int c = 0; c < op.cout; c++)
+                lds[op.dst + c * kBlock + lane] = d_lut(blob + op.w, lds[op.dst + c * kBlock + lane]);
+              break;
+            case ACT_IDENTITY: break;
+            default: __builtin_trap(); break;
           }
 #undef NAM_ACT_ROWS
           break;
@@ -276,8 +281,8 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
             const float gin = lds[op.dst + (c + B) * kBlock + lane];
             const float s1 = (op.k == ACT_PRELU) ? blob[op.w + 4 + c % op.ring] : 0.0f;
             const float s2 = (op.dil == ACT_PRELU) ? blob[op.b + 4 + c % op.ring_id] : 0.0f;
-            const float av = d_act_rt(op.k, pre, a0, a1, a2, a3, s1);
-            const float gv = d_act_rt(op.dil, gin, g0, g1, g2, g3, s2);
+            const float av = op.k == ACT_LUT ? d_lut(blob + op.w, pre) : d_act_rt(op.k, pre, a0, a1, a2, a3, s1);
+            const float gv = op.dil == ACT_LUT ? d_lut(blob + op.b, gin) : d_act_rt(op.dil, gin, g0, g1, g2, g3, s2);
             lds[op.dst + c * kBlock + lane] = (op.flag == GATING_GATED) ? av * gv : gv * av + (1.0f - gv) * pre;
           }
           break;

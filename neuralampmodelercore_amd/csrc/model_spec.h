@@ -38,14 +38,30 @@ enum ActType : int
   ACT_LEAKYHARDTANH = 10,
   ACT_SOFTSIGN = 11,
   // LSTM-only helper (activations::fast_sigmoid, NAM/activations.h:100-103)
-  ACT_FASTSIGMOID = 12
+  ACT_FASTSIGMOID = 12,
+  // FastLUTActivation (NAM/activations.h:371-422): p = {min_x, max_x, inv_step, n_points}, `slopes` = the table
+  ACT_LUT = 13
 };
 
 struct ActSpec
 {
   int type = ACT_IDENTITY;
   float p[4] = {0, 0, 0, 0}; // LeakyReLU: p[0]; LeakyHardtanh: min_val,max_val,min_slope,max_slope
-  std::vector<float> slopes; // PReLU
+  std::vector<float> slopes; // PReLU slopes; ACT_LUT: the lookup table
+};
+
+// Activation::enable_lut(function_name, min, max, n_points) — NAM/activations.cpp:189-212 — as a load option
+struct LutSpec
+{
+  int act_type = 0; // ACT_TANH, ACT_SIGMOID or ACT_SILU (the only three the reference accepts)
+  float min_x = 0.0f, max_x = 0.0f;
+  int n_points = 0;
+};
+// What the reference keeps in process-globals around get_dsp (activations.cpp:168-212), as explicit load options
+struct LoadOptions
+{
+  bool fast_tanh = false;
+  std::vector<LutSpec> luts;
 };
 
 enum GatingMode : int
@@ -176,8 +192,8 @@ struct ModelSpec
 
 // ---- loader entry points (nam_loader.cpp) ----
 // nam::get_dsp(path) front half: validate_nam_file + populate_dsp_data + config parse.
-std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, bool fast_tanh);
-std::shared_ptr<ModelSpec> load_nam_text(const std::string& json_text, bool fast_tanh);
+std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, const LoadOptions& lo);
+std::shared_ptr<ModelSpec> load_nam_text(const std::string& json_text, const LoadOptions& lo);
 
 // Slimmable helpers (slimmable.cpp:80-294)
 int ratio_to_channels(double ratio, const std::vector<int>& allowed);

@@ -448,7 +448,9 @@ int nam_hip_model_load(const char* nam_path, int fast_tanh, nam_hip_model** out_
   if (!nam_path || !out_model)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_load: null argument");
   *out_model = nullptr;
-  return guarded([&]() { return build_model(load_nam_file(nam_path, fast_tanh != 0), out_model); });
+  LoadOptions lo;
+  lo.fast_tanh = fast_tanh != 0;
+  return guarded([&]() { return build_model(load_nam_file(nam_path, lo), out_model); });
 }
 
 int nam_hip_model_load_json(const char* json_text, int fast_tanh, nam_hip_model** out_model)
@@ -456,7 +458,49 @@ int nam_hip_model_load_json(const char* json_text, int fast_tanh, nam_hip_model*
   if (!json_text || !out_model)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_load_json: null argument");
   *out_model = nullptr;
-  return guarded([&]() { return build_model(load_nam_text(json_text, fast_tanh != 0), out_model); });
+  LoadOptions lo;
+  lo.fast_tanh = fast_tanh != 0;
+  return guarded([&]() { return build_model(load_nam_text(json_text, lo), out_model); });
+}
+
+int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam_hip_load_options* options,
+                          nam_hip_model** out_model)
+{
+  if ((!nam_path) == (!json_text) || !out_model)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_load_ex: pass exactly one of nam_path / json_text, and out_model");
+  *out_model = nullptr;
+  return guarded([&]() {
+    LoadOptions lo;
+    if (options)
+    {
+      lo.fast_tanh = options->fast_tanh != 0;
+      if (options->n_luts < 0 || (options->n_luts > 0 && !options->luts))
+        throw std::runtime_error("nam_hip_model_load_ex: bad lookup-table list");
+      for (int i = 0; i < options->n_luts; i++)
+      {
+        const nam_hip_lut& l = options->luts[i];
+        const std::string name = l.function_name ? l.function_name : "";
+        LutSpec ls;
+        if (name == "Tanh")
+          ls.act_type = ACT_TANH;
+        else if (name == "Sigmoid")
+          ls.act_type = ACT_SIGMOID;
+        else if (name == "SiLU")
+          ls.act_type = ACT_SILU;
+        else // the reference's message (activations.cpp:209-211)
+          throw std::runtime_error("Tried to enable LUT for a function other than Tanh, Sigmoid, or SiLU");
+        if (l.n_points < 2 || l.n_points > (1 << 22) || !(l.max_x > l.min_x))
+          throw std::runtime_error("nam_hip_model_load_ex: a lookup table needs max > min and 2 <= n_points <= 4194304");
+        ls.min_x = l.min_x;
+        ls.max_x = l.max_x;
+        ls.n_points = l.n_points;
+        lo.luts.erase(std::remove_if(lo.luts.begin(), lo.luts.end(), [&](const LutSpec& o) { return o.act_type == ls.act_type; }),
+                      lo.luts.end()); // a later enable_lut of the same function replaces the earlier one
+        lo.luts.push_back(ls);
+      }
+    }
+    return build_model(nam_path ? load_nam_file(nam_path, lo) : load_nam_text(json_text, lo), out_model);
+  });
 }
 
 void nam_hip_model_free(nam_hip_model* model)

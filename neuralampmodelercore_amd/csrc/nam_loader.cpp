@@ -120,8 +120,36 @@ static int act_type_from_name(const std::string& name)
   throw std::runtime_error("Unknown activation type: " + name);
 }
 
+// FastLUTActivation's constructor (activations.h:374-388): the table is f(min + i * step) in float arithmetic, built
+// with the host's libm exactly as the reference builds it; the device only interpolates.
+static ActSpec make_lut_activation(const LutSpec& l)
+{
+  ActSpec a;
+  a.type = ACT_LUT;
+  const float step = (l.max_x - l.min_x) / (float)(l.n_points - 1);
+  a.p[0] = l.min_x;
+  a.p[1] = l.max_x;
+  a.p[2] = 1.0f / step;
+  a.p[3] = (float)l.n_points;
+  a.slopes.reserve((size_t)l.n_points);
+  for (int i = 0; i < l.n_points; i++)
+  {
+    const float x = l.min_x + (float)i * step;
+    float y;
+    if (l.act_type == ACT_TANH)
+      y = std::tanh(x);
+    else
+    {
+      const float sg = 1.0f / (1.0f + expf(-x)); // activations.h:71-74
+      y = l.act_type == ACT_SIGMOID ? sg : x * sg; // swish, activations.h:107-110
+    }
+    a.slopes.push_back(y);
+  }
+  return a;
+}
+
 // ActivationConfig::from_json + Activation::get_activation(config) folded together.
-static ActSpec parse_activation(const Value& j, bool fast_tanh)
+static ActSpec parse_activation(const Value& j, const LoadOptions& lo)
 {
   ActSpec a;
   if (j.is_string())
@@ -169,8 +197,14 @@ static ActSpec parse_activation(const Value& j, bool fast_tanh)
   }
   else
     throw std::runtime_error("Invalid activation config: expected string or object");
+  // Activation::enable_lut replaces the registry entry of "Tanh" / "Sigmoid" / "SiLU" with a FastLUTActivation
+  // (activations.cpp:189-212, activations.h:371-422); a model binds whatever the registry holds when it is built.
+  // It wins over fast tanh (same as calling enable_fast_tanh() and then enable_lut("Tanh", ...)).
+  for (const LutSpec& l : lo.luts)
+    if (l.act_type == a.type)
+      return make_lut_activation(l);
   // Activation::enable_fast_tanh swaps only the "Tanh" entry (activations.cpp:168-177)
-  if (fast_tanh && a.type == ACT_TANH)
+  if (lo.fast_tanh && a.type == ACT_TANH)
     a.type = ACT_FASTTANH;
   return a;
 }
@@ -219,7 +253,7 @@ static void check_divisible(int in_ch, int out_ch, int groups)
                              + std::to_string(groups) + ")");
 }
 
-static LayerArraySpec parse_layer_array(const Value& lc, size_t i, bool fast_tanh)
+static LayerArraySpec parse_layer_array(const Value& lc, size_t i, const LoadOptions& lo)
 {
   LayerArraySpec p;
   const std::string la = "Layer array " + std::to_string(i);
@@ -286,13 +320,13 @@ static LayerArraySpec parse_layer_array(const Value& lc, size_t i, bool fast_tan
   if (act.is_array())
   {
     for (const auto& a : act.arr)
-      p.activations.push_back(parse_activation(a, fast_tanh));
+      p.activations.push_back(parse_activation(a, lo));
     if (p.activations.size() != n)
       throw std::runtime_error(la + ": activation array size (" + std::to_string(p.activations.size())
                                + ") must match dilations size (" + std::to_string(n) + ")");
   }
   else
-    p.activations.assign(n, parse_activation(act, fast_tanh));
+    p.activations.assign(n, parse_activation(act, lo));
 
   const Value* sa = lc.find("secondary_activation");
   if (const Value* gm = lc.find("gating_mode"))
@@ -312,10 +346,10 @@ static LayerArraySpec parse_layer_array(const Value& lc, size_t i, bool fast_tan
               if (p.gating_modes.size() > sa->arr.size())
                 throw std::runtime_error(la + ": secondary_activation array size must be at least "
                                          + std::to_string(p.gating_modes.size()));
-              p.secondary_activations.push_back(parse_activation(sa->arr[p.gating_modes.size() - 1], fast_tanh));
+              p.secondary_activations.push_back(parse_activation(sa->arr[p.gating_modes.size() - 1], lo));
             }
             else
-              p.secondary_activations.push_back(parse_activation(*sa, fast_tanh));
+              p.secondary_activations.push_back(parse_activation(*sa, lo));
           }
           else
             p.secondary_activations.push_back(simple_act(ACT_SIGMOID));
@@ -336,7 +370,7 @@ static LayerArraySpec parse_layer_array(const Value& lc, size_t i, bool fast_tan
       p.gating_modes.assign(n, mode);
       ActSpec s;
       if (mode != GATING_NONE)
-        s = sa ? parse_activation(*sa, fast_tanh) : simple_act(ACT_SIGMOID);
+        s = sa ? parse_activation(*sa, lo) : simple_act(ACT_SIGMOID);
       p.secondary_activations.assign(n, s);
     }
   }
@@ -494,7 +528,7 @@ long LSTMSpec::expected_weight_count() const
   return n + (long)out_channels * hidden_size + out_channels;
 }
 
-static std::shared_ptr<ModelSpec> build_model(const Value& root, bool fast_tanh);
+static std::shared_ptr<ModelSpec> build_model(const Value& root, const LoadOptions& lo);
 
 static bool config_is_slimmable(const Value& config)
 {
@@ -519,7 +553,7 @@ static bool config_is_slimmable(const Value& config)
   return false;
 }
 
-static void parse_wavenet(const Value& config_in, double sample_rate, bool fast_tanh, ModelSpec& out)
+static void parse_wavenet(const Value& config_in, double sample_rate, const LoadOptions& lo, ModelSpec& out)
 {
   WaveNetSpec& wc = out.wavenet;
   const bool slimmable = config_is_slimmable(config_in);
@@ -529,7 +563,7 @@ static void parse_wavenet(const Value& config_in, double sample_rate, bool fast_
   const Value* cd = config.find("condition_dsp");
   if (cd && !cd->is_null())
   {
-    wc.condition_dsp = build_model(*cd, fast_tanh);
+    wc.condition_dsp = build_model(*cd, lo);
     if (wc.condition_dsp->sample_rate != sample_rate)
     {
       std::stringstream ss;
@@ -540,7 +574,7 @@ static void parse_wavenet(const Value& config_in, double sample_rate, bool fast_
   }
   const Value& layers = config.at("layers");
   for (size_t i = 0; i < layers.size(); i++)
-    wc.arrays.push_back(parse_layer_array(layers.at(i), i, fast_tanh));
+    wc.arrays.push_back(parse_layer_array(layers.at(i), i, lo));
 
   const Value* hj = config.find("head");
   wc.with_head = hj && !hj->is_null();
@@ -568,7 +602,7 @@ static void parse_wavenet(const Value& config_in, double sample_rate, bool fast_
         throw std::runtime_error("WaveNet Head: kernel_sizes entries must be >= 1");
       wc.head.kernel_sizes.push_back(k.as_int());
     }
-    wc.head.activation = parse_activation(hj->at("activation"), fast_tanh);
+    wc.head.activation = parse_activation(hj->at("activation"), lo);
     if (wc.head.kernel_sizes.empty())
       throw std::runtime_error("WaveNet config: head.kernel_sizes must be non-empty");
   }
@@ -672,10 +706,10 @@ static void check_wavenet_weights(const WaveNetSpec& wc)
   }
 }
 
-static std::shared_ptr<ModelSpec> build_model(const Value& root, bool fast_tanh)
+static std::shared_ptr<ModelSpec> build_model(const Value& root, const LoadOptions& lo)
 {
   auto m = std::make_shared<ModelSpec>();
-  m->fast_tanh = fast_tanh;
+  m->fast_tanh = lo.fast_tanh;
   m->version = root.at("version").as_string();
   verify_config_version(m->version);
   const Value* w = root.find("weights");
@@ -708,7 +742,7 @@ static std::shared_ptr<ModelSpec> build_model(const Value& root, bool fast_tanh)
   if (arch == "WaveNet")
   {
     m->arch = ARCH_WAVENET;
-    parse_wavenet(config, m->sample_rate, fast_tanh, *m);
+    parse_wavenet(config, m->sample_rate, lo, *m);
     m->wavenet.weights = std::move(weights);
     check_wavenet_weights(m->wavenet);
   }
@@ -738,7 +772,7 @@ static std::shared_ptr<ModelSpec> build_model(const Value& root, bool fast_tanh)
     for (const Value& entry : subs->arr)
     {
       m->sub_max_value.push_back(entry.at("max_value").as_double());
-      m->submodels.push_back(build_model(entry.at("model"), fast_tanh)); // each one is a full .nam document
+      m->submodels.push_back(build_model(entry.at("model"), lo)); // each one is a full .nam document
     }
     for (size_t i = 1; i < m->sub_max_value.size(); i++)
       if (m->sub_max_value[i] <= m->sub_max_value[i - 1])
@@ -762,15 +796,15 @@ static std::shared_ptr<ModelSpec> build_model(const Value& root, bool fast_tanh)
   return m;
 }
 
-std::shared_ptr<ModelSpec> load_nam_text(const std::string& text, bool fast_tanh)
+std::shared_ptr<ModelSpec> load_nam_text(const std::string& text, const LoadOptions& lo)
 {
   Value root = json::parse(text);
   if (!root.is_object())
     throw std::runtime_error("Invalid .nam JSON: root value must be an object.");
-  return build_model(root, fast_tanh);
+  return build_model(root, lo);
 }
 
-std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, bool fast_tanh)
+std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, const LoadOptions& lo)
 {
   // validate_nam_file nam_file.cpp:9-40
   std::ifstream in(path, std::ios::binary);
@@ -798,7 +832,7 @@ std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, bool fast_tanh
   for (const char* key : {"version", "architecture", "config", "weights"})
     if (!root.contains(key))
       throw FileValidationError("Invalid .nam file [" + path + "]: missing required key \"" + key + "\".");
-  return build_model(root, fast_tanh);
+  return build_model(root, lo);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -686,7 +686,7 @@ void build_a1(const WaveNetSpec& wn, Plan& plan)
         return;
       const ActSpec& a = A.activations[l];
       const ActSpec& a0 = A.activations[0];
-      if (a.type != a0.type || a.type == ACT_PRELU || a.type == ACT_LEAKYHARDTANH || a.p[0] != a0.p[0])
+      if (a.type != a0.type || a.type == ACT_PRELU || a.type == ACT_LEAKYHARDTANH || a.type == ACT_LUT || a.p[0] != a0.p[0])
         return;
     }
   }

@@ -49,7 +49,8 @@ enum
   ORC_ACT_SILU = 8,
   ORC_ACT_HARDSWISH = 9,
   ORC_ACT_LEAKYHARDTANH = 10,
-  ORC_ACT_SOFTSIGN = 11
+  ORC_ACT_SOFTSIGN = 11,
+  ORC_ACT_LUT = 13 /* FastLUTActivation, activations.h:371-422 (enable_lut, activations.cpp:189-212) */
 };
 
 #define ORC_MAX_SLOPES 64
@@ -60,6 +61,10 @@ typedef struct
   float p[4]; /* LeakyReLU: p[0]=slope; LeakyHardtanh: min_val,max_val,min_slope,max_slope */
   int n_slopes; /* PReLU */
   float slopes[ORC_MAX_SLOPES];
+  /* ORC_ACT_LUT: p[0] = min_x, p[1] = max_x, p[2] = base function (TANH / SIGMOID / SILU), p[3] = n points */
+  float lut_step, lut_inv_step;
+  int lut_n;
+  float* lut; /* owned by the process (test infrastructure: never freed) */
 } orc_act;
 
 /* activations.h:91-98 */
@@ -86,10 +91,24 @@ static inline float orc_leaky_relu(float x, float ns)
   return x > 0.0f ? x : ns * x;
 }
 
+/* FastLUTActivation::lookup, activations.h:391-409 */
+static inline float orc_lut_lookup(const orc_act* a, float x)
+{
+  const float min_x = a->p[0], max_x = a->p[1];
+  x = x < min_x ? min_x : (x > max_x ? max_x : x);
+  const float f_idx = (x - min_x) * a->lut_inv_step;
+  const size_t i = (size_t)f_idx;
+  if (i >= (size_t)a->lut_n - 1)
+    return a->lut[a->lut_n - 1];
+  const float frac = f_idx - (float)i;
+  return a->lut[i] + (a->lut[i + 1] - a->lut[i]) * frac;
+}
+
 static inline float orc_act_scalar(const orc_act* a, float x, float slope)
 {
   switch (a->type)
   {
+    case ORC_ACT_LUT: return orc_lut_lookup(a, x);
     case ORC_ACT_IDENTITY: return x;
     case ORC_ACT_TANH: return tanhf(x); /* std::tanh(float) activations.h:188 */
     case ORC_ACT_HARDTANH: /* activations.h:69-73 */
@@ -973,6 +992,20 @@ static void orc_act_from_cfg(orc_act* a, const float* cfg)
   {
     a->n_slopes = 1;
     a->slopes[0] = 0.01f;
+  }
+  if (a->type == ORC_ACT_LUT)
+  {
+    /* FastLUTActivation's constructor, activations.h:374-388: step = (max - min) / (size - 1); table[i] = f(min + i * step) */
+    const int base = (int)a->p[2];
+    a->lut_n = (int)a->p[3];
+    a->lut_step = (a->p[1] - a->p[0]) / (float)(a->lut_n - 1);
+    a->lut_inv_step = 1.0f / a->lut_step;
+    a->lut = (float*)malloc(sizeof(float) * (size_t)a->lut_n);
+    for (int i = 0; i < a->lut_n; i++)
+    {
+      const float x = a->p[0] + (float)i * a->lut_step;
+      a->lut[i] = base == ORC_ACT_TANH ? tanhf(x) : base == ORC_ACT_SIGMOID ? orc_sigmoid(x) : x * orc_sigmoid(x);
+    }
   }
 }
 

@@ -207,6 +207,22 @@ def verify_config_version(version: str) -> None:
 # ---------------------------------------------------------------------------
 # Activation configs — activations.cpp:59-166
 # ---------------------------------------------------------------------------
+class LoadMode:
+    """What the reference keeps in process-globals around get_dsp (activations.cpp:168-212): fast tanh and the
+    lookup tables of Activation::enable_lut. Travels wherever a plain ``fast_tanh`` bool travels (truthiness = fast
+    tanh); ``luts`` = {"Tanh" | "Sigmoid" | "SiLU": (min, max, n_points)}."""
+
+    def __init__(self, fast_tanh: bool = False, luts=None):
+        self.fast_tanh = bool(fast_tanh)
+        self.luts = dict(luts or {})
+        for name in self.luts:
+            if name not in ("Tanh", "Sigmoid", "SiLU"):  # activations.cpp:209-211
+                raise RuntimeError("Tried to enable LUT for a function other than Tanh, Sigmoid, or SiLU")
+
+    def __bool__(self):
+        return self.fast_tanh
+
+
 def act_cfg(j, fast_tanh: bool = False) -> np.ndarray:
     """Encode an activation JSON (string or object) as the float cfg the C side takes:
     [type, p0, p1, p2, p3, n_slopes, slopes...]."""
@@ -243,6 +259,14 @@ def act_cfg(j, fast_tanh: bool = False) -> np.ndarray:
                  float(j.get("min_slope", 0.01)), float(j.get("max_slope", 0.01))]
     else:
         raise RuntimeError("Invalid activation config: expected string or object")
+    # Activation::enable_lut replaces the registry entry the model binds at construction (activations.cpp:189-212);
+    # it wins over fast tanh (enable_fast_tanh() followed by enable_lut("Tanh", ...))
+    for name, (lo, hi, n) in getattr(fast_tanh, "luts", {}).items():
+        if t == ACT_TYPES[name]:
+            out = np.zeros(7, dtype=np.float32)
+            out[0] = 13  # ORC_ACT_LUT
+            out[1:5] = [lo, hi, ACT_TYPES[name], n]
+            return out
     # Activation::enable_fast_tanh swaps only the "Tanh" registry entry (activations.cpp:168-177)
     if fast_tanh and t == ACT_TYPES["Tanh"]:
         t = ACT_TYPES["Fasttanh"]
@@ -950,5 +974,6 @@ def validate_nam_file(path: str) -> dict:
     return j
 
 
-def get_dsp(path: str, fast_tanh: bool = False) -> OracleDSP:
-    return load_nam_json(validate_nam_file(path), fast_tanh=fast_tanh)
+def get_dsp(path: str, fast_tanh: bool = False, luts=None) -> OracleDSP:
+    """``luts``: see LoadMode (Activation::enable_lut before get_dsp)."""
+    return load_nam_json(validate_nam_file(path), fast_tanh=LoadMode(fast_tanh, luts) if luts else fast_tanh)

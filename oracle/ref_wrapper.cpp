@@ -63,6 +63,32 @@ void* ref_load(const char* path, int fast_tanh, char* err, int errlen)
     return nullptr;
   }
 }
+// nam::activations::Activation::enable_lut(name, min, max, n) around get_dsp (NAM/activations.cpp:189-212): the
+// registry entry is what a model binds at construction, so the table stays with the loaded model
+void* ref_load_lut(const char* path, int fast_tanh, const char* lut_name, float lut_min, float lut_max, int lut_n,
+                   char* err, int errlen)
+{
+  if (fast_tanh)
+  {
+    // enable_lut("Tanh") and enable_fast_tanh share one backup slot (activations.cpp:169-199): combining them loses the
+    // libm tanh for the rest of the process. The wrapper is shared by every test, so it refuses.
+    set_err(err, errlen, "ref_load_lut: not with fast_tanh (the reference's shared tanh_bak would be clobbered)");
+    return nullptr;
+  }
+  try
+  {
+    nam::activations::Activation::disable_fast_tanh();
+    nam::activations::Activation::enable_lut(lut_name, lut_min, lut_max, (std::size_t)lut_n);
+  }
+  catch (const std::exception& e)
+  {
+    set_err(err, errlen, e.what());
+    return nullptr;
+  }
+  void* h = ref_load(path, fast_tanh, err, errlen);
+  nam::activations::Activation::disable_lut(lut_name);
+  return h;
+}
 void ref_free(void* p)
 {
   delete static_cast<Handle*>(p);

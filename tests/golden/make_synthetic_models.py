@@ -69,7 +69,7 @@ def build(name, arrays, seed):
     return len(weights)
 
 
-def build_general(name, in_channels, arrays, post_head, seed):
+def build_general(name, in_channels, arrays, post_head, seed, gain=0.9):
     """Plain (ungated, no FiLM) WaveNet with an optional post-stack head and any channel counts.
     arrays: (channels, dilations, activation, head_size, head_bias); post_head: dict or None
     (model.cpp:21-103: repeat activation -> Conv1D(kernel_sizes[i]) with bias, `channels` wide inside)."""
@@ -77,7 +77,7 @@ def build_general(name, in_channels, arrays, post_head, seed):
     layers, weights = [], []
 
     def w(shape, fan_in):
-        v = rng.standard_normal(shape).astype(np.float32) * np.float32(0.9 / np.sqrt(fan_in))
+        v = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
         weights.extend(v.reshape(-1).tolist())
 
     K = 3
@@ -118,6 +118,12 @@ GENERAL = {
     # post-stack head: ReLU -> Conv1D(K=3) -> ReLU -> Conv1D(K=2), 3 -> 5 -> 2 channels: two outputs
     "synth_posthead": dict(in_channels=1, arrays=[(4, [1, 2, 4], "Tanh", 3, True)],
                            post_head=dict(channels=5, out_channels=2, kernel_sizes=[3, 2], activation="ReLU"), seed=21),
+    # LeakyHardtanh (activations.h:75-89) in its object form with all four parameters and in its string form (registry
+    # defaults -1, 1, 0.01, 0.01), plus the "LeakyHardTanh" spelling the parser also accepts; inputs driven past both knees
+    "synth_leakyhardtanh": dict(in_channels=1, arrays=[
+        (4, [1, 2, 4], dict(type="LeakyHardtanh", min_val=-0.5, max_val=0.7, min_slope=0.02, max_slope=0.05), 3, True),
+        (3, [1, 3], "LeakyHardtanh", 2, True), (2, [2, 5], dict(type="LeakyHardTanh", min_val=-0.2, max_val=0.1), 1, False)],
+        post_head=None, seed=23, gain=2.5),
     # 3 inputs / 2 outputs (the shape tools/test/test_real_time_safe.cpp:1069 uses), no post-stack head
     "synth_multich": dict(in_channels=3, arrays=[(4, [1, 3], "ReLU", 2, False), (2, [2, 5], "Tanh", 2, True)], post_head=None, seed=22),
 }

@@ -621,3 +621,101 @@ def test_mfma_kernel_is_deterministic_and_launch_shape_independent(nam_lib):
         b.close()
     for y in outs[1:]:
         np.testing.assert_array_equal(outs[0], y)
+
+
+# ---- round 2 pins -------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n_streams", [256, 700])
+def test_headline_config_every_stream_matches_oracle(nam_lib, oracle, n_streams):
+    """BASELINE.json configs[1] exactly — wavenet_a1_standard, 256 concurrent streams, buffer 64, fast tanh (the
+    benchmodel default), one launch per buffer, AUTO kernel — EVERY stream against the oracle over 8 buffers; and 700
+    streams (a second / third workgroup per CU), every stream as well."""
+    nam = nam_lib
+    block, n = 64, 64 * 8
+    x = stream_bank(n_streams, n, seed=2024)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    b = model.batch(n_streams, block)
+    b.Reset(prewarm=True)
+    y = b.process_stream(x, block)
+    b.close()
+    ref = oracle.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    worst = 0.0
+    for s in range(n_streams):
+        ref.Reset(48000.0, block)
+        r = ref.process_stream(x[s], block)
+        err = float(np.max(np.abs(r - y[s])))
+        worst = max(worst, err)
+        assert err <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), (n_streams, s, err)
+    print(f"headline parity: {n_streams} streams x {n} frames, worst max-abs error {worst:.3e}")
+
+
+@pytest.mark.parametrize("ratio,channels", [(0.0, 3), (1.0, 8)])
+@pytest.mark.parametrize("kernel", ["a1_mfma", "a1", "generic"])
+def test_a2_matches_the_reference_fast_path(nam_lib, ratio, channels, kernel):
+    """A2.nam against what the reference ACTUALLY runs for it by default: wavenet/a2_fast.cpp (NAM_ENABLE_A2_FAST,
+    CMakeLists.txt:58; dispatch model.cpp:1317), built unmodified into oracle/_ref/libnam_ref_a2fast.so. Protocol of
+    the reference's own A/B test (tools/test/test_a2_fast.cpp:109-128,272-300): two-tone input, 2,048 frames, block
+    sizes 64 and 256, Reset (with prewarm) before each run, max-abs tolerance 5e-5. A2-Lite (3 channels) and A2-Full
+    (8); the K-tap MFMA kernel (Full), the VALU kernel and the op-program interpreter."""
+    import nam_ref
+    if not nam_ref.available():
+        pytest.skip("prebuilt oracle/_ref not available")
+    nam = nam_lib
+    x = two_tone(2048)
+    model = nam.get_dsp(model_path("A2"), fast_tanh=False)
+    for block in (64, 256):
+        ref = nam_ref.get_dsp(model_path("A2"), fast_tanh=False, a2_fast=True)
+        ref.Reset(48000.0, block)
+        ref.SetSlimmableSize(ratio)
+        r = ref.process_stream(x, block)[0]
+        b = model.batch(2, block)
+        b.set_kernel({"a1_mfma": nam.KERNEL_A1_MFMA, "a1": nam.KERNEL_A1, "generic": nam.KERNEL_GENERIC}[kernel])
+        b.Reset(prewarm=True)
+        b.SetSlimmableSize(ratio)
+        y = b.process_stream(np.stack([x, x]), block)[:, 0, :]
+        b.close()
+        for s in range(2):
+            err = float(np.max(np.abs(r - y[s])))
+            assert err <= 5e-5, (channels, kernel, block, s, err)
+
+
+@pytest.mark.parametrize("name,luts,fast_tanh", [
+    ("wavenet", {"Tanh": (-5.0, 5.0, 1024)}, False),
+    ("wavenet", {"Tanh": (-5.0, 5.0, 1024)}, True),  # a table wins over fast tanh
+    ("wavenet_a1_standard", {"Tanh": (-4.0, 4.0, 4096)}, False),
+    ("wavenet_a2_max", {"Sigmoid": (-8.0, 8.0, 1024), "SiLU": (-6.0, 6.0, 333)}, False),  # gated / blended secondaries too
+])
+def test_lookup_table_activations_match_oracle(nam_lib, oracle, name, luts, fast_tanh):
+    """FastLUTActivation (activations.h:371-422) on the device: the table is built on the host exactly as the reference
+    builds it, the kernel clamps / indexes / interpolates (device_common.h: d_lut). The oracle it is compared with is
+    bit-exact with the reference build for the same tables (tests/test_reference_build.py)."""
+    nam = nam_lib
+    n_streams, block, n = 3, 64, 64 * 5 + 9
+    x = stream_bank(n_streams, n, seed=77)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh, luts=luts)
+    b = model.batch(n_streams, block)
+    b.Reset(prewarm=True)
+    y = b.process_stream(x, block)
+    b.close()
+    for s in range(n_streams):
+        ref = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh, luts=luts)
+        ref.Reset(48000.0, block)
+        r = ref.process_stream(x[s], block)
+        assert float(np.max(np.abs(r - y[s]))) <= 1e-4 * max(1.0, float(np.max(np.abs(r)))), (name, s)
+
+
+def test_leaky_hardtanh_matches_oracle(nam_lib, oracle):
+    """LeakyHardtanh (activations.h:75-89) on the device: object form with four parameters, string form (registry
+    defaults) and the alternative spelling; the fixture drives every array past both knees."""
+    nam = nam_lib
+    n_streams, block, n = 4, 64, 64 * 4 + 31
+    x = stream_bank(n_streams, n, seed=78)
+    for fast_tanh in (False, True):
+        model = nam.get_dsp(model_path("synth_leakyhardtanh"), fast_tanh=fast_tanh)
+        b = model.batch(n_streams, block)
+        b.Reset(prewarm=True)
+        y = b.process_stream(x, block)
+        b.close()
+        for s in range(n_streams):
+            r = _oracle_run(oracle, "synth_leakyhardtanh", x[s], block, fast_tanh)
+            assert float(np.max(np.abs(r - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), s

@@ -152,3 +152,19 @@ def test_no_cpu_fallback_without_library(monkeypatch, nam_lib):
     monkeypatch.setattr(nam, "lib_path", lambda: os.path.join(ROOT, "no_such_dir", "libnam_hip.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         nam.get_dsp(model_path("wavenet"))
+
+
+def test_lookup_table_load_option(nam_lib):
+    """Activation::enable_lut as a load option (activations.cpp:189-212): accepted names, the reference's message for
+    any other, and a model with a table is not handed to the register-resident kernels."""
+    nam = nam_lib
+    m = nam.get_dsp(model_path("wavenet_a1_standard"), luts={"Tanh": (-5.0, 5.0, 1024)})
+    assert m.info.has_a1_kernel == 0  # tables are interpolated by the op-program interpreter only
+    assert nam.get_dsp(model_path("wavenet_a1_standard")).info.has_a1_kernel == 3
+    with pytest.raises(nam.NamHipError) as e:
+        nam.get_dsp(model_path("wavenet"), luts={"ReLU": (-1.0, 1.0, 16)})
+    assert "Tried to enable LUT for a function other than Tanh, Sigmoid, or SiLU" in str(e.value)
+    with pytest.raises(nam.NamHipError):
+        nam.get_dsp(model_path("wavenet"), luts={"Tanh": (1.0, -1.0, 16)})
+    with open(model_path("wavenet")) as f:
+        assert nam.get_dsp_json(f.read(), luts={"Sigmoid": (-8.0, 8.0, 64)}).NumOutputChannels() == 1

@@ -60,6 +60,46 @@ def test_slimmable_sizes_bit_exact(oracle, name, ratios):
             np.testing.assert_array_equal(ref.process_stream(x, 64), orc.process_stream(x, 64))
 
 
+@pytest.mark.parametrize("ratio", [0.0, 1.0])
+def test_oracle_matches_the_reference_a2_fast_path(oracle, ratio):
+    """The reference's default build runs A2-shaped files through wavenet/a2_fast.cpp (NAM_ENABLE_A2_FAST,
+    CMakeLists.txt:58, dispatch model.cpp:1317) — libnam_ref_a2fast.so is that build. Its own A/B protocol against
+    the generic WaveNet (tools/test/test_a2_fast.cpp:109-128,272-300: two-tone, 2,048 frames, blocks 64 and 256,
+    5e-5) applied to fast path vs generic reference vs oracle, plus the prewarm-count guard (:307-325)."""
+    from signals import two_tone
+    x = two_tone(2048)
+    for block in (64, 256):
+        fast = nam_ref.get_dsp(model_path("A2"), a2_fast=True)
+        gen = nam_ref.get_dsp(model_path("A2"))
+        orc = oracle.get_dsp(model_path("A2"))
+        outs = []
+        for d in (fast, gen, orc):
+            d.Reset(48000.0, block)
+            d.SetSlimmableSize(ratio)
+            outs.append(d.process_stream(x, block))
+        assert fast.GetPrewarmSamples() == gen.GetPrewarmSamples() == orc.GetPrewarmSamples()
+        np.testing.assert_array_equal(outs[1], outs[2])  # generic reference == oracle, bit for bit
+        assert float(np.max(np.abs(outs[0] - outs[2]))) <= 5e-5  # fast path within the reference's own bound
+        assert float(np.max(np.abs(outs[0]))) > 0.05
+
+
+@pytest.mark.parametrize("name,lut", [("wavenet", ("Tanh", -5.0, 5.0, 1024)), ("wavenet_a1_standard", ("Tanh", -4.0, 4.0, 4096)),
+                                      ("wavenet_a2_max", ("Sigmoid", -8.0, 8.0, 1024)), ("wavenet_a2_max", ("SiLU", -6.0, 6.0, 333))])
+def test_lookup_table_activations_bit_exact(oracle, name, lut):
+    """Activation::enable_lut(name, min, max, n) before get_dsp (activations.cpp:189-212, FastLUTActivation
+    activations.h:371-422; the reference's own check is tools/test/test_fast_lut.cpp): oracle == reference, and the
+    table actually changes the output."""
+    x = _signal(1, 640)
+    ref = nam_ref.get_dsp(model_path(name), lut=lut)
+    orc = oracle.get_dsp(model_path(name), luts={lut[0]: lut[1:]})
+    plain = oracle.get_dsp(model_path(name))
+    for d in (ref, orc, plain):
+        d.Reset(48000.0, 64)
+    y = orc.process_stream(x, 64)
+    np.testing.assert_array_equal(ref.process_stream(x, 64), y)
+    assert float(np.max(np.abs(y - plain.process_stream(x, 64)))) > 0.0
+
+
 @pytest.mark.parametrize("key", [k for k in G.files if "__ft" in k])
 def test_committed_goldens_are_the_reference_outputs(key):
     name, ft = key.split("__ft")
