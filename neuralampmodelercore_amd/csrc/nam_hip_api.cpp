@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -97,6 +98,9 @@ struct WidthGroup
   long state_stride = 0;
   std::vector<int> streams; // members, ascending
   int* d_map = nullptr; // device copy of `streams` (nullptr when the group is all streams in order)
+  // Which ring layout the state currently holds (only models whose A1 kernels run on zero-padded channels have two:
+  // plan.h, Plan::a1_padded_layout): -1 = freshly zeroed (either), 0 = the op program's, 1 = the padded A1 layout
+  int state_family = -1;
 };
 } // namespace
 
@@ -116,6 +120,9 @@ struct nam_hip_batch
   long long* dbg = nullptr; // device buffer of the profiling instantiation (nam_hip_batch_debug_timeline)
   bool was_reset = false;
   bool reset_with_prewarm = true; // thread_local gPrewarmOnResetDefault = true (NAM/dsp.cpp:20)
+  // the caller-supplied stream of the last nam_hip_batch_process_device: control calls that free or rewrite device
+  // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
+  hipStream_t last_ext_stream = nullptr;
 };
 
 namespace
@@ -161,11 +168,29 @@ int ensure_state(nam_hip_batch* b, WidthGroup& g)
   return NAM_HIP_OK;
 }
 
+// Wait for everything the batch may still have in flight: its own stream and the last caller-supplied one.
+hipError_t quiesce(nam_hip_batch* b)
+{
+  hipError_t e = b->stream ? hipStreamSynchronize(b->stream) : hipSuccess;
+  if (b->last_ext_stream && b->last_ext_stream != b->stream)
+  {
+    const hipError_t e2 = hipStreamSynchronize(b->last_ext_stream);
+    if (e == hipSuccess)
+      e = e2;
+  }
+  return e;
+}
+
+int state_family_of(const Plan& p, int kernel)
+{
+  return (p.a1_padded_layout && kernel != NAM_HIP_KERNEL_GENERIC) ? 1 : 0;
+}
+
 int refresh_map(nam_hip_batch* b, WidthGroup& g)
 {
   if (g.d_map)
   {
-    NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
+    NAM_HIP_CHECK(quiesce(b));
     NAM_HIP_CHECK(hipFree(g.d_map));
     g.d_map = nullptr;
   }
@@ -213,6 +238,14 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
   if (p.arch == ARCH_WAVENET)
   {
     const int kernel = pick_kernel(b, g);
+    // the op program and the A1 kernels of a channel-padded model keep different ring layouts: a change of kernel
+    // family is only legal on freshly reset state
+    const int fam = state_family_of(p, kernel);
+    if (g.state_family >= 0 && g.state_family != fam)
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
+                  "kernel change crosses state layouts (this model runs its A1 kernels on zero-padded channels): "
+                  "call nam_hip_batch_reset before switching between NAM_HIP_KERNEL_GENERIC and the A1 kernels");
+    g.state_family = fam;
     if (kernel != NAM_HIP_KERNEL_GENERIC)
     {
       A1Args a;
@@ -353,7 +386,11 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
     return NAM_HIP_OK;
   const Plan& p = *g.plan;
   if (p.arch == ARCH_WAVENET)
+  {
     NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, d_map, n, nullptr, 0, p.state_floats, b->stream));
+    if (n == (int)g.streams.size())
+      g.state_family = -1; // every stream of the group is zeroed: either layout may follow
+  }
   if (prewarm)
   {
     const int rc = launch_group(b, g, d_map, n, nullptr, nullptr, prewarm_frames(b, p), 0, b->stream);
@@ -566,36 +603,50 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   if (device < 0 || device >= count)
     return fail(NAM_HIP_ERR_DEVICE, "nam_hip_batch_create: no such HIP device " + std::to_string(device));
   NAM_HIP_CHECK(hipSetDevice(device));
-  auto b = std::make_unique<nam_hip_batch>();
+  nam_hip_batch* b = new (std::nothrow) nam_hip_batch();
+  if (!b)
+    return fail(NAM_HIP_ERR_DEVICE, "nam_hip_batch_create: out of host memory");
   b->model = model;
   b->device = device;
   b->n_streams = n_streams;
   b->max_frames = max_frames;
-  NAM_HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  b->groups.resize(model->plans.size());
-  for (size_t i = 0; i < model->plans.size(); i++)
-  {
-    b->groups[i].plan = &model->plans[i];
-    const int rc = upload_group(b.get(), b->groups[i]);
-    if (rc != NAM_HIP_OK)
-      return rc;
-  }
-  b->stream_width.assign(n_streams, model->full_width);
-  WidthGroup& g = b->groups[model->full_width];
-  g.streams.resize(n_streams);
-  for (int i = 0; i < n_streams; i++)
-    g.streams[i] = i;
-  int rc = ensure_state(b.get(), g);
+  // everything that can fail runs inside this lambda; on failure the half-built batch goes through
+  // nam_hip_batch_destroy, which frees whatever was already allocated (stream, blobs, state, staging)
+  const int rc = [&]() -> int {
+    NAM_HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->groups.resize(model->plans.size());
+    for (size_t i = 0; i < model->plans.size(); i++)
+    {
+      b->groups[i].plan = &model->plans[i];
+      const int r = upload_group(b, b->groups[i]);
+      if (r != NAM_HIP_OK)
+        return r;
+    }
+    b->stream_width.assign(n_streams, model->full_width);
+    WidthGroup& g = b->groups[model->full_width];
+    g.streams.resize(n_streams);
+    for (int i = 0; i < n_streams; i++)
+      g.streams[i] = i;
+    const int r = ensure_state(b, g);
+    if (r != NAM_HIP_OK)
+      return r;
+    const size_t in_floats = (size_t)n_streams * model->spec->in_channels() * max_frames;
+    const size_t out_floats = (size_t)n_streams * model->spec->out_channels() * max_frames;
+    NAM_HIP_CHECK(hipMalloc(&b->d_in, in_floats * sizeof(float)));
+    NAM_HIP_CHECK(hipMalloc(&b->d_out, out_floats * sizeof(float)));
+    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), std::max(in_floats, out_floats) * sizeof(float),
+                                hipHostMallocDefault));
+    NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
+    return NAM_HIP_OK;
+  }();
   if (rc != NAM_HIP_OK)
+  {
+    const std::string msg = g_last_error; // destroy must not clobber the reason
+    nam_hip_batch_destroy(b);
+    g_last_error = msg;
     return rc;
-  const size_t in_floats = (size_t)n_streams * model->spec->in_channels() * max_frames;
-  const size_t out_floats = (size_t)n_streams * model->spec->out_channels() * max_frames;
-  NAM_HIP_CHECK(hipMalloc(&b->d_in, in_floats * sizeof(float)));
-  NAM_HIP_CHECK(hipMalloc(&b->d_out, out_floats * sizeof(float)));
-  NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage), std::max(in_floats, out_floats) * sizeof(float),
-                              hipHostMallocDefault));
-  NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
-  *out_batch = b.release();
+  }
+  *out_batch = b;
   return NAM_HIP_OK;
 }
 
@@ -604,8 +655,7 @@ void nam_hip_batch_destroy(nam_hip_batch* batch)
   if (!batch)
     return;
   (void)hipSetDevice(batch->device);
-  if (batch->stream)
-    (void)hipStreamSynchronize(batch->stream);
+  (void)quiesce(batch);
   for (auto& g : batch->groups)
     free_group(g);
   if (batch->d_in)
@@ -624,6 +674,7 @@ int nam_hip_batch_reset(nam_hip_batch* batch, int prewarm)
   if (!batch)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_reset: null batch");
   NAM_HIP_CHECK(hipSetDevice(batch->device));
+  NAM_HIP_CHECK(quiesce(batch)); // launches still running on a caller-supplied stream must not race with the zeroing
   batch->was_reset = true;
   batch->reset_with_prewarm = prewarm != 0;
   for (auto& g : batch->groups)
@@ -673,7 +724,7 @@ int nam_hip_batch_set_slimmable_size(nam_hip_batch* batch, const int* stream_ids
       moved.push_back(s);
   if (moved.empty())
     return NAM_HIP_OK;
-  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  NAM_HIP_CHECK(quiesce(batch));
   for (int s : moved)
   {
     auto& old = batch->groups[batch->stream_width[s]].streams;
@@ -713,6 +764,8 @@ int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float*
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_process_device: frame_stride < n_frames");
   NAM_HIP_CHECK(hipSetDevice(batch->device));
   hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : batch->stream;
+  if (hip_stream)
+    batch->last_ext_stream = s;
   for (auto& g : batch->groups)
   {
     if (g.streams.empty())
@@ -841,7 +894,18 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
     if (kernel == NAM_HIP_KERNEL_A1_MFMA && !full.ws_ok && !full.kt_ok)
       return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 MFMA kernel cannot run this model");
   }
+  // a change of ring layout (channel-padded models: op program <-> A1 kernels) needs freshly reset state
+  const int prev = batch->kernel;
   batch->kernel = kernel;
+  for (const auto& g : batch->groups)
+    if (g.plan->arch == ARCH_WAVENET && !g.streams.empty() && g.state_family >= 0
+        && state_family_of(*g.plan, pick_kernel(batch, g)) != g.state_family)
+    {
+      batch->kernel = prev;
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
+                  "nam_hip_batch_set_kernel: this model runs its A1 kernels on zero-padded channels, whose history rings "
+                  "differ from the op program's; call nam_hip_batch_reset(batch, 0) first, then switch, then reset / prewarm");
+    }
   return NAM_HIP_OK;
 }
 

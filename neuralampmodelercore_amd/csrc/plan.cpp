@@ -1008,10 +1008,45 @@ bool pad_channels_for_mfma(const WaveNetSpec& wn, WaveNetSpec& out)
   return w == wn.weights.data() + wn.weights.size();
 }
 
+// Geometry of a (possibly downloaded, possibly corrupt) file before any 32-bit offset is derived from it: dilations and
+// kernel sizes must be positive and the per-stream history — every ring is (K - 1) * dilation + 64 frames of its input
+// channels, counted here with the channel padding the A1 kernels may add — must stay within 1 GiB, which also keeps
+// every byte offset inside the kernels' 32-bit descriptors. The reference would throw std::bad_alloc or run out of
+// memory on such a file; here it is a load error.
+void validate_wavenet_geometry(const WaveNetSpec& wn)
+{
+  constexpr long long kMaxStateFloats = 1ll << 28; // 1 GiB of float32 per stream
+  long long total = 0;
+  auto ring = [&](long long K, long long dil, long long cin, const char* what) {
+    if (K < 1 || dil < 1)
+      throw std::runtime_error(std::string("plan: ") + what + " needs kernel_size >= 1 and dilation >= 1");
+    if (K > 4096 || dil > (1ll << 26))
+      throw std::runtime_error(std::string("plan: ") + what + " kernel_size / dilation out of range for the device path");
+    const long long frames = (K - 1) * dil + kBlock;
+    total += frames * ((cin + 3) / 4 * 4 + 4);
+    if (total > kMaxStateFloats)
+      throw std::runtime_error("plan: per-stream history exceeds 1 GiB (kernel_size x dilation too large for the device path)");
+  };
+  for (const LayerArraySpec& A : wn.arrays)
+  {
+    if (A.channels < 1 || A.channels > 4096 || A.bottleneck < 1 || A.bottleneck > 4096 || A.head_size < 1 || A.head_size > 4096)
+      throw std::runtime_error("plan: channel counts out of range for the device path");
+    for (int l = 0; l < A.num_layers(); l++)
+      ring(A.kernel_sizes[(size_t)l], A.dilations[(size_t)l], A.channels, "a WaveNet layer");
+    ring(A.head_kernel_size, A.head_dilation, A.head_output_size(), "a head rechannel");
+  }
+  if (wn.with_head)
+    for (int k : wn.head.kernel_sizes)
+      ring(k, 1, std::max(wn.head.channels, wn.head.in_channels), "a post-stack head convolution");
+  if (wn.condition_dsp && wn.condition_dsp->arch == ARCH_WAVENET)
+    validate_wavenet_geometry(wn.condition_dsp->wavenet);
+}
+
 } // namespace
 
 Plan build_wavenet_plan(const WaveNetSpec& wn)
 {
+  validate_wavenet_geometry(wn);
   Plan plan;
   plan.arch = ARCH_WAVENET;
   plan.in_channels = wn.in_channels;
@@ -1071,6 +1106,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
           if (plan.a1.arr[a].ring_id[l] >= 0)
             need = std::max(need, plan.a1.arr[a].ring_off[l] + plan.a1.arr[a].channels * plan.a1.arr[a].ring_len[l]);
       plan.state_floats = std::max(plan.state_floats, (table + need + kBlock - 1) / kBlock * kBlock);
+      plan.a1_padded_layout = true;
     }
   }
   if (plan.a1.valid)

@@ -263,6 +263,10 @@ struct Plan
   int generic_blob_floats = 0; // leading part of `blob` the op program reads (weights, biases, activation parameters)
   int n_rings = 0;
   int state_floats = 0; // per-stream state size (floats), multiple of 64; first n_rings words = write positions
+  // true when the A1 kernels run a zero-padded copy of the model (plan.cpp: pad_channels_for_mfma): their rings are
+  // [R][C_padded] while the op program's are [R][C] — two state layouts, so switching between the generic kernel and
+  // the A1 kernels needs freshly reset state (nam_hip_api.cpp enforces it)
+  bool a1_padded_layout = false;
   A1Plan a1;
   LSTMPlan lstm;
   std::string describe() const;

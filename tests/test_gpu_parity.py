@@ -719,3 +719,47 @@ def test_leaky_hardtanh_matches_oracle(nam_lib, oracle):
         for s in range(n_streams):
             r = _oracle_run(oracle, "synth_leakyhardtanh", x[s], block, fast_tanh)
             assert float(np.max(np.abs(r - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), s
+
+
+@pytest.mark.parametrize("name", ["synth_a1_lite", "synth_a1_c14"])
+def test_generic_and_padded_a1_kernels_do_not_share_state(nam_lib, oracle, name):
+    """Models whose A1 kernels run on zero-padded channels (6 -> 8, 14 -> 16, 10 -> 12) keep two ring layouts: the op
+    program's [R][C] and the A1 kernels' [R][C_padded]. Switching family mid-stream must be refused (it used to read
+    rings written in the other layout and produce wrong audio silently); after a Reset either family runs and matches
+    the oracle, and unpadded models still switch freely."""
+    nam = nam_lib
+    n_streams, block = 3, 64
+    x = stream_bank(n_streams, 64 * 4, seed=91)
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    b = model.batch(n_streams, block)
+    b.Reset(prewarm=True)  # AUTO: the MFMA kernel on the padded layout
+    assert b.get_kernel() == nam.KERNEL_A1_MFMA
+    with pytest.raises(nam.NamHipError):
+        b.set_kernel(nam.KERNEL_GENERIC)
+    assert b.get_kernel() == nam.KERNEL_A1_MFMA
+    b.set_kernel(nam.KERNEL_A1)  # same family: allowed, bit-compatible state
+    y0 = b.process(x[:, :64])
+    b.Reset(prewarm=False)  # zeroed state: either layout may follow
+    b.set_kernel(nam.KERNEL_GENERIC)
+    b.Reset(prewarm=True)
+    y = b.process_stream(x, block)
+    with pytest.raises(nam.NamHipError):
+        b.set_kernel(nam.KERNEL_AUTO)
+    b.close()
+    for s in range(n_streams):
+        r = _oracle_run(oracle, name, x[s], block, True)
+        assert float(np.max(np.abs(r - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r))))
+        assert float(np.max(np.abs(r[:, :64] - y0[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r))))
+    # an unpadded model: one layout, free switching (as before)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    b = model.batch(2, block)
+    b.Reset(prewarm=True)
+    parts = []
+    for i, k in enumerate((nam.KERNEL_A1_MFMA, nam.KERNEL_GENERIC, nam.KERNEL_A1, nam.KERNEL_AUTO)):
+        b.set_kernel(k)
+        parts.append(b.process(x[:2, 64 * i:64 * (i + 1)]))
+    b.close()
+    y = np.concatenate(parts, axis=-1)
+    for s in range(2):
+        r = _oracle_run(oracle, "wavenet_a1_standard", x[s], block, True)
+        assert float(np.max(np.abs(r - y[s]))) <= 5e-5

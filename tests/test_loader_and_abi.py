@@ -168,3 +168,19 @@ def test_lookup_table_load_option(nam_lib):
         nam.get_dsp(model_path("wavenet"), luts={"Tanh": (1.0, -1.0, 16)})
     with open(model_path("wavenet")) as f:
         assert nam.get_dsp_json(f.read(), luts={"Sigmoid": (-8.0, 8.0, 64)}).NumOutputChannels() == 1
+
+
+@pytest.mark.parametrize("field,value", [("dilations", [1, -2]), ("dilations", [1, 0]), ("dilations", [1, 1 << 28]),
+                                          ("dilations", [1 << 25, 1 << 25]), ("kernel_size", 0)])
+def test_corrupt_geometry_is_a_load_error(nam_lib, tmp_path, field, value):
+    """A crafted .nam (negative / zero / huge dilation, zero kernel size) must fail at load instead of overflowing the
+    32-bit state offsets the kernels use (the reference would run out of memory)."""
+    import json
+    with open(model_path("wavenet")) as f:
+        j = json.load(f)
+    j["config"]["layers"][0][field] = value
+    p = str(tmp_path / "bad.nam")
+    with open(p, "w") as f:
+        json.dump(j, f)
+    with pytest.raises(nam_lib.NamHipError):
+        nam_lib.get_dsp(p)
