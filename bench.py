@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """
-bench.py — headline benchmark: real-time audio streams (xRT) at 48 kHz through
-wavenet_a1_standard.nam on MI355X (BASELINE.json metric / configs[1]).
+bench.py — real-time audio streams (xRT) at 48 kHz on MI355X: BASELINE.json's metric on its configs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}]
 
-A "step" is one pass of the hot path over one batch: every stream of the batch advances by one
-64-frame buffer (`DSP::process(in, out, 64)` for all streams at once). Inputs are resident in HBM
-before the timed region; K steps are timed between barrier + torch.cuda.synchronize() pairs and the
-MAX over ranks is used. Weak scaling: every GPU owns `--streams` independent streams (no data-path
-collective; RCCL only scatters the input bank before and gathers checksums after the timed region).
+  --config 2 (default)  wavenet_a1_standard.nam, 256 concurrent streams per GPU, buffer = 64   (BASELINE configs[1], headline)
+  --config 3            lstm.nam, 1,024 concurrent streams per GPU                             (configs[2])
+  --config 4            wavenet_a2_max.nam (+ FiLM, nested condition_dsp), 512 streams per GPU (configs[3]: 4,096 over 8 GPUs)
+  --config 5            slimmable_wavenet.nam, 768 streams per GPU at mixed widths             (configs[4])
+
+A "step" is one pass of the hot path over one batch: every stream of the batch advances by one 64-frame buffer
+(`DSP::process(in, out, 64)` for all streams at once). Inputs are resident in HBM before the timed region. After W
+untimed warm-up steps a timed region is EXACTLY K steps between barrier + torch.cuda.synchronize() pairs, MAX over
+ranks; the region is repeated --reps times (default 11, protocol of the reference's benchmark_wavenet_a1.sh:10) and
+`value` is the MEDIAN region (every region's time is in the line). Weak scaling: every GPU owns `--streams`
+independent streams, sharded per width class (no data-path collective; RCCL only broadcasts the model text once,
+scatters the input bank before and gathers the rendered tail after the timed regions).
 
 Launch modes (the kernel is the same):
   --launch block     one kernel launch per 64-frame step, K launches enqueued back to back
                      (the real-time serving shape: buffer = 64 samples)            [default]
   --launch resident  ONE launch walks all K steps of the resident signal (offline re-amp shape)
 
-Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel's algorithmic FLOPs
-(2 x MAC per stream-sample, SURVEY.md §8d: 26,640 for wavenet_a1_standard) against the fp32 peak
-of MI355X (157.3 TFLOP/s — the fp32 MFMA peak equals the fp32 vector peak on gfx950);
-`cpu_baseline` times the CPU oracle (oracle/, -Ofast build made on this box) on one host core.
+Prints ONE JSON line (rank 0): contract keys + `roofline` (algorithmic bytes of SURVEY.md §8d against the 8 TB/s HBM
+peak, with the fp32 fraction, the PMC-measured HBM bytes and the LDS counters of the dominant kernel from
+profiles/traffic.json) + `cpu_baseline` (the CPU oracle on the box's host cores) + `latency_us` (per-launch
+min / p50 / p99 / p99.9, as tools/bench_a2_fast.cpp:274-296 prints them) + `fast_tanh_off` and `zeros_input` side runs.
+
+--dry-run executes the same scatter -> steps -> gather -> all_reduce(MAX) code on CPU tensors over gloo with a stub
+in place of the kernels (tests/test_bench_dry_run.py): the distributed branch is exercised without GPUs.
 """
 import argparse
 import json
@@ -51,34 +60,15 @@ def wavenet_history_bytes_per_sample(cfg: dict) -> int:
     return total
 
 
-LDS_PEAK_GBS = 150000.0  # MI355X_MICROARCH.md, LDS section: ~150 TB/s aggregate for ds_read_b64 / b128 at 2.4 GHz
-
-
-def mfma_lds_bytes_per_stream_block(cfg: dict) -> int:
-    """Bytes that nam_a1_mfma_kernel's LDS instructions move per stream and 64-frame block, counted from the kernel's
-    per-job structure, not from a counter. Per layer job, 256 compute lanes: two shifted-tap reads
-    (16 B full layout, 8 B half layout = 8 channels), the input sample (4 B), nine 16-byte operand reads (four weight
-    tiles, extra tile, four constant vectors), one 16-byte publish by the lanes that own a channel quad; 256 mover
-    lanes: 16-byte ring-append read, two 16-byte history-set drops, one 16-byte tile drop."""
-    total = 0
-    for lc in cfg["layers"]:
-        C = lc["channels"]
-        half = C == 8
-        quads = (C + 3) // 4
-        per_lane_compute = 2 * (8 if half else 16) + 4 + 9 * 16
-        publish = 64 * quads * 16
-        movers = 64 * quads * 16 + 256 * (2 * 16 + 16)
-        total += len(lc["dilations"]) * (256 * per_lane_compute + publish + movers)
-    return total
-
-
-def measured_traffic(kernel: str, streams: int, block: int, launch: str):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), if the
-    profiled configuration matches this run."""
+def measured_traffic(kernel: str, model: str, streams: int, block: int, launch: str):
+    """Counters of the dominant kernel from committed rocprofv3 PMC passes (profiles/traffic.json), if the profiled
+    configuration matches this run: keyed by the kernel FUNCTION name the library reports for the batch
+    (nam_hip_batch_kernel_name), the model and the launch shape — a K-tap run can never pick up an a1 entry."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for e in json.load(f)["entries"]:
-                if (e["kernel"], e["streams"], e["block"], e["launch"]) == (kernel, streams, block, launch):
+                if (e["kernel"], e.get("model", "wavenet_a1_standard"), e["streams"], e["block"], e["launch"]) == (
+                        kernel, model, streams, block, launch):
                     return e
     except Exception:
         pass
@@ -223,6 +213,16 @@ def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: f
     return out
 
 
+
+CONFIGS = {
+    2: dict(model="wavenet_a1_standard", streams=256, slim_mix=False, name="BASELINE.json configs[1]"),
+    3: dict(model="lstm", streams=1024, slim_mix=False, name="BASELINE.json configs[2]"),
+    4: dict(model="wavenet_a2_max", streams=512, slim_mix=False, name="BASELINE.json configs[3] (4,096 streams over 8 GPUs = 512 per GPU)"),
+    5: dict(model="slimmable_wavenet", streams=768, slim_mix=True, name="BASELINE.json configs[4] (ratios 0.0 / 0.34 / 0.67 / 1.0 -> widths 1, 2, 3, 3)"),
+}
+SLIM_RATIOS = (0.0, 0.34, 0.67, 1.0)
+
+
 def cpu_worker(argv):
     """One worker of cpu_baseline's all-cores figure: prints its own xRT for one stream (no torch import)."""
     import numpy as np  # noqa: F401
@@ -240,30 +240,128 @@ def cpu_worker(argv):
     print(len(x) / SR / (time.perf_counter() - t0), flush=True)
 
 
+class HipEngine:
+    """The product path: one nam_hip batch on this rank's GPU, launched on a dedicated HIP stream."""
+
+    def __init__(self, nam, torch, model, n_streams, block, local_rank, kernel, classes):
+        self.torch, self.nam = torch, nam
+        self.dev = torch.device("cuda", local_rank)
+        self.batch = model.batch(n_streams, block, device=local_rank)
+        if kernel != "auto":
+            self.batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[kernel])
+        self.batch.Reset(prewarm=True)
+        if classes is not None:  # mixed widths: stream i of this rank runs at ratio SLIM_RATIOS[classes[i]]
+            for c in sorted(set(classes)):
+                self.batch.SetSlimmableSize(SLIM_RATIOS[c], [i for i, ci in enumerate(classes) if ci == c])
+        # a dedicated (non-null) HIP stream: the kernels are launched on it through the C ABI and the HIP events that
+        # time them are recorded on the same stream
+        self.stream = torch.cuda.Stream(self.dev)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        assert self.stream.cuda_stream != 0
+        self.block = block
+
+    def bind(self, x, y):
+        self.xp, self.yp, self.T = x.data_ptr(), y.data_ptr(), x.shape[2]
+
+    def run_steps(self, first, count, launch):
+        sh, b = self.stream.cuda_stream, self.block
+        if launch == "block":
+            for s in range(first, first + count):
+                self.batch.process_device(self.xp + s * b * 4, self.yp + s * b * 4, b, self.T, sh)
+        else:
+            self.batch.process_device(self.xp + first * b * 4, self.yp + first * b * 4, count * b, self.T, sh)
+
+    def event(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record(self.stream)
+        return e
+
+    def elapsed_ms(self, e0, e1):
+        return e0.elapsed_time(e1)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def kernel_name(self):
+        return self.batch.kernel_name()
+
+    def close(self):
+        self.batch.close()
+
+
+class StubEngine:
+    """--dry-run: stands in for the kernels on CPU tensors (y = 0.5 x on the window) so that the distributed plumbing
+    of this file — model-text broadcast, per-class sharding, scatter, the timed regions with their barriers and
+    all_reduce(MAX), gather — runs under gloo without a GPU. Never used for a measurement."""
+
+    def __init__(self, torch, block):
+        self.torch, self.block = torch, block
+
+    def bind(self, x, y):
+        self.x, self.y = x, y
+
+    def run_steps(self, first, count, launch):
+        a, b = first * self.block, (first + count) * self.block
+        self.y[:, :, a:b] = 0.5 * self.x[:, :1, a:b]
+
+    def event(self):
+        return time.perf_counter()
+
+    def elapsed_ms(self, e0, e1):
+        return (e1 - e0) * 1e3
+
+    def sync(self):
+        pass
+
+    def kernel_name(self):
+        return "stub"
+
+    def close(self):
+        pass
+
+
+def percentile(sorted_vals, q):
+    if not sorted_vals:
+        return None
+    i = min(len(sorted_vals) - 1, max(0, int(round(q * (len(sorted_vals) - 1)))))
+    return sorted_vals[i]
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--streams", type=int, default=256, help="streams per GPU (weak scaling)")
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--reps", type=int, default=11, help="timed regions of exactly --steps steps; value = the median region")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (see the module docstring)")
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (weak scaling); default from --config")
     ap.add_argument("--block", type=int, default=64)
-    ap.add_argument("--model", default="wavenet_a1_standard")
+    ap.add_argument("--model", default=None, help="fixture name under tests/golden/models; default from --config")
     ap.add_argument("--fast-tanh", type=int, default=1, help="benchmodel default: fast tanh ON (tools/benchmodel.cpp:27)")
     ap.add_argument("--launch", choices=["block", "resident"], default="block")
     ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the latency pass and the fast_tanh-off / zeros-input runs")
     ap.add_argument("--slim-mix", action="store_true",
                     help="slimmable models: stream s runs at ratio (0.0, 0.34, 0.67, 1.0)[s %% 4] (BASELINE.json configs[4])")
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="untimed GPU work on a scratch batch before the warm-up steps (brings the clocks up; the measured "
+                         "batch's state is not touched)")
     ap.add_argument("--check", type=int, default=1, help="verify stream 0 of rank 0 against the oracle after timing")
+    ap.add_argument("--dry-run", action="store_true", help="CPU tensors + gloo + a stub instead of the kernels (plumbing test)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    model_name = args.model or cfg["model"]
+    n_streams = args.streams or cfg["streams"]
+    slim_mix = args.slim_mix or (cfg["slim_mix"] and args.model is None)
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    import neuralampmodelercore_amd as nam
     from signals import stream_bank
+    from neuralampmodelercore_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -273,127 +371,182 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not distributed and args.gpus != 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
 
-    model_path = os.path.join(ROOT, "tests", "golden", "models", args.model + ".nam")
-    model = nam.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
-    ic, oc = model.NumInputChannels(), model.NumOutputChannels()
-    n_streams, block, K, W = args.streams, args.block, args.steps, args.warmup
-    total_steps = K + W
-    T = total_steps * block
+    model_path = os.path.join(ROOT, "tests", "golden", "models", model_name + ".nam")
+    block, K, W, R = args.block, args.steps, args.warmup, max(1, args.reps)
+    T = (W + K) * block
+
+    # ---- one-time weight broadcast: rank 0 reads the file, the text travels once over RCCL ----
+    model_text = None
+    if distributed:
+        model_text = sharding.broadcast_model_text(model_path if rank == 0 else None, src=0, device=dev)
+    model = nam = None
+    ic = oc = 1
+    if not args.dry_run:
+        import neuralampmodelercore_amd as nam
+        model = nam.get_dsp_json(model_text, fast_tanh=bool(args.fast_tanh)) if distributed else nam.get_dsp(
+            model_path, fast_tanh=bool(args.fast_tanh))
+        ic, oc = model.NumInputChannels(), model.NumOutputChannels()
+
+    # ---- ownership: global stream s has width class s % 4 when widths are mixed; every rank gets the same mix ----
+    n_total = n_streams * world
+    classes_global = [s % len(SLIM_RATIOS) for s in range(n_total)] if slim_mix else [0] * n_total
+    owners = [sharding.shard_by_class(classes_global, r, world) for r in range(world)]
+    mine = owners[rank]
+    n_local = len(mine)  # == n_streams unless a width class does not divide by the world size (ragged shards are fine)
+    local_classes = [classes_global[s] for s in mine] if slim_mix else None
 
     # ---- synthetic input bank: generated on rank 0, scattered to the ranks over RCCL ----
-    from neuralampmodelercore_amd import sharding
-    n_total = n_streams * world
-    bank = None
-    if rank == 0:
-        bank = stream_bank(n_total, T, seed=0)  # [world*n_streams, T]
+    bank = stream_bank(n_total, T, seed=0) if rank == 0 else None  # [world * n_streams, T]
     if distributed:
         full = torch.from_numpy(bank[:, None, :]).to(dev) if rank == 0 else None
-        x = sharding.scatter_streams(full, n_total, src=0, device=dev)  # RCCL send/recv of stream batches
+        x = sharding.scatter_rows(full, owners, src=0, device=dev)
         del full
     else:
         x = torch.from_numpy(bank[:, None, :]).to(dev)
-    assert tuple(x.shape) == (n_streams, ic, T)
-    y = torch.zeros((n_streams, oc, T), dtype=torch.float32, device=dev)
+    if ic > 1:  # multi-channel models: every input channel carries the stream's signal
+        x = x.repeat(1, ic, 1).contiguous()
+    assert tuple(x.shape) == (n_local, ic, T)
+    y = torch.zeros((n_local, oc, T), dtype=torch.float32, device=dev)
 
-    batch = model.batch(n_streams, block, device=local_rank)
-    if args.kernel != "auto":
-        batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA}[args.kernel])
-    batch.Reset(prewarm=True)
-    if args.slim_mix:
-        for i, ratio in enumerate((0.0, 0.34, 0.67, 1.0)):
-            batch.SetSlimmableSize(ratio, list(range(i, n_streams, 4)))
-    # a dedicated (non-null) HIP stream: the kernels are launched on it through the C ABI and the
-    # HIP events that time them are recorded on the same stream
-    stream = torch.cuda.Stream(dev)
-    stream.wait_stream(torch.cuda.current_stream(dev))
-    sh = stream.cuda_stream
-    assert sh != 0
-    xp, yp = x.data_ptr(), y.data_ptr()
-
-    def run_steps(first, count):
-        if args.launch == "block":
-            for s in range(first, first + count):
-                off = s * block * 4
-                batch.process_device(xp + off, yp + off, block, T, sh)
-        else:
-            off = first * block * 4
-            batch.process_device(xp + off, yp + off, count * block, T, sh)
-
-    def fence():
-        torch.cuda.synchronize(dev)
+    def fence(engine):
+        engine.sync()
         if distributed:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            engine.sync()
 
-    run_steps(0, W)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run_steps(W, K)
-    t_enqueue = time.perf_counter() - t0  # host time to enqueue the K steps (GPU still running)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
+    def reduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    if args.dry_run:
+        engine = StubEngine(torch, block)
+    else:
+        if args.spinup_ms > 0:  # clocks up, on a scratch batch whose state is thrown away
+            scratch = HipEngine(nam, torch, model, n_local, block, local_rank, args.kernel, local_classes)
+            scratch.bind(x, y)
+            t_end = time.perf_counter() + args.spinup_ms / 1e3
+            while time.perf_counter() < t_end:
+                scratch.run_steps(0, min(W + K, 64), "block")
+                scratch.sync()
+            scratch.close()
+            y.zero_()
+        engine = HipEngine(nam, torch, model, n_local, block, local_rank, args.kernel, local_classes)
+    engine.bind(x, y)
+
+    # ---- W warm-up steps, then R timed regions of exactly K steps (the window W..W+K is re-read, state runs on) ----
+    engine.run_steps(0, W, args.launch)
+    regions = []
+    got_dev = None
+    n_chk = min(T, 64 * 40)
+    for rep in range(R):
+        fence(engine)
+        t0 = time.perf_counter()
+        e0 = engine.event()
+        engine.run_steps(W, K, args.launch)
+        t_enq = time.perf_counter() - t0
+        e1 = engine.event()
+        fence(engine)
+        wall = time.perf_counter() - t0
+        wall_max, gpu_s_max = reduce_max([wall, engine.elapsed_ms(e0, e1) / 1e3])
+        regions.append({"wall_s": wall_max, "gpu_s": gpu_s_max, "enqueue_s": t_enq})
+        if rep == 0:
+            got_dev = y[0, 0, :n_chk].clone()  # parity sample: blocks 0..W+K of the FIRST pass over the window
+    order = sorted(range(R), key=lambda i: regions[i]["wall_s"])
+    med = regions[order[R // 2]]
+    wall_med, gpu_s_med = med["wall_s"], med["gpu_s"]
+
+    # alongside (not `value`): the same K blocks as ONE resident launch — the offline re-amp shape, no per-block kernel
+    # boundary — timed the same way
+    other = None
+    if args.launch == "block":
+        fence(engine)
+        t1 = time.perf_counter()
+        engine.run_steps(W, K, "resident")
+        fence(engine)
+        other = reduce_max([time.perf_counter() - t1])[0]
+
+    # per-launch latency distribution (min / p50 / p99 / p99.9, tools/bench_a2_fast.cpp:274-296): a separate pass with a
+    # HIP event between launches on the launch stream (the events cost a little, so this is never the timed region)
+    latency = None
+    if rank == 0 and not args.no_side_runs and args.launch == "block":
+        n_lat = min(K, 1000)
+        fence_local = engine.sync
+        fence_local()
+        evs = [engine.event()]
+        for s in range(n_lat):
+            engine.run_steps(W + s, 1, "block")
+            evs.append(engine.event())
+        fence_local()
+        d = sorted(engine.elapsed_ms(evs[i], evs[i + 1]) * 1e3 for i in range(n_lat))
+        latency = {"launches": n_lat, "min": round(d[0], 2), "p50": round(percentile(d, 0.5), 2),
+                   "p99": round(percentile(d, 0.99), 2), "p99_9": round(percentile(d, 0.999), 2), "max": round(d[-1], 2),
+                   "note": "us between consecutive HIP events on the launch stream, one launch per step (event overhead included)"}
     if distributed:
         dist.barrier()
-        torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
 
-    tmax = torch.tensor([wall, gpu_ms / 1e3], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall_max, gpu_s_max = float(tmax[0]), float(tmax[1])
-
-    # alongside (not `value`): the same K blocks as ONE resident launch — the offline re-amp shape, no per-block
-    # kernel boundary — timed the same way after the primary region; the input window is re-read, the state runs on
-    other = None
-    n_chk = min(T, 64 * 40)
-    got_dev = y[0, 0, :n_chk].clone()  # parity sample of the primary pass (the re-run below overwrites its window)
-    if args.launch == "block":
-        fence()
-        t1 = time.perf_counter()
-        batch.process_device(xp + W * block * 4, yp + W * block * 4, K * block, T, sh)
-        torch.cuda.synchronize(dev)
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-        t_res = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if distributed:
-            dist.all_reduce(t_res, op=dist.ReduceOp.MAX)
-        other = float(t_res[0])
-
-    # after the timed region: gather the last rendered block of every stream back to rank 0 over RCCL
-    tail = y[:, :, (total_steps - 1) * block:].contiguous()
-    gathered = sharding.gather_streams(tail, n_total, dst=0) if distributed else tail
+    # after the timed regions: gather the last rendered block of every stream back to rank 0 over RCCL
+    tail = y[:, :, (W + K - 1) * block:].contiguous()
+    gathered = sharding.gather_rows(tail, owners, n_total, dst=0) if distributed else tail
     finite = bool(torch.isfinite(y).all()) and (gathered is None or bool(torch.isfinite(gathered).all()))
+    gathered_ok = gathered is None or tuple(gathered.shape) == (n_total, oc, block)
 
     parity = None
-    if rank == 0 and args.check:
+    if rank == 0 and args.check and not args.dry_run:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nam_oracle
         ref = nam_oracle.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
-        if args.slim_mix:
-            ref.SetSlimmableSize(0.0)  # stream 0's size
+        if slim_mix:
+            ref.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[0]]])
         ref.Reset(SR, block)
-        r = ref.process_stream(bank[0, :n_chk], block)[0]
-        got = got_dev.cpu().numpy()
-        parity = float(np.max(np.abs(r - got)))
+        r = ref.process_stream(bank[mine[0], :n_chk], block)[0]
+        parity = float(np.max(np.abs(r - got_dev.cpu().numpy())))
+    elif rank == 0 and args.dry_run:
+        parity = float(torch.max(torch.abs(got_dev - 0.5 * x[0, 0, :n_chk])))
+
+    # side runs on rank 0 (N = 1): fast_tanh OFF and an all-zeros input (benchmodel's own input, tools/benchmodel.cpp:103-132)
+    side = {}
+    if rank == 0 and world == 1 and not args.no_side_runs and not args.dry_run:
+        def quick(engine2, xin):
+            engine2.bind(xin, y)
+            engine2.run_steps(0, W, args.launch)
+            ts = []
+            for _ in range(min(R, 5)):
+                engine2.sync()
+                t0 = time.perf_counter()
+                engine2.run_steps(W, K, args.launch)
+                engine2.sync()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return {"value": round(n_streams * block * K / SR / ts[len(ts) // 2], 1), "ms_per_step": round(ts[len(ts) // 2] / K * 1e3, 6)}
+        side["zeros_input"] = quick(engine, torch.zeros_like(x))
+        if model.architecture == "WaveNet" or True:
+            m2 = nam.get_dsp(model_path, fast_tanh=not bool(args.fast_tanh))
+            e2 = HipEngine(nam, torch, m2, n_streams, block, local_rank, args.kernel, local_classes)
+            side["fast_tanh_off" if args.fast_tanh else "fast_tanh_on"] = dict(quick(e2, x), kernel=e2.kernel_name())
+            e2.close()
 
     if rank == 0:
         macs = model_macs(model_path)
         flops_per_sample = 2 * macs
         samples_per_step_gpu = n_streams * block
-        total_samples = samples_per_step_gpu * K * world
-        xrt = total_samples / SR / wall_max
+        total_samples = n_total * block * K
+        xrt = total_samples / SR / wall_med
         launches = K if args.launch == "block" else 1
-        avg_launch_s = gpu_s_max / launches
+        avg_launch_s = gpu_s_med / launches
         samples_per_launch = samples_per_step_gpu * (1 if args.launch == "block" else K)
         flops_per_launch = flops_per_sample * samples_per_launch
         achieved_tf = flops_per_launch / avg_launch_s / 1e12
@@ -401,63 +554,75 @@ def main():
         hist = wavenet_history_bytes_per_sample(mj["config"]) if mj["architecture"] == "WaveNet" else 0
         bytes_per_sample = hist + 4 * (ic + oc)
         achieved_gbs = bytes_per_sample * samples_per_launch / avg_launch_s / 1e9
-        kname = {1: "generic", 2: "a1_valu", 3: "a1_mfma"}.get(batch.get_kernel(), "?")
-        tr = measured_traffic(kname, n_streams, block, args.launch)
+        kname = engine.kernel_name()
+        tr = measured_traffic(kname, model_name, n_streams, block, args.launch)
+        lds = None
+        if tr and tr.get("lds_idx_active_cycles") is not None and tr.get("kernel_cycles"):
+            # SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones (MI355X_MICROARCH.md, LDS);
+            # peak = every CU's LDS array busy for the whole kernel
+            busy = tr["lds_idx_active_cycles"] / (256.0 * tr["kernel_cycles"])
+            lds = {"achieved": round(busy, 4), "peak": 1.0, "unit": "fraction of LDS-array cycles busy (SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles))",
+                   "frac": round(busy, 4), "bank_conflict_frac_of_active": round(tr.get("lds_bank_conflict_cycles", 0) / max(tr["lds_idx_active_cycles"], 1), 4),
+                   "note": tr.get("lds_note", "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT, per launch")}
         out = {
-            "metric": "real-time audio streams (xRT) at 48 kHz, wavenet_a1_standard" if args.model == "wavenet_a1_standard"
-            else f"real-time audio streams (xRT) at 48 kHz, {args.model}",
+            "metric": f"real-time audio streams (xRT) at 48 kHz, {model_name}",
             "value": round(xrt, 1),
             "unit": "xRT (48 kHz real-time streams sustained)",
             "n_gpus": world,
             "steps": K,
-            "host_enqueue_us_per_step": round(t_enqueue / K * 1e6, 2),
             "warmup": W,
-            "ms_per_step": round(wall_max * 1e3 / K, 6),
+            "ms_per_step": round(wall_med * 1e3 / K, 6),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model}.nam, {n_streams} concurrent streams per GPU, buffer={block} samples, "
-                            f"fast_tanh={'on' if args.fast_tanh else 'off'} (BASELINE.json configs[1])",
+                "workload": f"{model_name}.nam, {n_streams} concurrent streams per GPU, buffer={block} samples, "
+                            f"fast_tanh={'on' if args.fast_tanh else 'off'}"
+                            + (", mixed widths (ratios 0.0/0.34/0.67/1.0 interleaved)" if slim_mix else "")
+                            + (f" ({cfg['name']})" if args.model is None and args.streams is None else ""),
+                "baseline_config": args.config,
                 "streams_per_gpu": n_streams, "block": block, "launch": args.launch,
                 "kernel": kname,
-                "sharding": f"streams x{world} (no data-path collective)",
+                "sharding": f"streams x{world}, contiguous per width class (no data-path collective)",
             },
-            # The path is bound by history traffic through HBM / Infinity Cache (191.8 KB of state per
-            # stream cannot stay in LDS): 8 TB/s / 3,848 B / 48 kHz = 43 k xRT, below the fp32 ceiling of
-            # 157.3 TF / 26,640 FLOP / 48 kHz = 123 k xRT. Both fractions are reported.
+            "repetitions": {"n": R, "statistic": "median region (each region = exactly `steps` steps between barrier+sync pairs, max over ranks)",
+                            "ms_per_step_all": [round(r_["wall_s"] * 1e3 / K, 6) for r_ in regions],
+                            "ms_per_step_min": round(regions[order[0]]["wall_s"] * 1e3 / K, 6),
+                            "ms_per_step_max": round(regions[order[-1]]["wall_s"] * 1e3 / K, 6)},
+            "host_enqueue_us_per_step": round(med["enqueue_s"] / K * 1e6, 2),
+            # The WaveNet path is bound by history traffic through HBM / Infinity Cache (the per-stream state cannot stay
+            # in LDS): e.g. a1_standard 8 TB/s / 3,848 B / 48 kHz = 43 k xRT, below its fp32 ceiling of 123 k xRT.
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "kernel": kname,
                 "traffic": (tr["hbm_bytes_per_launch"] if tr else None),
-                "traffic_note": (tr["note"] if tr else "no PMC pass committed for this exact configuration"),
+                "traffic_note": (tr["note"] if tr else "no PMC pass committed for this exact kernel / model / launch shape"),
                 "note": f"algorithmic {bytes_per_sample} B/stream-sample ({hist} history + {4 * (ic + oc)} I/O) x "
                         f"{samples_per_launch} stream-samples per launch; avg launch {avg_launch_s * 1e6:.2f} us from HIP "
-                        "events on the launch stream",
-                "lds": (None if kname != "a1_mfma" or mj["architecture"] != "WaveNet" or args.model != "wavenet_a1_standard" else {
-                    "achieved": round(mfma_lds_bytes_per_stream_block(mj["config"]) * n_streams
-                                      * (1 if args.launch == "block" else K) / avg_launch_s / 1e9, 1),
-                    "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(mfma_lds_bytes_per_stream_block(mj["config"]) * n_streams
-                                  * (1 if args.launch == "block" else K) / avg_launch_s / 1e9 / LDS_PEAK_GBS, 4),
-                    "note": "bytes moved by the kernel's LDS instructions, counted from its per-job structure (not a counter)"}),
+                        "events on the launch stream (median region)",
+                "lds": lds,
                 "compute": {"achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
                             "note": f"{flops_per_sample} FLOP/stream-sample; fp32 MFMA peak == fp32 vector peak"},
             },
-            "gpu_ms_total": round(gpu_s_max * 1e3, 3),
+            "gpu_ms_total": round(gpu_s_med * 1e3, 3),
+            "latency_us": latency,
             "resident_launch": (None if other is None else {
-                "value": round(n_streams * block * K * world / SR / other, 1), "ms_per_step": round(other / K * 1e3, 6),
+                "value": round(n_total * block * K / SR / other, 1), "ms_per_step": round(other / K * 1e3, 6),
                 "note": "same K blocks as one launch walking device-resident audio (offline re-amp shape); not `value`"}),
-            "finite": finite,
+            "finite": finite and gathered_ok,
             "max_abs_err_vs_oracle": parity,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(side)
+        if args.dry_run:
+            out["data"] = "dry-run (stub compute on CPU tensors over gloo): plumbing only, not a measurement"
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(model_path, bool(args.fast_tanh), block)
         print(json.dumps(out), flush=True)
-    batch.close()
+    engine.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -178,6 +178,10 @@ NAM_HIP_API int nam_hip_batch_synchronize(nam_hip_batch* batch);
 NAM_HIP_API int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel);
 NAM_HIP_API int nam_hip_batch_get_kernel(const nam_hip_batch* batch);
 NAM_HIP_API int nam_hip_batch_n_streams(const nam_hip_batch* batch);
+/* Name of the __global__ function the batch's largest stream group currently runs ("nam_a1_mfma_kernel",
+ * "nam_kt_mfma_kernel", "nam_a1_kernel", "nam_generic_kernel", "nam_lstm_mfma_reg_kernel", ...): the name
+ * rocprofv3 --kernel-trace reports (without template arguments), so measurements can be attributed to the right kernel. */
+NAM_HIP_API const char* nam_hip_batch_kernel_name(const nam_hip_batch* batch);
 
 /* Developer tool, not part of the drop-in surface: runs n_frames of silence through the MFMA kernel's profiling
  * instantiation; out_stamps (96 x 8 int64) receives, per wavefront w of workgroup 0 (row w): barrier cycles, total

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "nam_hip_model_get_info", "nam_hip_model_slimmable_breakpoints", "nam_hip_batch_create", "nam_hip_batch_destroy",
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
     "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_render_f32", "nam_hip_batch_synchronize",
-    "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams",
+    "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams", "nam_hip_batch_kernel_name",
     "nam_hip_batch_debug_timeline",
 ]
 
@@ -136,6 +136,8 @@ def load_library():
     L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
     L.nam_hip_batch_get_kernel.argtypes = [vp]
     L.nam_hip_batch_n_streams.argtypes = [vp]
+    L.nam_hip_batch_kernel_name.argtypes = [vp]
+    L.nam_hip_batch_kernel_name.restype = ctypes.c_char_p
     L.nam_hip_batch_debug_timeline.argtypes = [vp, ci, vp]
     _lib = L
     return L
@@ -262,6 +264,10 @@ class Batch:
 
     def get_kernel(self) -> int:
         return _check(self._L.nam_hip_batch_get_kernel(self._h))
+
+    def kernel_name(self) -> str:
+        """The __global__ function the batch's largest stream group runs (the name rocprofv3 reports)."""
+        return self._L.nam_hip_batch_kernel_name(self._h).decode()
 
     def synchronize(self):
         _check(self._L.nam_hip_batch_synchronize(self._h))

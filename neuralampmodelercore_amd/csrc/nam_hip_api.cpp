@@ -228,6 +228,26 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
   }
 }
 
+// Name of the __global__ function launch_group runs for this group (what rocprofv3 --kernel-trace reports, without
+// template arguments): lets callers attribute measurements to the right kernel.
+const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
+{
+  const Plan& p = *g.plan;
+  if (p.arch == ARCH_WAVENET)
+  {
+    switch (pick_kernel(b, g))
+    {
+      case NAM_HIP_KERNEL_GENERIC: return "nam_generic_kernel";
+      case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
+      default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
+    }
+  }
+  const LSTMPlan& L = p.lstm;
+  if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
+    return (L.input_size <= 4 && L.n_layers <= 2 && L.mf_nt <= 6) ? "nam_lstm_mfma_reg_kernel" : "nam_lstm_mfma_kernel";
+  return "nam_lstm_kernel";
+}
+
 // Launch one group's kernel over `n` streams given by `d_map` (nullptr = streams 0..n-1).
 int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const float* d_in, float* d_out,
                  int n_frames, long io_stride, hipStream_t s)
@@ -942,6 +962,18 @@ int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* 
     return rc;
   NAM_HIP_CHECK(e);
   return NAM_HIP_OK;
+}
+
+const char* nam_hip_batch_kernel_name(const nam_hip_batch* batch)
+{
+  if (!batch)
+    return "";
+  // the group with the most streams (a uniform batch has exactly one populated group)
+  const WidthGroup* best = &batch->groups[batch->model->full_width];
+  for (const auto& g : batch->groups)
+    if (g.streams.size() > best->streams.size())
+      best = &g;
+  return group_kernel_name(batch, *best);
 }
 
 int nam_hip_batch_n_streams(const nam_hip_batch* batch)

@@ -17,7 +17,7 @@ st = rows("trace_kernel_stats.csv")
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for r in st:
     print(f"{r.get('Name','?')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
-for tag, ctr in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", None)):
+for tag, ctr in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", None), ("pmc_inst", None)):
     rs = rows(f"{tag}_counter_collection.csv")
     agg = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(int)

@@ -1,0 +1,61 @@
+"""bench.py's distributed branch without GPUs: two processes over gloo run the SAME code the 8-GPU bench runs —
+model-text broadcast from rank 0, per-width-class sharding, scatter of the input bank, warm-up + timed regions with
+their barriers and all_reduce(MAX), gather of the rendered tail — with a stub in place of the kernels (--dry-run).
+Plus the unit tests of the class-aware partition (every GPU gets the same width mix)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_by_class_gives_every_rank_the_same_mix():
+    from neuralampmodelercore_amd import sharding
+    for n, world in ((768, 8), (4096, 8), (10, 3), (7, 2), (4, 8)):
+        classes = [s % 4 for s in range(n)]
+        owners = [sharding.shard_by_class(classes, r, world) for r in range(world)]
+        flat = sorted(s for o in owners for s in o)
+        assert flat == list(range(n))  # every stream owned exactly once
+        for c in range(4):
+            per_rank = [sum(1 for s in o if classes[s] == c) for o in owners]
+            assert max(per_rank) - min(per_rank) <= 1  # balanced within every class
+        assert all(o == sorted(o) for o in owners)
+    # one class = the plain contiguous partition
+    assert [sharding.shard_by_class([0] * 10, r, 3) for r in range(3)] == [list(range(*sharding.shard_range(10, r, 3))) for r in range(3)]
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("config,streams", [(5, 6), (2, 5)])
+def test_bench_distributed_branch_world2_gloo(config, streams):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "2",
+             "--reps", "3", "--config", str(config), "--streams", str(streams)],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=150) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]  # only rank 0 prints the JSON line
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["finite"] is True and line["max_abs_err_vs_oracle"] == 0.0
+    assert line["repetitions"]["n"] == 3 and len(line["repetitions"]["ms_per_step_all"]) == 3
+    assert line["value"] > 0 and line["config"]["streams_per_gpu"] == streams
+    assert line["data"].startswith("dry-run")
