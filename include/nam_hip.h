@@ -58,6 +58,11 @@ extern "C" {
                                     sizes (A2) -> K-tap kernel (4 waves per stream). Narrower submodels of a container
                                     that neither can run use NAM_HIP_KERNEL_A1 */
 
+#define NAM_HIP_KERNEL_A1_IL 4 /* interleaved-frame fp32-MFMA kernel (kernel size 3): compute wave w owns frames 4j + w, so
+                                  dilations 4..32 are DPP row shifts inside the wave and dilations >= 64 are the lane's own
+                                  ring rows — 4 workgroup barriers per block for wavenet_a1_standard instead of 20; one
+                                  loader wave stages the weights in LDS. Falls back to NAM_HIP_KERNEL_A1_MFMA */
+
 typedef struct nam_hip_model nam_hip_model;
 typedef struct nam_hip_batch nam_hip_batch;
 
@@ -78,7 +83,8 @@ typedef struct nam_hip_model_info
   double output_level; /* DSP::GetOutputLevel dsp.h:133 */
   int64_t num_weights;
   int32_t fast_tanh; /* load-time switch replacing the global Activation::enable_fast_tanh (activations.cpp:168) */
-  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: one of the A1 MFMA kernels can */
+  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: one of the A1 MFMA kernels can; bit 2: the
+                            interleaved-frame MFMA kernel can */
   int64_t state_bytes_per_stream; /* HBM history per stream */
   char version[32]; /* .nam "version" */
 } nam_hip_model_info;

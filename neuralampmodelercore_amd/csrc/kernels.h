@@ -52,6 +52,9 @@ struct A1Args
   int xt_off, n_xt; // blob offset / count of the extra tiles
   int lds_tiles_b, lds_xt_b, lds_cond_b, lds_bytes; // dynamic LDS layout (bytes)
   int prefetch; // the plan's ws_prefetch (mover prefetch depth the descriptors were built for)
+  // interleaved-frame kernel (plan.h: A1Plan::il_*)
+  int il_jobs, il_real_jobs, il_depth, il_exch;
+  int il_consts_b, il_xt_b, il_tiles_b, il_flag_b, il_lds_bytes;
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 
@@ -79,6 +82,7 @@ struct LSTMArgs
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
+hipError_t launch_a1_il(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,
                           hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);

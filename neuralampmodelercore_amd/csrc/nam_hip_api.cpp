@@ -211,12 +211,14 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 {
   const bool a1 = g.plan->a1.valid && g.d_a1;
   const bool mfma = a1 && (g.plan->a1.ws_ok || g.plan->a1.kt_ok);
+  const bool il = a1 && g.plan->a1.il_ok;
   const int fallback = a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
   switch (b->kernel)
   {
     case NAM_HIP_KERNEL_GENERIC: return NAM_HIP_KERNEL_GENERIC;
     case NAM_HIP_KERNEL_A1: return fallback;
     case NAM_HIP_KERNEL_A1_MFMA: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback;
+    case NAM_HIP_KERNEL_A1_IL: return il ? NAM_HIP_KERNEL_A1_IL : (mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback);
     default: // AUTO
       if (!mfma)
         return fallback;
@@ -239,6 +241,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
     {
       case NAM_HIP_KERNEL_GENERIC: return "nam_generic_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
+      case NAM_HIP_KERNEL_A1_IL: return "nam_a1_il_kernel";
       default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
     }
   }
@@ -284,7 +287,30 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
       a.n_mjobs = a.tiles_off = a.consts_off = 0;
       a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = a.prefetch = 0;
-      if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && n_frames > (1 << 28))
+      a.il_jobs = a.il_real_jobs = a.il_depth = a.il_exch = 0;
+      a.il_consts_b = a.il_xt_b = a.il_tiles_b = a.il_flag_b = a.il_lds_bytes = 0;
+      if (kernel == NAM_HIP_KERNEL_A1_IL)
+      {
+        int act = p.a1.arr[0].act;
+        for (int i = 1; i < p.a1.n_arrays; i++)
+          if (p.a1.arr[i].act != act)
+            act = -1;
+        a.tiles_off = p.a1.ws_tiles_off;
+        a.consts_off = p.a1.ws_consts_off;
+        a.xt_off = p.a1.ws_xt_off;
+        a.n_xt = p.a1.ws_n_xt;
+        a.il_jobs = p.a1.il_jobs;
+        a.il_real_jobs = p.a1.il_real_jobs;
+        a.il_depth = p.a1.il_depth;
+        a.il_exch = p.a1.il_exch;
+        a.il_consts_b = p.a1.il_consts_b;
+        a.il_xt_b = p.a1.il_xt_b;
+        a.il_tiles_b = p.a1.il_tiles_b;
+        a.il_flag_b = p.a1.il_flag_b;
+        a.il_lds_bytes = p.a1.il_lds_bytes;
+        NAM_HIP_CHECK(launch_a1_il(a, n, act, s));
+      }
+      else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && n_frames > (1 << 28))
         // the K-tap kernel addresses the launch's input through a 32-bit buffer descriptor (1 GiB of float32 audio per
         // stream and launch): longer launches take the VALU kernel, same state layout
         NAM_HIP_CHECK(launch_a1(a, n, s));
@@ -590,7 +616,8 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
                       : s.arch == ARCH_LSTM  ? (int64_t)s.lstm.weights.size()
                                              : 0; // a container has no weights of its own
   info->fast_tanh = s.fast_tanh ? 1 : 0;
-  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0);
+  info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0)
+                        | ((p.a1.valid && p.a1.il_ok) ? 4 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -901,7 +928,7 @@ int nam_hip_batch_synchronize(nam_hip_batch* batch)
 
 int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
-  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_MFMA)
+  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_IL)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
   if (kernel >= NAM_HIP_KERNEL_A1)
   {
@@ -913,6 +940,8 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
     const A1Plan& full = batch->groups[batch->model->full_width].plan->a1;
     if (kernel == NAM_HIP_KERNEL_A1_MFMA && !full.ws_ok && !full.kt_ok)
       return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the A1 MFMA kernel cannot run this model");
+    if (kernel == NAM_HIP_KERNEL_A1_IL && !full.il_ok)
+      return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the interleaved-frame MFMA kernel cannot run this model");
   }
   // a change of ring layout (channel-padded models: op program <-> A1 kernels) needs freshly reset state
   const int prev = batch->kernel;

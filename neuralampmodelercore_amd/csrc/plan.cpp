@@ -654,6 +654,131 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   a1.ws_ok = 1;
 }
 
+// Job table of nam_a1_il_kernel (plan.h: IlDesc / IlFetch). Built from the finished A1 plan: same eligibility, tiles,
+// constants and per-job flags as nam_a1_mfma_kernel; ring offsets are final (write-position table included).
+void build_a1_il(Plan& plan)
+{
+  A1Plan& a1 = plan.a1;
+  a1.il_ok = 0;
+  if (!a1.valid || !a1.ws_ok)
+    return;
+  int n_layers = 0;
+  for (int ai = 0; ai < a1.n_arrays; ai++)
+    n_layers += a1.arr[ai].n_layers;
+  // the kernel's job loop is unrolled 10 deep: jobs per block are padded to a multiple of 10 with idle jobs
+  const int D = 10;
+  const int NJ = (n_layers + 9) / 10 * 10;
+  if (NJ > kIlJobMax || n_layers > kWsJobMax)
+    return;
+  struct Geo
+  {
+    int C = 4, d = 1, R = 64, ring_b = 0, ring_id = 0, kind = IL_IDLE;
+  };
+  std::vector<Geo> geo((size_t)NJ);
+  int j = 0, n_exch = 0;
+  for (int ai = 0; ai < a1.n_arrays; ai++)
+    for (int l = 0; l < a1.arr[ai].n_layers; l++, j++)
+    {
+      Geo& G = geo[(size_t)j];
+      const A1Array& A = a1.arr[ai];
+      G.C = A.channels;
+      G.d = A.dil[l];
+      G.R = A.ring_len[l];
+      G.ring_b = A.ring_off[l] * 4;
+      G.ring_id = A.ring_id[l];
+      if (G.d >= kBlock)
+      {
+        // every tap lies in an earlier block. Across a block boundary of one launch a lane may only re-read rows it
+        // stored itself (same-wave program order is the only ordering there is without a barrier): lookbacks must be
+        // whole blocks
+        if (G.d % kBlock != 0)
+          return;
+        G.kind = IL_HIST;
+      }
+      else if (G.d == 4 || G.d == 8 || G.d == 16 || G.d == 32)
+        G.kind = IL_DPP;
+      else
+      {
+        if (2 * G.d > kBlock && (2 * G.d) % kBlock != 0)
+          return; // tap 0 would come from the ring at a lookback that is not a whole number of blocks (see above)
+        G.kind = IL_EXCH;
+        n_exch++;
+      }
+    }
+  a1.il_jobs = NJ;
+  a1.il_real_jobs = n_layers;
+  a1.il_depth = D;
+  a1.il_exch = n_exch;
+  // LDS: exchange windows [2] | constants [jobs][64] | extra tiles [n][256] | tiles [jobs][1024] | loader progress word
+  a1.il_consts_b = 2 * kIlWinB;
+  a1.il_xt_b = a1.il_consts_b + n_layers * 256;
+  a1.il_tiles_b = a1.il_xt_b + a1.ws_n_xt * 1024;
+  a1.il_flag_b = a1.il_tiles_b + n_layers * kWsTileFloats * 4;
+  a1.il_lds_bytes = a1.il_flag_b + 64;
+  if (a1.il_lds_bytes > 160 * 1024)
+    return;
+  std::memset(a1.il_desc, 0, sizeof(a1.il_desc));
+  std::memset(a1.il_fetch, 0, sizeof(a1.il_fetch));
+  auto xt_of = [&](int job) { return a1.il_xt_b + (a1.cdesc[job].xt_b - a1.ws_lds_xt_b); };
+  for (j = 0; j < NJ; j++)
+  {
+    const Geo& G = geo[(size_t)j];
+    IlDesc& Dd = a1.il_desc[j];
+    Dd.kind = G.kind;
+    if (G.kind != IL_IDLE)
+    {
+      Dd.flags = a1.cdesc[j].flags;
+      Dd.act = a1.cdesc[j].act;
+      Dd.gp = a1.cdesc[j].gp & 0xff;
+      Dd.ring_b = G.ring_b;
+      Dd.R = G.R;
+      Dd.ring_id = G.ring_id;
+      Dd.row_b = G.C * 4;
+      Dd.dil = G.d;
+      Dd.tap0_lds = (G.kind == IL_EXCH && 2 * G.d <= kBlock) ? 1 : 0;
+    }
+    else
+    {
+      Dd.R = kBlock;
+      Dd.row_b = 16;
+    }
+    // operands of the next real job (padding jobs pass job 0's along: they sit at the end of the block)
+    const int nj = (j + 1) % NJ;
+    const int nreal = geo[(size_t)nj].kind != IL_IDLE ? nj : 0;
+    Dd.n_consts_b = a1.il_consts_b + nreal * 256;
+    Dd.n_xt_b = xt_of(nreal);
+    Dd.n_tiles_b = a1.il_tiles_b + nreal * kWsTileFloats * 4;
+    Dd.n_ready = nreal + 1;
+    // requests for the job D ahead
+    const Geo& F = geo[(size_t)((j + D) % NJ)];
+    IlFetch& Ff = a1.il_fetch[j];
+    Ff.ring_b = F.ring_b;
+    Ff.R = F.kind != IL_IDLE ? F.R : kBlock;
+    Ff.ring_id = F.kind != IL_IDLE ? F.ring_id : 0;
+    Ff.row_b = F.kind != IL_IDLE ? F.C * 4 : 16;
+    Ff.nA = Ff.nB = 16;
+    switch (F.kind)
+    {
+      case IL_HIST:
+        Ff.LA = 2 * F.d;
+        Ff.LB = F.d;
+        break;
+      case IL_DPP:
+        Ff.LA = 2 * F.d;
+        Ff.LB = F.d;
+        Ff.nA = std::min(16, F.d / 2);
+        Ff.nB = F.d / 4;
+        break;
+      case IL_EXCH:
+        Ff.LA = kBlock; // the lane's own frame of the previous block, for the "previous" half of the LDS window
+        Ff.LB = 2 * F.d > kBlock ? 2 * F.d : 0; // tap 0 from the ring
+        break;
+      default: Ff.LA = Ff.LB = 0; break;
+    }
+  }
+  a1.il_ok = 1;
+}
+
 void build_a1(const WaveNetSpec& wn, Plan& plan)
 {
   A1Plan& a1 = plan.a1;
@@ -1126,6 +1251,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
       plan.a1.vdesc[j].f_rbase += table * 4;
     }
     build_a1_kt(plan);
+    build_a1_il(plan);
   }
   return plan;
 }

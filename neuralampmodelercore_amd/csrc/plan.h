@@ -165,6 +165,50 @@ struct VDesc // 16 x int32, one s_load_dwordx16
 };
 static_assert(sizeof(CDesc) == 32 && sizeof(VDesc) == 64, "descriptor sizes are part of the kernel ABI");
 
+// ---- Interleaved-frame MFMA kernel (nam_a1_il_kernel): same models, tiles and constants as nam_a1_mfma_kernel ----
+// Compute wave w of a stream's workgroup owns frames t = 4 j + w (j = lane & 15) of the 64-frame block instead of 16
+// consecutive ones. A dilated tap (t - L) then lives
+//   * L >= 64            : in an earlier block — the lane fetches it from the history ring itself (IL_HIST);
+//   * L = d or 2d, d in {4, 8, 16, 32}: in the SAME wave, L / 4 lanes down the 16-lane row — a DPP row shift of the
+//                          lane's own registers; the lanes that fall off the row take the previous block's frames from
+//                          the ring (IL_DPP);
+//   * anything else (d = 1, 2, ...): in another wave — one LDS window + one workgroup barrier (IL_EXCH).
+// wavenet_a1_standard: 4 barrier jobs per block instead of 20; the other 16 layers run without touching LDS for
+// activations and without waiting for anybody. No mover waves: every compute lane requests its own history kIlDepth
+// jobs ahead (two 16-byte buffer loads per job, lanes that need nothing use an out-of-range offset = no traffic) and
+// appends its own frame to the ring. A fifth "loader" wave copies the constants and the weight tiles of all jobs
+// into LDS once per launch, job by job, and publishes its progress in an LDS word the compute waves check.
+enum IlKind : int32_t
+{
+  IL_IDLE = 0, // padding job (jobs per block are padded to a multiple of the request depth)
+  IL_HIST = 1,
+  IL_DPP = 2,
+  IL_EXCH = 3
+};
+struct IlDesc // 16 x int32, one s_load_dwordx16
+{
+  int32_t flags; // CDescFlags
+  int32_t kind; // IlKind
+  int32_t act;
+  int32_t gp; // as CDesc::gp, bits 0-7 only: 16 * (C / 4 - 1)
+  int32_t ring_b, R, ring_id, row_b; // this job's ring: byte offset in the stream state, frames, position index, C * 4
+  int32_t dil;
+  int32_t tap0_lds; // IL_EXCH: 1 = tap 0 (lookback 2d <= 64) is read from the LDS window, 0 = from the ring request
+  int32_t n_consts_b, n_xt_b, n_tiles_b; // LDS byte offsets of the NEXT job's constants / extra tile / 4 tiles
+  int32_t n_ready; // loader progress required before the next job's operands may be read (its job index + 1)
+  int32_t pad[2];
+};
+struct IlFetch // 8 x int32: the two ring requests issued now for the job `depth` ahead
+{
+  int32_t ring_b, R, ring_id, row_b;
+  int32_t LA, LB; // lookbacks in frames (0 = no request)
+  int32_t nA, nB; // lanes j < n request (16 = every lane)
+};
+static_assert(sizeof(IlDesc) == 64 && sizeof(IlFetch) == 32, "descriptor sizes are part of the kernel ABI");
+constexpr int kIlJobMax = kWsJobMax + 8;
+constexpr int kIlWinRowB = kMfSC * 4; // LDS window row pitch (bytes)
+constexpr int kIlWinB = 2 * kBlock * kIlWinRowB; // one window: [previous 64 | current 64] frames
+
 // ---- K-tap MFMA kernel (nam_kt_mfma_kernel): single-array A1-family models with any per-layer kernel size ----
 // (A2: K = 6 / 15, head rechannel K = 16.) A layer is cut into CHUNKS of up to kKtTaps taps; the current frame is a
 // tap like any other (lookback 0). Only a layer's last chunk activates, applies the 1x1, publishes the layer output
@@ -215,6 +259,14 @@ struct A1Plan
   int32_t ws_prefetch = 6; // D
   CDesc cdesc[kWsJobMax];
   VDesc vdesc[kWsJobMax];
+  // interleaved-frame MFMA kernel (shares ws_tiles_off / ws_consts_off / ws_xt_off with the kernel above)
+  int32_t il_ok = 0;
+  int32_t il_jobs = 0, il_real_jobs = 0; // jobs per block incl. padding / real layers
+  int32_t il_depth = 5; // request depth = unroll factor (10 when it divides the layer count, else 5)
+  int32_t il_exch = 0; // IL_EXCH jobs (= workgroup barriers) per block
+  int32_t il_consts_b = 0, il_xt_b = 0, il_tiles_b = 0, il_flag_b = 0, il_lds_bytes = 0; // LDS layout (bytes); windows at 0
+  IlDesc il_desc[kIlJobMax];
+  IlFetch il_fetch[kIlJobMax];
   // K-tap MFMA kernel
   int32_t kt_ok = 0; // nam_kt_mfma_kernel can run this model (plan.cpp: build_a1_kt)
   int32_t kt_chunks = 0; // chunks per block

@@ -763,3 +763,71 @@ def test_generic_and_padded_a1_kernels_do_not_share_state(nam_lib, oracle, name)
     for s in range(2):
         r = _oracle_run(oracle, "wavenet_a1_standard", x[s], block, True)
         assert float(np.max(np.abs(r - y[s]))) <= 5e-5
+
+
+@pytest.mark.parametrize("name", ["wavenet_a1_standard"] + SYNTH_A1)
+@pytest.mark.parametrize("fast_tanh", [True, False])
+def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh):
+    """nam_a1_il_kernel (frames 4j + w per wave): exchange / DPP / ring-only jobs, idle padding jobs (13, 12, 15 layers),
+    full / half / partial-quad layouts, padded channel counts, run-time activation dispatch — one launch per buffer with
+    a ragged tail, one multi-block launch (requests prefetched across block boundaries), and alternating with the
+    wave-specialised MFMA kernel and the VALU kernel on the same state between buffers."""
+    nam = nam_lib
+    n_streams, block, n = 3, 64, 64 * 6 + 17
+    x = stream_bank(n_streams, n, seed=131)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+    assert model.info.has_a1_kernel & 4, "fixture must be eligible for the interleaved-frame kernel"
+    for mode, max_frames in (("blocks", block), ("one_launch", 512)):
+        refs = [_oracle_run(oracle, name, x[s], max_frames, fast_tanh) for s in range(n_streams)]
+        b = model.batch(n_streams, max_frames)
+        b.set_kernel(nam.KERNEL_A1_IL)
+        assert b.get_kernel() == nam.KERNEL_A1_IL and b.kernel_name() == "nam_a1_il_kernel"
+        b.Reset(prewarm=True)
+        y = b.process_stream(x, max_frames)
+        b.close()
+        for s in range(n_streams):
+            scale = max(1.0, float(np.max(np.abs(refs[s]))))
+            err = float(np.max(np.abs(refs[s] - y[s])))
+            assert err <= _tol(fast_tanh) * scale, (name, mode, s, err, scale)
+    # same rings, same write positions: the three A1 kernels are interchangeable between buffers
+    b = model.batch(n_streams, block)
+    b.Reset(prewarm=True)
+    parts = []
+    for i, k0 in enumerate(range(0, 64 * 6, 64)):
+        b.set_kernel((nam.KERNEL_A1_IL, nam.KERNEL_A1_MFMA, nam.KERNEL_A1_IL, nam.KERNEL_A1)[i % 4])
+        parts.append(b.process(x[:, k0:k0 + 64]))
+    y = np.concatenate(parts, axis=-1)
+    b.close()
+    for s in range(n_streams):
+        r = _oracle_run(oracle, name, x[s, :64 * 6], block, fast_tanh)
+        assert float(np.max(np.abs(r - y[s]))) <= _tol(fast_tanh) * max(1.0, float(np.max(np.abs(r)))), (name, "switch", s)
+
+
+def test_interleaved_mfma_kernel_headline_shape_and_determinism(nam_lib, oracle):
+    """256 streams x 8 buffers on nam_a1_il_kernel, every stream against the oracle; the same audio as block launches and
+    as one resident launch (twice each) is bit-identical: any unsynchronised hand-off (loader progress word, LDS
+    exchange windows, ring rows read back across blocks) would show up as run-to-run differences; 700 streams = more
+    workgroups than CUs."""
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    x = stream_bank(256, 64 * 8, seed=2025)
+    b = model.batch(256, 64)
+    b.set_kernel(nam.KERNEL_A1_IL)
+    b.Reset(prewarm=True)
+    y = b.process_stream(x, 64)
+    b.close()
+    ref = oracle.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    for s in range(256):
+        ref.Reset(48000.0, 64)
+        r = ref.process_stream(x[s], 64)
+        assert float(np.max(np.abs(r - y[s]))) <= 5e-5, s
+    x = stream_bank(700, 64 * 30 + 13, seed=123)
+    outs = []
+    for rep in range(4):
+        b = model.batch(700, 64)
+        b.set_kernel(nam.KERNEL_A1_IL)
+        b.Reset(prewarm=True)
+        outs.append(b.process_stream(x, 64) if rep % 2 == 0 else np.stack(b.render(list(x))))
+        b.close()
+    for yy in outs[1:]:
+        np.testing.assert_array_equal(outs[0], yy)
