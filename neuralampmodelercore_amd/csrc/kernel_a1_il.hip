@@ -37,6 +37,8 @@ using u4 = __attribute__((ext_vector_type(4))) unsigned;
 struct Slot
 {
   f4 a, b; // raw ring rows (16 bytes of the lane's channel quad) of the job's two requests
+  float inp; // input sample of the lane's frame in the block the job belongs to (every job carries it: a load inside
+             // an `if (block boundary)` would turn every counted vmcnt wait behind it into vmcnt(0))
 };
 struct Ops // one job's register-resident operands
 {
@@ -90,13 +92,17 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
   const int NJ = a.il_jobs; // multiple of D
   const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
   const int total = n_blocks * NJ;
-  volatile int* const progress = reinterpret_cast<volatile int*>(lds + a.il_flag_b);
+  // loader progress word: relaxed workgroup-scope atomics on an LDS-typed pointer = plain ds_read_b32 / ds_write_b32 that
+  // the optimiser neither hoists out of the polling loop nor (as it does for a volatile access through the generic
+  // `lds` pointer: a flat access) brackets with vmcnt(0) waits
+  int* const progress = reinterpret_cast<int*>(lds_il) + a.il_flag_b / 4;
+  auto progress_load = [&]() { return __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
   if (w == 4)
   {
     // ------------------------------------------------ loader role -------------------------------------
     if (lane == 0)
-      *progress = 0;
+      __hip_atomic_store(progress, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     lds_barrier(); // nobody looks at the progress word before it is zeroed (LDS contents are undefined at launch)
     const f4* __restrict__ csrc = reinterpret_cast<const f4*>(blob + a.consts_off);
     const f4* __restrict__ xsrc = reinterpret_cast<const f4*>(blob + a.xt_off);
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
                     v[jj][q]);
           __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the tiles (and, the first time, constants) are in LDS
           if (lane == 0)
-            *progress = j0 + jj + 1;
+            __hip_atomic_store(progress, j0 + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     // the compute waves' workgroup barriers count every wave of the workgroup
@@ -150,9 +156,11 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
   const bool hi_pair = (g >> 1) != 0; // half layout: this lane's pair is elements 2, 3 of its 16-byte quad
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st, 0, (int)(a.state_stride * 4), 0x00020000);
   const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(in ? in : st), 0, in ? a.n_frames * 4 : 0, 0x00020000);
+  const auto rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out ? out : st), 0, out ? a.n_frames * 4 : 0, 0x00020000);
   int* wpos_tbl = reinterpret_cast<int*>(st);
   int wposv = lane < a.n_rings ? wpos_tbl[lane] : 0; // lane r = write position of ring r
   const int ring_len_v = P->ring_len_by_id[lane];
+  int ji = 0, blk = 0; // job inside the block / block inside the launch
 
   // the two ring requests of the job described by F (`ahead` = 1: the job belongs to the next block)
   auto fetch = [&](Slot& s, const IlFetch& F, int ahead, bool valid) {
@@ -178,10 +186,11 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
       else
         s.b = r;
     }
+    s.inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((blk + ahead) * (kBlock * 4)), 0));
   };
   // a job's operands from LDS (offsets given by the PREVIOUS job's descriptor), progress word first
   auto load_ops = [&](Ops& o, int consts_b, int xt_b, int tiles_b) {
-    o.ready = *progress;
+    o.ready = progress_load();
     const unsigned a_t = v_lane16 + (unsigned)tiles_b;
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
   // wait (bounded) until the loader has published `need` jobs
   auto wait_loader = [&](int need) {
     int spins = 0;
-    while (uni(*progress) < need)
+    while (uni(progress_load()) < need)
     {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1 << 22))
@@ -207,12 +216,16 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
   Slot slot[D];
 #pragma unroll
   for (int u = 0; u < D; u++)
+  {
+    // (the same five-operation pattern as a job of the main loop, so that the waitcnt pass sees one request order on
+    // the loop's entry and back edges)
+    __builtin_amdgcn_raw_buffer_store_b128(il::u4{0u, 0u, 0u, 0u}, rsrc, (int)kOob, 0, WT ? 17 : 0);
     fetch(slot[u], P->il_fetch[NJ - D + u], 0, true); // position NJ - D + u describes job u
-  float cond = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rsrc_out, (int)kOob, 0, 0);
+  }
   lds_barrier(); // matches the loader's: the progress word is zeroed (the requests above are already in flight)
 
   f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f};
-  int ji = 0, blk = 0;
   int nvalid = min(kBlock, a.n_frames);
   unsigned win_par = 0; // which LDS window the next IL_EXCH job uses
   IlDesc Dn = P->il_desc[0];
@@ -236,30 +249,47 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
       Dn = P->il_desc[ji + 1 == NJ ? 0 : ji + 1];
       const IlFetch F = P->il_fetch[ji];
       const int flags = J.flags;
-      if (J.kind != IL_IDLE)
+      const bool real = J.kind != IL_IDLE;
+      // nothing moves across a job boundary (left alone, the scheduler hoists the next jobs' LDS / ring requests far up
+      // and the live ranges no longer fit the register file)
+      __builtin_amdgcn_sched_barrier(0);
+      // Every job issues the same five vector-memory operations in straight-line code — append, two ring requests,
+      // input sample, output sample — with out-of-range offsets where there is nothing to do. A VMEM operation inside
+      // a branch (or a different count on two paths) makes hipcc's waitcnt pass forget the request order, and every
+      // wait behind it becomes vmcnt(0).
+      const Slot S = slot[u % D];
+      asm volatile("" ::"v"(S.a), "v"(S.b), "v"(S.inp)); // one wait for the whole slot (the oldest requests in flight)
+      const float cond = S.inp;
+      Ops& O = ops[u & 1];
+      if (real && uni(O.ready) < ji + 1) // the loader had not published this job when its operands were read
       {
-        Ops& O = ops[u & 1];
-        if (uni(O.ready) < ji + 1) // the loader had not published this job when its operands were read: wait and re-read
-        {
-          wait_loader(ji + 1);
-          const IlDesc Pv = P->il_desc[ji == 0 ? NJ - 1 : ji - 1];
-          load_ops(O, Pv.n_consts_b, Pv.n_xt_b, Pv.n_tiles_b);
-        }
-        const unsigned g16max = (unsigned)J.gp;
-        if (flags & CD_X0)
-        {
-          x = O.ev * cond; // ev = first array's rechannel column (in_size == 1)
-          head = f4{0.f, 0.f, 0.f, 0.f};
-        }
-        // this job's input -> its history ring (row of frame t), 16 bytes per lane that owns a channel quad
-        {
-          const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + t);
-          const unsigned widx = min(v, v - (unsigned)J.R);
-          const bool ok = t < nvalid && v_g16 <= g16max;
-          const unsigned off = ok ? __umul24(widx, (unsigned)J.row_b) + v_g16 + (unsigned)J.ring_b : kOob;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(il::u4, x), rsrc, (int)off, 0, WT ? 17 : 0);
-        }
-        const Slot S = slot[u % D];
+        wait_loader(ji + 1);
+        const IlDesc Pv = P->il_desc[ji == 0 ? NJ - 1 : ji - 1]; // (padding jobs pass job 0's operands along)
+        load_ops(O, Pv.n_consts_b, Pv.n_xt_b, Pv.n_tiles_b);
+      }
+      const unsigned g16max = (unsigned)J.gp;
+      if (flags & CD_X0)
+      {
+        x = O.ev * cond; // ev = first array's rechannel column (in_size == 1)
+        head = f4{0.f, 0.f, 0.f, 0.f};
+      }
+      // this job's input -> its history ring (row of frame t), 16 bytes per lane that owns a channel quad
+      {
+        const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + t);
+        const unsigned widx = min(v, v - (unsigned)J.R);
+        const bool ok = real && t < nvalid && v_g16 <= g16max;
+        const unsigned off = ok ? __umul24(widx, (unsigned)J.row_b) + v_g16 + (unsigned)J.ring_b : kOob;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(il::u4, x), rsrc, (int)off, 0, WT ? 17 : 0);
+      }
+      // the slot is consumed (copied) above: request the job D ahead into it, then the next job's operands
+      {
+        const int ahead = ji + D >= NJ ? 1 : 0;
+        fetch(slot[u % D], F, ahead, !ahead || blk + 1 < n_blocks);
+      }
+      load_ops(ops[(u + 1) & 1], J.n_consts_b, J.n_xt_b, J.n_tiles_b);
+      float yout = 0.0f;
+      if (real)
+      {
         auto job_body = [&](auto nk_tag) {
           constexpr int NK = decltype(nk_tag)::value;
           // the lane's slice of a raw ring row: its quad (full layout) or its pair inside the quad (half layout)
@@ -339,31 +369,20 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
           }
           x = y0 + y1;
           if (flags & CD_POST_OUT)
-          {
-            const f4 hout = mfma_n<NK>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev;
-            if (out && g == 0 && t < nvalid)
-              out[(size_t)blk * kBlock + t] = head_scale * hout[0];
-          }
+            yout = head_scale * (mfma_n<NK>(O.xt, head, f4{0.f, 0.f, 0.f, 0.f}) + O.ev)[0];
           else if (flags & CD_POST_RECH)
             x = mfma_n<NK>(O.xt, x, f4{0.f, 0.f, 0.f, 0.f}); // next array's rechannel (no bias), its layout
         };
-        // the slot is consumed (copied) above: request the job D ahead into it, then the next job's operands
-        {
-          const int ahead = ji + D >= NJ ? 1 : 0;
-          fetch(slot[u % D], F, ahead, !ahead || blk + 1 < n_blocks);
-        }
-        load_ops(ops[(u + 1) & 1], J.n_consts_b, J.n_xt_b, J.n_tiles_b);
         if (flags & CD_HALF)
           job_body(std::integral_constant<int, 2>{});
         else
           job_body(std::integral_constant<int, 4>{});
       }
-      else
+      // the block's output sample (offset out of range on every job but the block's last)
       {
-        // padding job: keeps the request pipeline and the operand double buffer moving, computes nothing
-        const int ahead = ji + D >= NJ ? 1 : 0;
-        fetch(slot[u % D], F, ahead, !ahead || blk + 1 < n_blocks);
-        load_ops(ops[(u + 1) & 1], J.n_consts_b, J.n_xt_b, J.n_tiles_b);
+        const bool ok = (flags & CD_POST_OUT) && g == 0 && t < nvalid;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? t * 4 : (int)kOob,
+                                              uni(blk * (kBlock * 4)), 0);
       }
       if (++ji == NJ)
       {
@@ -373,7 +392,6 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
           wposv -= ring_len_v;
         blk++;
         nvalid = min(kBlock, a.n_frames - blk * kBlock);
-        cond = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni(blk * (kBlock * 4)), 0));
       }
     }
   }
