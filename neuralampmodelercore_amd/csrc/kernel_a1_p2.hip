@@ -1,0 +1,360 @@
+// kernel_a1_p2.hip — nam_a1_p2_kernel: the interleaved-frame MFMA kernel with the official A1 topology compiled in.
+#include "device_common.h"
+#include "il_common.h"
+
+namespace namhip
+{
+
+// ================================================================================================
+// nam_a1_p2_kernel<C0, C1> — nam_a1_il_kernel (kernel_a1_il.hip: frames t = 4 j + w per compute wave, DPP / ring /
+// exchange jobs, loader wave, request slots; read its header first) for ONE topology: two arrays of ten layers, kernel
+// size 3, dilations 1 ... 512 — every official WaveNet size (standard 16 / 8 channels, lite 12 / 6 -> 8, feather
+// 8 / 4). The job table is plan.h's constexpr p2::desc / p2::fetch evaluated at compile time (plan.cpp only selects
+// this kernel when those functions reproduce the model's run-time tables bit for bit), so a block is twenty
+// straight-line jobs: no descriptor loads, no kind / layout / flag tests, immediate LDS offsets and ring constants.
+// Why it exists: with one compute wave per SIMD the INSTRUCTION COUNT is the time. The descriptor-driven kernel
+// issues ~340 instructions per job for 16 MFMAs (2,100 cycles measured); this one ~1/3 of that.
+// Same state layout, rings and write positions as every other A1 kernel; same numerics (the MFMAs and the
+// activation code are the same, only the control flow is resolved by the compiler).
+// ================================================================================================
+template <int C0, int C1, int ACT_T, bool WT>
+__global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict__ blob, const A1Args a)
+{
+  using namespace mf;
+  using il::kOob;
+  using il::Ops;
+  using il::Slot;
+  constexpr int NJ = p2::kJobs;
+  constexpr int D = 10; // request depth in jobs (register sets); divides the 20 jobs of a block
+  extern __shared__ __attribute__((aligned(16))) float lds_p2[];
+  char* const lds = reinterpret_cast<char*>(lds_p2);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = uni(tid >> 6);
+  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  float* st = a.state + (size_t)stream * a.state_stride;
+  const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
+  int* const progress = reinterpret_cast<int*>(lds_p2) + p2::kFlagB / 4;
+  auto progress_load = [&]() { return __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+  if (w == 4)
+  {
+    // ------------------------------------------------ loader role (as in nam_a1_il_kernel) -------------
+    if (lane == 0)
+      __hip_atomic_store(progress, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_barrier();
+    const f4* __restrict__ csrc = reinterpret_cast<const f4*>(blob + a.consts_off);
+    const f4* __restrict__ xsrc = reinterpret_cast<const f4*>(blob + a.xt_off);
+    const f4* __restrict__ tsrc = reinterpret_cast<const f4*>(blob + a.tiles_off);
+    for (int i = lane; i < NJ * 16; i += 64)
+      lds_st4(lds, (unsigned)p2::kConstsB + (unsigned)i * 16u, csrc[i]);
+    for (int i = lane; i < p2::kXt * 64; i += 64)
+      lds_st4(lds, (unsigned)p2::kXtB + (unsigned)i * 16u, xsrc[i]);
+    constexpr int kB = 4;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NJ; j0 += kB)
+    {
+      f4 v[kB][4];
+#pragma unroll
+      for (int jj = 0; jj < kB; jj++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          v[jj][q] = tsrc[(size_t)(j0 + jj) * 256 + q * 64 + lane];
+#pragma unroll
+      for (int jj = 0; jj < kB; jj++)
+      {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          lds_st4(lds, (unsigned)p2::kTilesB + (unsigned)(j0 + jj) * 4096u + (unsigned)q * 1024u + (unsigned)lane * 16u, v[jj][q]);
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+        if (lane == 0)
+          __hip_atomic_store(progress, j0 + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    const int n_bar = n_blocks * 4; // IL_EXCH jobs per block: dilations 1 and 2 of both arrays
+    for (int i = 0; i < n_bar; i++)
+      lds_barrier();
+    return;
+  }
+
+  // -------------------------------------------------- compute role ------------------------------------
+  const int g = lane >> 4;
+  const int j = lane & 15;
+  const int t = 4 * j + w; // this lane's frame inside the block
+  const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
+  float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
+  const float head_scale = a.head_scale;
+  const float act_p0 = a.act_p0;
+  const unsigned v_g16 = (unsigned)g * 16u;
+  const unsigned v_gh8 = (unsigned)(g & 1) * 16u + (unsigned)(g >> 1) * 8u;
+  const unsigned v_lane16 = (unsigned)lane * 16u;
+  const bool hi_pair = (g >> 1) != 0;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st, 0, (int)(a.state_stride * 4), 0x00020000);
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(in ? in : st), 0, in ? a.n_frames * 4 : 0, 0x00020000);
+  const auto rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out ? out : st), 0, out ? a.n_frames * 4 : 0, 0x00020000);
+  int* wpos_tbl = reinterpret_cast<int*>(st);
+  int wposv = lane < NJ ? wpos_tbl[lane] : 0; // lane r = write position of ring r (ring r = job r)
+  const int ring_len_v = 2 * (1 << (lane % p2::kLayers)) + kBlock;
+  int blk = 0;
+
+  // the two ring requests (+ the input sample) of job TJ, which belongs to block blk + AHEAD
+  // (tl / gl16: the lane's frame and channel-quad offset, laundered per job by the caller — see `job`)
+  auto fetch = [&](Slot& s, auto tj_tag, auto ahead_tag, bool valid, int tl, unsigned gl16) {
+    constexpr int JF = (decltype(tj_tag)::value + NJ - p2::kDepth) % NJ; // table position whose entry describes job TJ
+    constexpr int AHEAD = decltype(ahead_tag)::value;
+    constexpr IlFetch F = p2::fetch(C0, C1, JF);
+    int wp = __builtin_amdgcn_readlane(wposv, F.ring_id) + (AHEAD ? kBlock : 0);
+    if (wp >= F.R)
+      wp -= F.R;
+    constexpr bool half = F.row_b == 32;
+    const unsigned chan = min(half ? (gl16 & 16u) : gl16, (unsigned)F.row_b - 16u);
+    const unsigned base = (unsigned)F.ring_b + chan;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+    {
+      constexpr int LA = F.LA, LB = F.LB, nA = F.nA, nB = F.nB;
+      const int L = q == 0 ? LA : LB;
+      const int n = q == 0 ? nA : nB;
+      f4 r;
+      if (L > 0)
+      {
+        const unsigned v = (unsigned)(wp + tl - L + F.R);
+        const unsigned idx = min(v, v - (unsigned)F.R);
+        const bool want = valid && tl < 4 * n; // lanes j < n
+        const unsigned off = want ? __umul24(idx, (unsigned)F.row_b) + base : kOob;
+        r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+      }
+      else // (exchange jobs have no second request; keep the five-operation pattern)
+        r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)kOob, 0, 0));
+      if (q == 0)
+        s.a = r;
+      else
+        s.b = r;
+    }
+    s.inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((blk + AHEAD) * (kBlock * 4)), 0));
+  };
+  auto load_ops = [&](Ops& o, auto j_tag) {
+    constexpr int JN = decltype(j_tag)::value; // the job whose operands are read
+    constexpr unsigned consts_b = p2::kConstsB + JN * 256, xt_b = p2::kXtB + p2::xt_index(JN) * 1024,
+                       tiles_b = p2::kTilesB + JN * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      o.t[q] = lds_ld4(lds, v_lane16 + tiles_b + 1024u * q);
+    o.bv = lds_ld4(lds, v_g16 + consts_b);
+    o.mv = lds_ld4(lds, v_g16 + consts_b + 64u);
+    o.b1v = lds_ld4(lds, v_g16 + consts_b + 128u);
+    (void)xt_b; // the extra tile / constants are read by the four jobs that have them, when they start (load_extra)
+  };
+  // extra tile + extra constants of job JN (array entry / exit jobs only): 8 VGPRs that need no double buffer
+  auto load_extra = [&](f4& xt, f4& ev, auto j_tag) {
+    constexpr int JN = decltype(j_tag)::value;
+    xt = lds_ld4(lds, v_lane16 + (unsigned)(p2::kXtB + p2::xt_index(JN) * 1024));
+    ev = lds_ld4(lds, v_g16 + (unsigned)(p2::kConstsB + JN * 256) + 192u);
+  };
+  auto wait_loader = [&](int need) {
+    int spins = 0;
+    while (uni(progress_load()) < need)
+    {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22))
+        __builtin_trap();
+    }
+  };
+
+  Slot slot[D];
+  // prologue: the requests of jobs 0 .. D-1, each in the five-operation pattern of a job
+  auto prologue = [&](auto u_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    __builtin_amdgcn_raw_buffer_store_b128(il::u4{0u, 0u, 0u, 0u}, rsrc, (int)kOob, 0, WT ? 17 : 0);
+    fetch(slot[U], std::integral_constant<int, U>{}, std::integral_constant<int, 0>{}, true, t, v_g16);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rsrc_out, (int)kOob, 0, 0);
+  };
+  il::for_each_index(prologue, std::make_integer_sequence<int, D>{});
+  lds_barrier();
+
+  f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f};
+  int nvalid = min(kBlock, a.n_frames);
+  // One operand register set: a job reads its own tiles / constants from LDS when it starts and hides the latency
+  // behind its ring append, its requests and its tap shuffles (~40 instructions) — a double buffer filled one job ahead
+  // costs 29 more VGPRs, and with them the compiler spilled request slots. Only the loader's progress word is read one
+  // job ahead (a wait on it would be exposed).
+  Ops O;
+  wait_loader(1);
+  int ready = progress_load();
+
+  // one job, everything about it known at compile time
+  auto job = [&](auto j_tag) {
+    constexpr int JI = decltype(j_tag)::value;
+    constexpr IlDesc J = p2::desc(C0, C1, 0, JI);
+    constexpr int flags = J.flags;
+    constexpr int NK = (flags & CD_HALF) ? 2 : 4;
+    constexpr unsigned g16max = (unsigned)J.gp;
+    const int act = a.act; // (only read by the run-time-dispatch instantiation)
+    __builtin_amdgcn_sched_barrier(0);
+    // The lane's frame and quad offset, opaque to the optimiser from here on: every address below would otherwise be a
+    // block-loop invariant, computed once for all twenty jobs in front of the loop and kept in (then spilled from)
+    // ~40 VGPRs; recomputing costs two or three VALU instructions per use.
+    int tl = t;
+    unsigned gl16 = v_g16;
+    asm volatile("" : "+v"(tl), "+v"(gl16));
+    const Slot S = slot[JI % D];
+    asm volatile("" ::"v"(S.a), "v"(S.b), "v"(S.inp)); // one wait for the whole slot (the oldest requests in flight)
+    const float cond = S.inp;
+    if (uni(ready) < JI + 1) // the loader had not published this job yet when the previous job looked
+      wait_loader(JI + 1);
+    load_ops(O, j_tag);
+    f4 xt = {0.f, 0.f, 0.f, 0.f}, ev = {0.f, 0.f, 0.f, 0.f};
+    if constexpr ((flags & (CD_X0 | CD_PRE_HEAD | CD_POST_RECH | CD_POST_OUT)) != 0)
+      load_extra(xt, ev, j_tag); // (behind the progress check above: the loader has published this job)
+    if constexpr ((flags & CD_X0) != 0)
+    {
+      x = ev * cond;
+      head = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // this job's input -> its history ring
+    {
+      const unsigned v = (unsigned)(__builtin_amdgcn_readlane(wposv, J.ring_id) + tl);
+      const unsigned widx = min(v, v - (unsigned)J.R);
+      const bool ok = tl < nvalid && gl16 <= g16max;
+      const unsigned off = ok ? __umul24(widx, (unsigned)J.row_b) + gl16 + (unsigned)J.ring_b : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(il::u4, x), rsrc, (int)off, 0, WT ? 17 : 0);
+    }
+    // requests of the job D ahead into the slot just consumed, then the next job's operands
+    {
+      constexpr int TJ = (JI + D) % NJ;
+      constexpr int AHEAD = JI + D >= NJ ? 1 : 0;
+      fetch(slot[JI % D], std::integral_constant<int, TJ>{}, std::integral_constant<int, AHEAD>{}, !AHEAD || blk + 1 < n_blocks, tl, gl16);
+    }
+    ready = progress_load(); // for the next job
+    auto slice = [&](const f4& r) { return NK == 4 ? r : (hi_pair ? f4{r[2], r[3], 0.f, 0.f} : f4{r[0], r[1], 0.f, 0.f}); };
+    f4 bt0, bt1;
+    if constexpr (J.kind == IL_HIST)
+    {
+      bt0 = slice(S.a);
+      bt1 = slice(S.b);
+    }
+    else if constexpr (J.kind == IL_DPP)
+    {
+      bt0 = bt1 = f4{0.f, 0.f, 0.f, 0.f};
+      il::dpp_taps<NK, J.dil / 4>(x, slice(S.a), slice(S.b), bt0, bt1);
+    }
+    else
+    {
+      // exchange: jobs 0, 1, 10, 11 -> windows 0, 1, 0, 1 of every block
+      constexpr unsigned wb = (unsigned)(JI & 1) * (unsigned)kIlWinB;
+      if (gl16 <= g16max)
+      {
+        lds_st4(lds, wb + (unsigned)(kBlock + tl) * kIlWinRowB + gl16, x);
+        lds_st4(lds, wb + (unsigned)tl * kIlWinRowB + gl16, S.a);
+      }
+      lds_barrier();
+      const unsigned chan = NK == 4 ? min(gl16, g16max) : v_gh8;
+      const unsigned r1 = wb + (unsigned)(kBlock + tl - J.dil) * kIlWinRowB + chan;
+      const unsigned r0 = wb + (unsigned)(kBlock + tl - 2 * J.dil) * kIlWinRowB + chan;
+      if constexpr (NK == 4)
+      {
+        bt1 = lds_ld4(lds, r1);
+        bt0 = lds_ld4(lds, r0);
+      }
+      else
+      {
+        const f2 p1 = *reinterpret_cast<const f2*>(lds + r1);
+        const f2 p0 = *reinterpret_cast<const f2*>(lds + r0);
+        bt1 = f4{p1[0], p1[1], 0.f, 0.f};
+        bt0 = f4{p0[0], p0[1], 0.f, 0.f};
+      }
+    }
+    if constexpr ((flags & CD_PRE_HEAD) != 0)
+      head = ((flags & CD_PREV_HALF) ? mfma_n<2>(xt, head, f4{0.f, 0.f, 0.f, 0.f}) : mfma_n<4>(xt, head, f4{0.f, 0.f, 0.f, 0.f}))
+             + ev;
+    f4 acc0 = O.mv * cond, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = O.bv;
+#pragma unroll
+    for (int s = 0; s < NK; s++)
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NK; s++)
+    {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
+    }
+    const f4 pre = (acc0 + acc1) + acc2;
+    const f4 z = act4<ACT_T>(act, NK == 2 ? f4{pre[0], pre[1], pre[0], pre[1]} : pre, act_p0);
+    head += z;
+    // pin the accumulator: otherwise the optimiser sinks these adds to the next USE of `head` (ten jobs later) and
+    // keeps every job's z alive until then — 40 VGPRs
+    asm volatile("" : "+v"(head));
+    f4 y0 = x + O.b1v, y1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NK; s += 2)
+    {
+      y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s], z[s], y0, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s + 1], z[s + 1], y1, 0, 0, 0);
+    }
+    x = y0 + y1;
+    float yout = 0.0f;
+    if constexpr ((flags & CD_POST_OUT) != 0)
+      yout = head_scale * (mfma_n<NK>(xt, head, f4{0.f, 0.f, 0.f, 0.f}) + ev)[0];
+    else if constexpr ((flags & CD_POST_RECH) != 0)
+      x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
+    {
+      const bool ok = (flags & CD_POST_OUT) && gl16 == 0 && tl < nvalid;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob,
+                                            uni(blk * (kBlock * 4)), 0);
+    }
+  };
+
+#pragma unroll 1
+  for (int b = 0; b < n_blocks; b++)
+  {
+    il::for_each_index(job, std::make_integer_sequence<int, NJ>{});
+    wposv += nvalid;
+    if (wposv >= ring_len_v)
+      wposv -= ring_len_v;
+    blk++;
+    nvalid = min(kBlock, a.n_frames - blk * kBlock);
+  }
+  if (w == 0 && lane < NJ)
+    wpos_tbl[lane] = wposv;
+}
+
+namespace
+{
+template <int C0, int C1, int ACT_T, bool WT>
+hipError_t launch_p2_inst(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  static bool configured = false;
+  if (!configured)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_p2_kernel<C0, C1, ACT_T, WT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p2::kLdsBytes);
+    if (e != hipSuccess)
+      return e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT>), dim3(n_blocks), dim3(320), p2::kLdsBytes, stream, a.blob, a);
+  return hipGetLastError();
+}
+template <int C0, int C1>
+hipError_t launch_p2_shape(const A1Args& a, int n_blocks, int act, hipStream_t stream)
+{
+  const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
+  if (act == ACT_FASTTANH)
+    return wt ? launch_p2_inst<C0, C1, ACT_FASTTANH, true>(a, n_blocks, stream) : launch_p2_inst<C0, C1, ACT_FASTTANH, false>(a, n_blocks, stream);
+  if (act == ACT_TANH)
+    return wt ? launch_p2_inst<C0, C1, ACT_TANH, true>(a, n_blocks, stream) : launch_p2_inst<C0, C1, ACT_TANH, false>(a, n_blocks, stream);
+  return wt ? launch_p2_inst<C0, C1, -1, true>(a, n_blocks, stream) : launch_p2_inst<C0, C1, -1, false>(a, n_blocks, stream);
+}
+} // namespace
+
+hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream)
+{
+  if (c0 == 16 && c1 == 8)
+    return launch_p2_shape<16, 8>(a, n_blocks, act, stream);
+  if (c0 == 12 && c1 == 8)
+    return launch_p2_shape<12, 8>(a, n_blocks, act, stream);
+  if (c0 == 8 && c1 == 4)
+    return launch_p2_shape<8, 4>(a, n_blocks, act, stream);
+  return hipErrorInvalidValue;
+}
+
+} // namespace namhip

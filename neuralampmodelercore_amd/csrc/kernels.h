@@ -55,6 +55,7 @@ struct A1Args
   // interleaved-frame kernel (plan.h: A1Plan::il_*)
   int il_jobs, il_real_jobs, il_depth, il_exch;
   int il_consts_b, il_xt_b, il_tiles_b, il_flag_b, il_lds_bytes;
+  int act; // the arrays' activation type when it is uniform (nam_a1_p2_kernel's run-time-dispatch instantiation)
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 
@@ -83,6 +84,7 @@ hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hip
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_a1_il(const A1Args& a, int n_blocks, int act, hipStream_t stream);
+hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
 hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,
                           hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);

@@ -123,6 +123,7 @@ struct nam_hip_batch
   // the caller-supplied stream of the last nam_hip_batch_process_device: control calls that free or rewrite device
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
+  bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
 };
 
 namespace
@@ -241,7 +242,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
     {
       case NAM_HIP_KERNEL_GENERIC: return "nam_generic_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
-      case NAM_HIP_KERNEL_A1_IL: return "nam_a1_il_kernel";
+      case NAM_HIP_KERNEL_A1_IL: return (p.a1.p2_ok && !b->il_generic) ? "nam_a1_p2_kernel" : "nam_a1_il_kernel";
       default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
     }
   }
@@ -288,7 +289,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.n_mjobs = a.tiles_off = a.consts_off = 0;
       a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = a.prefetch = 0;
       a.il_jobs = a.il_real_jobs = a.il_depth = a.il_exch = 0;
-      a.il_consts_b = a.il_xt_b = a.il_tiles_b = a.il_flag_b = a.il_lds_bytes = 0;
+      a.il_consts_b = a.il_xt_b = a.il_tiles_b = a.il_flag_b = a.il_lds_bytes = a.act = 0;
       if (kernel == NAM_HIP_KERNEL_A1_IL)
       {
         int act = p.a1.arr[0].act;
@@ -308,7 +309,11 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
         a.il_tiles_b = p.a1.il_tiles_b;
         a.il_flag_b = p.a1.il_flag_b;
         a.il_lds_bytes = p.a1.il_lds_bytes;
-        NAM_HIP_CHECK(launch_a1_il(a, n, act, s));
+        a.act = act;
+        if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
+          NAM_HIP_CHECK(launch_a1_p2(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
+        else
+          NAM_HIP_CHECK(launch_a1_il(a, n, act, s));
       }
       else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && n_frames > (1 << 28))
         // the K-tap kernel addresses the launch's input through a 32-bit buffer descriptor (1 GiB of float32 audio per
@@ -617,7 +622,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
                                              : 0; // a container has no weights of its own
   info->fast_tanh = s.fast_tanh ? 1 : 0;
   info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0)
-                        | ((p.a1.valid && p.a1.il_ok) ? 4 : 0);
+                        | ((p.a1.valid && p.a1.il_ok) ? 4 : 0) | ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? 8 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -655,6 +660,10 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
     return fail(NAM_HIP_ERR_DEVICE, "nam_hip_batch_create: out of host memory");
   b->model = model;
   b->device = device;
+  {
+    const char* e = std::getenv("NAM_HIP_IL_GENERIC");
+    b->il_generic = e && e[0] == '1';
+  }
   b->n_streams = n_streams;
   b->max_frames = max_frames;
   // everything that can fail runs inside this lambda; on failure the half-built batch goes through

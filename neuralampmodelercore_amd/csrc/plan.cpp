@@ -777,6 +777,27 @@ void build_a1_il(Plan& plan)
     }
   }
   a1.il_ok = 1;
+  // the official topology with compile-time tables (plan.h: namespace p2): only if those tables ARE this model's
+  a1.p2_ok = 0;
+  if (a1.n_arrays == 2 && n_layers == p2::kJobs && NJ == p2::kJobs && D == p2::kDepth && a1.ws_n_xt == p2::kXt
+      && a1.il_consts_b == p2::kConstsB && a1.il_xt_b == p2::kXtB && a1.il_tiles_b == p2::kTilesB
+      && a1.il_flag_b == p2::kFlagB && a1.arr[0].act == a1.arr[1].act)
+  {
+    const int C0 = a1.arr[0].channels, C1 = a1.arr[1].channels;
+    bool same = (C0 == 16 && C1 == 8) || (C0 == 12 && C1 == 8) || (C0 == 8 && C1 == 4); // instantiated in kernel_a1_p2.hip
+    for (j = 0; same && j < NJ; j++)
+    {
+      const IlDesc e = p2::desc(C0, C1, a1.arr[0].act, j);
+      const IlFetch f = p2::fetch(C0, C1, j);
+      same = std::memcmp(&e, &a1.il_desc[j], sizeof(e)) == 0 && std::memcmp(&f, &a1.il_fetch[j], sizeof(f)) == 0;
+    }
+    if (same)
+    {
+      a1.p2_ok = 1;
+      a1.p2_c0 = C0;
+      a1.p2_c1 = C1;
+    }
+  }
 }
 
 void build_a1(const WaveNetSpec& wn, Plan& plan)

@@ -209,6 +209,85 @@ constexpr int kIlJobMax = kWsJobMax + 8;
 constexpr int kIlWinRowB = kMfSC * 4; // LDS window row pitch (bytes)
 constexpr int kIlWinB = 2 * kBlock * kIlWinRowB; // one window: [previous 64 | current 64] frames
 
+// ---- The official A1 topology at compile time (nam_a1_p2_kernel) ----------------------------------------------
+// Every official WaveNet size (standard 16/8, lite 12/6, feather 8/4 channels) is two arrays of ten layers, kernel
+// size 3, dilations 1, 2, 4, ... 512. For that topology the whole job table of the interleaved-frame kernel is a
+// function of the two (padded) channel counts: these constexpr functions restate plan.cpp's build_a1_il for it, the
+// kernel instantiates them as compile-time constants (no descriptor loads, no kind / layout / flag branches, immediate
+// LDS offsets), and plan.cpp sets A1Plan::p2_ok only if they reproduce the model's il_desc / il_fetch tables exactly.
+namespace p2
+{
+constexpr int kLayers = 10, kJobs = 20, kDepth = 10, kXt = 3;
+constexpr int kConstsB = 2 * kIlWinB;
+constexpr int kXtB = kConstsB + kJobs * 256;
+constexpr int kTilesB = kXtB + kXt * 1024;
+constexpr int kFlagB = kTilesB + kJobs * kWsTileFloats * 4;
+constexpr int kLdsBytes = kFlagB + 64;
+constexpr int chan(int C0, int C1, int j) { return j < kLayers ? C0 : C1; }
+constexpr int dil(int j) { return 1 << (j % kLayers); }
+constexpr int kind(int j) { return dil(j) >= kBlock ? IL_HIST : dil(j) >= 4 ? IL_DPP : IL_EXCH; }
+// float offset of job j's ring in the stream state: write-position table (64 words), then the rings in layer order
+constexpr int ring_floats(int C0, int C1, int j)
+{
+  int off = kBlock;
+  for (int k = 0; k < j; k++)
+    off += chan(C0, C1, k) * (2 * dil(k) + kBlock);
+  return off;
+}
+constexpr int xt_index(int j) { return j == 10 ? 1 : j == 19 ? 2 : 0; }
+constexpr IlDesc desc(int C0, int C1, int act, int j)
+{
+  IlDesc d{};
+  const int C = chan(C0, C1, j);
+  d.flags = CD_LAYER | (C == 8 ? CD_HALF : 0) | (j == 0 ? CD_X0 : 0) | (j == 9 ? CD_POST_RECH : 0)
+            | (j == 10 ? (CD_PRE_HEAD | (C0 == 8 ? CD_PREV_HALF : 0)) : 0) | (j == 19 ? CD_POST_OUT : 0);
+  d.kind = kind(j);
+  d.act = act;
+  d.gp = 16 * (C / 4 - 1);
+  d.ring_b = ring_floats(C0, C1, j) * 4;
+  d.R = 2 * dil(j) + kBlock;
+  d.ring_id = j;
+  d.row_b = C * 4;
+  d.dil = dil(j);
+  d.tap0_lds = kind(j) == IL_EXCH ? 1 : 0;
+  const int n = (j + 1) % kJobs;
+  d.n_consts_b = kConstsB + n * 256;
+  d.n_xt_b = kXtB + xt_index(n) * 1024;
+  d.n_tiles_b = kTilesB + n * kWsTileFloats * 4;
+  d.n_ready = n + 1;
+  return d;
+}
+constexpr IlFetch fetch(int C0, int C1, int j)
+{
+  IlFetch f{};
+  const int t = (j + kDepth) % kJobs; // the job the requests are for
+  const int d = dil(t);
+  f.ring_b = ring_floats(C0, C1, t) * 4;
+  f.R = 2 * d + kBlock;
+  f.ring_id = t;
+  f.row_b = chan(C0, C1, t) * 4;
+  f.nA = f.nB = 16;
+  if (kind(t) == IL_HIST)
+  {
+    f.LA = 2 * d;
+    f.LB = d;
+  }
+  else if (kind(t) == IL_DPP)
+  {
+    f.LA = 2 * d;
+    f.LB = d;
+    f.nA = d / 2 < 16 ? d / 2 : 16;
+    f.nB = d / 4;
+  }
+  else
+  {
+    f.LA = kBlock;
+    f.LB = 0;
+  }
+  return f;
+}
+} // namespace p2
+
 // ---- K-tap MFMA kernel (nam_kt_mfma_kernel): single-array A1-family models with any per-layer kernel size ----
 // (A2: K = 6 / 15, head rechannel K = 16.) A layer is cut into CHUNKS of up to kKtTaps taps; the current frame is a
 // tap like any other (lookback 0). Only a layer's last chunk activates, applies the 1x1, publishes the layer output
@@ -267,6 +346,8 @@ struct A1Plan
   int32_t il_consts_b = 0, il_xt_b = 0, il_tiles_b = 0, il_flag_b = 0, il_lds_bytes = 0; // LDS layout (bytes); windows at 0
   IlDesc il_desc[kIlJobMax];
   IlFetch il_fetch[kIlJobMax];
+  int32_t p2_ok = 0; // nam_a1_p2_kernel<p2_c0, p2_c1> runs this model (the official topology, see namespace p2)
+  int32_t p2_c0 = 0, p2_c1 = 0; // the two arrays' (padded) channel counts
   // K-tap MFMA kernel
   int32_t kt_ok = 0; // nam_kt_mfma_kernel can run this model (plan.cpp: build_a1_kt)
   int32_t kt_chunks = 0; // chunks per block

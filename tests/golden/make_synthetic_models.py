@@ -29,6 +29,10 @@ SPECS = {
     # zero-pads it to 8 for the A1 kernels (plan.cpp: pad_channels_for_mfma)
     "synth_a1_lite": dict(arrays=[(12, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
                                   (6, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=15),
+    # the official "feather" shape: 8 -> 4 channels, ten layers each (half layout first, then a single channel quad):
+    # the third instantiation of the compile-time-topology kernel (nam_a1_p2_kernel<8, 4>)
+    "synth_a1_feather": dict(arrays=[(8, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
+                                     (4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=17),
     # 14 -> 10 channels (padded to 16 -> 12), Sigmoid: the padded channels carry f(0) = 0.5 against zero weights
     "synth_a1_c14": dict(arrays=[(14, [1, 2, 4, 8, 16, 32], "Sigmoid", True), (10, [64, 128, 256, 512, 1, 2], "Sigmoid", True)], seed=16),
     "synth_a1_mixed": dict(arrays=[(16, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 1, 2], "ReLU", True),

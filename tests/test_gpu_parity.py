@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet"]
 # synthetic A1-family fixtures (tests/golden/make_synthetic_models.py) that reach the MFMA kernel's variants
-SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed", "synth_a1_lite", "synth_a1_c14"]
+SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed", "synth_a1_lite", "synth_a1_c14", "synth_a1_feather"]
 # single-array fixtures with per-layer kernel sizes 1..16 and a head rechannel with taps: the K-tap MFMA kernel
 SYNTH_KT = ["synth_kt_c8", "synth_kt_c16", "synth_kt_c12", "synth_kt_c4"]
 
@@ -767,7 +767,8 @@ def test_generic_and_padded_a1_kernels_do_not_share_state(nam_lib, oracle, name)
 
 @pytest.mark.parametrize("name", ["wavenet_a1_standard"] + SYNTH_A1)
 @pytest.mark.parametrize("fast_tanh", [True, False])
-def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh):
+@pytest.mark.parametrize("generic", [False, True])
+def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, monkeypatch, name, fast_tanh, generic):
     """nam_a1_il_kernel (frames 4j + w per wave): exchange / DPP / ring-only jobs, idle padding jobs (13, 12, 15 layers),
     full / half / partial-quad layouts, padded channel counts, run-time activation dispatch — one launch per buffer with
     a ragged tail, one multi-block launch (requests prefetched across block boundaries), and alternating with the
@@ -777,11 +778,19 @@ def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh
     x = stream_bank(n_streams, n, seed=131)
     model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
     assert model.info.has_a1_kernel & 4, "fixture must be eligible for the interleaved-frame kernel"
+    # the official topology (standard, lite, feather) runs nam_a1_p2_kernel, its job table compiled in; `generic` forces
+    # the descriptor-driven nam_a1_il_kernel on the same model (for other topologies the two runs are the same kernel)
+    p2 = bool(model.info.has_a1_kernel & 8)
+    assert p2 == (name in ("wavenet_a1_standard", "synth_a1_lite", "synth_a1_feather"))
+    if generic and not p2:
+        pytest.skip("not the official topology: already covered by the generic=False run")
+    monkeypatch.setenv("NAM_HIP_IL_GENERIC", "1" if generic else "0")
+    want_name = "nam_a1_p2_kernel" if (p2 and not generic) else "nam_a1_il_kernel"
     for mode, max_frames in (("blocks", block), ("one_launch", 512)):
         refs = [_oracle_run(oracle, name, x[s], max_frames, fast_tanh) for s in range(n_streams)]
         b = model.batch(n_streams, max_frames)
         b.set_kernel(nam.KERNEL_A1_IL)
-        assert b.get_kernel() == nam.KERNEL_A1_IL and b.kernel_name() == "nam_a1_il_kernel"
+        assert b.get_kernel() == nam.KERNEL_A1_IL and b.kernel_name() == want_name
         b.Reset(prewarm=True)
         y = b.process_stream(x, max_frames)
         b.close()

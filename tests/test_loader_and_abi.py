@@ -32,7 +32,7 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
     m = nam_lib.get_dsp(model_path("wavenet_a1_standard"))
     assert m.GetExpectedSampleRate() == -1.0 and not m.HasLoudness()  # get_dsp.cpp:275-281
     assert m.GetPrewarmSamples() == 4093  # model.cpp:653-658
-    assert m.info.has_a1_kernel == 7  # VALU + MFMA + interleaved-frame MFMA specialisations
+    assert m.info.has_a1_kernel == 15  # VALU + MFMA + interleaved-frame MFMA (+ its compile-time-topology form)
     # write-position table (64 words) + one ring of (K-1)*d + 64 frames per layer, rounded up to 64 floats
     floats = 64 + sum(c * (2 * d + 64) for c in (16, 8) for d in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512))
     assert m.info.state_bytes_per_stream == 4 * ((floats + 63) // 64 * 64)
@@ -41,15 +41,16 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
 
 
 @pytest.mark.parametrize("name,bits", [
-    ("wavenet_a1_standard", 7), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
+    ("wavenet_a1_standard", 15), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
     ("synth_a1_mixed", 7),  # kernel size 3 everywhere, several arrays: the wave-specialised + interleaved MFMA kernels
-    ("synth_a1_lite", 7), ("synth_a1_c14", 7),  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
+    ("synth_a1_lite", 15), ("synth_a1_feather", 15), ("synth_a1_c14", 7),  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
     ("slimmable_wavenet", 1),  # 3 channels: VALU kernel only
     ("wavenet_a2_max", 0), ("wavenet_condition_dsp", 0), ("synth_posthead", 0), ("synth_multich", 0),  # generic kernel
     ("lstm", 0)])
 def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
     """has_a1_kernel: bit 0 = the VALU A1 kernel, bit 1 = one of the MFMA kernels (plan.cpp: build_a1 / build_a1_ws /
-    build_a1_kt), bit 2 = the interleaved-frame MFMA kernel (build_a1_il). Decided on the host at load time, so it is checkable without a GPU."""
+    build_a1_kt), bit 2 = the interleaved-frame MFMA kernel (build_a1_il), bit 3 = its compile-time-topology
+    form for the official sizes (plan.h: namespace p2). Decided on the host at load time, so it is checkable without a GPU."""
     assert nam_lib.get_dsp(model_path(name)).info.has_a1_kernel == bits
 
 
@@ -160,7 +161,7 @@ def test_lookup_table_load_option(nam_lib):
     nam = nam_lib
     m = nam.get_dsp(model_path("wavenet_a1_standard"), luts={"Tanh": (-5.0, 5.0, 1024)})
     assert m.info.has_a1_kernel == 0  # tables are interpolated by the op-program interpreter only
-    assert nam.get_dsp(model_path("wavenet_a1_standard")).info.has_a1_kernel == 7
+    assert nam.get_dsp(model_path("wavenet_a1_standard")).info.has_a1_kernel == 15
     with pytest.raises(nam.NamHipError) as e:
         nam.get_dsp(model_path("wavenet"), luts={"ReLU": (-1.0, 1.0, 16)})
     assert "Tried to enable LUT for a function other than Tanh, Sigmoid, or SiLU" in str(e.value)
