@@ -14,18 +14,19 @@ namespace namhip
 // straight-line jobs: no descriptor loads, no kind / layout / flag tests, immediate LDS offsets and ring constants.
 // Why it exists: with one compute wave per SIMD the INSTRUCTION COUNT is the time. The descriptor-driven kernel
 // issues ~340 instructions per job for 16 MFMAs (2,100 cycles measured); this one ~1/3 of that.
+// Four waves per stream, no loader wave: the weights are staged in LDS by the compute waves themselves in front of
+// the first job (they arrive while the ring requests are in flight anyway), which leaves ONE wave per SIMD — the whole
+// 512-entry register file per wave — and that is what allows a request slot for every job of a block.
 // Same state layout, rings and write positions as every other A1 kernel; same numerics (the MFMAs and the
 // activation code are the same, only the control flow is resolved by the compiler).
 // ================================================================================================
 template <int C0, int C1, int ACT_T, bool WT>
-__global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict__ blob, const A1Args a)
+__global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict__ blob, const A1Args a)
 {
   using namespace mf;
   using il::kOob;
   using il::Ops;
-  using il::Slot;
   constexpr int NJ = p2::kJobs;
-  constexpr int D = 10; // request depth in jobs (register sets); divides the 20 jobs of a block
   extern __shared__ __attribute__((aligned(16))) float lds_p2[];
   char* const lds = reinterpret_cast<char*>(lds_p2);
   const int tid = threadIdx.x;
@@ -34,50 +35,7 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
   float* st = a.state + (size_t)stream * a.state_stride;
   const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
-  int* const progress = reinterpret_cast<int*>(lds_p2) + p2::kFlagB / 4;
-  auto progress_load = [&]() { return __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
-  if (w == 4)
-  {
-    // ------------------------------------------------ loader role (as in nam_a1_il_kernel) -------------
-    if (lane == 0)
-      __hip_atomic_store(progress, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    lds_barrier();
-    const f4* __restrict__ csrc = reinterpret_cast<const f4*>(blob + a.consts_off);
-    const f4* __restrict__ xsrc = reinterpret_cast<const f4*>(blob + a.xt_off);
-    const f4* __restrict__ tsrc = reinterpret_cast<const f4*>(blob + a.tiles_off);
-    for (int i = lane; i < NJ * 16; i += 64)
-      lds_st4(lds, (unsigned)p2::kConstsB + (unsigned)i * 16u, csrc[i]);
-    for (int i = lane; i < p2::kXt * 64; i += 64)
-      lds_st4(lds, (unsigned)p2::kXtB + (unsigned)i * 16u, xsrc[i]);
-    constexpr int kB = 4;
-#pragma unroll 1
-    for (int j0 = 0; j0 < NJ; j0 += kB)
-    {
-      f4 v[kB][4];
-#pragma unroll
-      for (int jj = 0; jj < kB; jj++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          v[jj][q] = tsrc[(size_t)(j0 + jj) * 256 + q * 64 + lane];
-#pragma unroll
-      for (int jj = 0; jj < kB; jj++)
-      {
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          lds_st4(lds, (unsigned)p2::kTilesB + (unsigned)(j0 + jj) * 4096u + (unsigned)q * 1024u + (unsigned)lane * 16u, v[jj][q]);
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-        if (lane == 0)
-          __hip_atomic_store(progress, j0 + jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-    const int n_bar = n_blocks * 4; // IL_EXCH jobs per block: dilations 1 and 2 of both arrays
-    for (int i = 0; i < n_bar; i++)
-      lds_barrier();
-    return;
-  }
-
-  // -------------------------------------------------- compute role ------------------------------------
   const int g = lane >> 4;
   const int j = lane & 15;
   const int t = 4 * j + w; // this lane's frame inside the block
@@ -97,9 +55,25 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
   const int ring_len_v = 2 * (1 << (lane % p2::kLayers)) + kBlock;
   int blk = 0;
 
-  // the two ring requests (+ the input sample) of job TJ, which belongs to block blk + AHEAD
-  // (tl / gl16: the lane's frame and channel-quad offset, laundered per job by the caller — see `job`)
-  auto fetch = [&](Slot& s, auto tj_tag, auto ahead_tag, bool valid, int tl, unsigned gl16) {
+  // ---- weights -> LDS, once per launch, by all four waves (no loader wave: with one wave per SIMD each wave may use
+  // the whole 512-entry register file, which is what lets a full block of ring requests stay in flight) ----
+  // requested first, written to LDS after the ring requests below have been issued behind them
+  constexpr int kT4 = NJ * 256 / 256; // 16-byte tile records per thread: 20 jobs x 256 records / 256 threads
+  f4 tl4[kT4];
+  {
+    const f4* __restrict__ tsrc = reinterpret_cast<const f4*>(blob + a.tiles_off);
+#pragma unroll
+    for (int i = 0; i < kT4; i++)
+      tl4[i] = tsrc[i * 256 + tid];
+  }
+  const f4* __restrict__ csrc = reinterpret_cast<const f4*>(blob + a.consts_off);
+  const f4* __restrict__ xsrc = reinterpret_cast<const f4*>(blob + a.xt_off);
+  const f4 c0v = csrc[tid], c1v = csrc[min(tid + 256, NJ * 16 - 1)]; // 320 constant records
+  const f4 x0v = xsrc[min(tid, p2::kXt * 64 - 1)]; // 192 extra-tile records
+
+  // the ring requests of job TJ, which belongs to block blk + AHEAD; (tl / gl16: the lane's frame and channel-quad
+  // offset, laundered per job by the caller — see `job`)
+  auto fetch = [&](f4& sa, f4& sb, auto tj_tag, auto ahead_tag, bool valid, int tl, unsigned gl16) {
     constexpr int JF = (decltype(tj_tag)::value + NJ - p2::kDepth) % NJ; // table position whose entry describes job TJ
     constexpr int AHEAD = decltype(ahead_tag)::value;
     constexpr IlFetch F = p2::fetch(C0, C1, JF);
@@ -115,72 +89,66 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
       constexpr int LA = F.LA, LB = F.LB, nA = F.nA, nB = F.nB;
       const int L = q == 0 ? LA : LB;
       const int n = q == 0 ? nA : nB;
-      f4 r;
-      if (L > 0)
+      if (L > 0) // (compile time: exchange jobs have one request)
       {
         const unsigned v = (unsigned)(wp + tl - L + F.R);
         const unsigned idx = min(v, v - (unsigned)F.R);
         const bool want = valid && tl < 4 * n; // lanes j < n
         const unsigned off = want ? __umul24(idx, (unsigned)F.row_b) + base : kOob;
-        r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+        const f4 r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+        if (q == 0)
+          sa = r;
+        else
+          sb = r;
       }
-      else // (exchange jobs have no second request; keep the five-operation pattern)
-        r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)kOob, 0, 0));
-      if (q == 0)
-        s.a = r;
-      else
-        s.b = r;
     }
-    s.inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((blk + AHEAD) * (kBlock * 4)), 0));
   };
+  // Request slots: ONE PER JOB of a block (a job's slot is refilled for the next block as soon as the job has consumed
+  // it), so a launch of one block has every ring request in flight before its first job starts — one memory round
+  // trip per launch — and a resident launch looks a whole block ahead. 20 appends + 36 requests + input + output
+  // sample = 58 vector-memory operations in flight at most (the counter holds 63).
+  f4 sa[NJ], sb[NJ];
+  float inp;
+  auto prologue = [&](auto u_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    fetch(sa[U], sb[U], std::integral_constant<int, U>{}, std::integral_constant<int, 0>{}, true, t, v_g16);
+  };
+  inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, 0, 0));
+  il::for_each_index(prologue, std::make_integer_sequence<int, NJ>{});
+  // the weights (requested before the ring rows, so they are here first)
+#pragma unroll
+  for (int i = 0; i < kT4; i++)
+    lds_st4(lds, (unsigned)p2::kTilesB + (unsigned)(i * 256 + tid) * 16u, tl4[i]);
+  lds_st4(lds, (unsigned)p2::kConstsB + (unsigned)tid * 16u, c0v);
+  if (tid + 256 < NJ * 16)
+    lds_st4(lds, (unsigned)p2::kConstsB + (unsigned)(tid + 256) * 16u, c1v);
+  if (tid < p2::kXt * 64)
+    lds_st4(lds, (unsigned)p2::kXtB + (unsigned)tid * 16u, x0v);
+  lds_barrier();
+
   auto load_ops = [&](Ops& o, auto j_tag) {
     constexpr int JN = decltype(j_tag)::value; // the job whose operands are read
-    constexpr unsigned consts_b = p2::kConstsB + JN * 256, xt_b = p2::kXtB + p2::xt_index(JN) * 1024,
-                       tiles_b = p2::kTilesB + JN * 4096;
+    constexpr unsigned consts_b = p2::kConstsB + JN * 256, tiles_b = p2::kTilesB + JN * 4096;
 #pragma unroll
     for (int q = 0; q < 4; q++)
       o.t[q] = lds_ld4(lds, v_lane16 + tiles_b + 1024u * q);
     o.bv = lds_ld4(lds, v_g16 + consts_b);
     o.mv = lds_ld4(lds, v_g16 + consts_b + 64u);
     o.b1v = lds_ld4(lds, v_g16 + consts_b + 128u);
-    (void)xt_b; // the extra tile / constants are read by the four jobs that have them, when they start (load_extra)
   };
-  // extra tile + extra constants of job JN (array entry / exit jobs only): 8 VGPRs that need no double buffer
+  // extra tile + extra constants of job JN (array entry / exit jobs only)
   auto load_extra = [&](f4& xt, f4& ev, auto j_tag) {
     constexpr int JN = decltype(j_tag)::value;
     xt = lds_ld4(lds, v_lane16 + (unsigned)(p2::kXtB + p2::xt_index(JN) * 1024));
     ev = lds_ld4(lds, v_g16 + (unsigned)(p2::kConstsB + JN * 256) + 192u);
   };
-  auto wait_loader = [&](int need) {
-    int spins = 0;
-    while (uni(progress_load()) < need)
-    {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 22))
-        __builtin_trap();
-    }
-  };
-
-  Slot slot[D];
-  // prologue: the requests of jobs 0 .. D-1, each in the five-operation pattern of a job
-  auto prologue = [&](auto u_tag) {
-    constexpr int U = decltype(u_tag)::value;
-    __builtin_amdgcn_raw_buffer_store_b128(il::u4{0u, 0u, 0u, 0u}, rsrc, (int)kOob, 0, WT ? 17 : 0);
-    fetch(slot[U], std::integral_constant<int, U>{}, std::integral_constant<int, 0>{}, true, t, v_g16);
-    __builtin_amdgcn_raw_buffer_store_b32(0u, rsrc_out, (int)kOob, 0, 0);
-  };
-  il::for_each_index(prologue, std::make_integer_sequence<int, D>{});
-  lds_barrier();
 
   f4 x = {0.f, 0.f, 0.f, 0.f}, head = {0.f, 0.f, 0.f, 0.f};
   int nvalid = min(kBlock, a.n_frames);
+  float cond = 0.0f;
   // One operand register set: a job reads its own tiles / constants from LDS when it starts and hides the latency
-  // behind its ring append, its requests and its tap shuffles (~40 instructions) — a double buffer filled one job ahead
-  // costs 29 more VGPRs, and with them the compiler spilled request slots. Only the loader's progress word is read one
-  // job ahead (a wait on it would be exposed).
+  // behind its ring append, its requests and its tap shuffles.
   Ops O;
-  wait_loader(1);
-  int ready = progress_load();
 
   // one job, everything about it known at compile time
   auto job = [&](auto j_tag) {
@@ -192,22 +160,25 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
     const int act = a.act; // (only read by the run-time-dispatch instantiation)
     __builtin_amdgcn_sched_barrier(0);
     // The lane's frame and quad offset, opaque to the optimiser from here on: every address below would otherwise be a
-    // block-loop invariant, computed once for all twenty jobs in front of the loop and kept in (then spilled from)
-    // ~40 VGPRs; recomputing costs two or three VALU instructions per use.
+    // block-loop invariant, computed once for all twenty jobs in front of the loop and kept in ~40 VGPRs; recomputing
+    // costs two or three VALU instructions per use.
     int tl = t;
     unsigned gl16 = v_g16;
     asm volatile("" : "+v"(tl), "+v"(gl16));
-    const Slot S = slot[JI % D];
-    asm volatile("" ::"v"(S.a), "v"(S.b), "v"(S.inp)); // one wait for the whole slot (the oldest requests in flight)
-    const float cond = S.inp;
-    if (uni(ready) < JI + 1) // the loader had not published this job yet when the previous job looked
-      wait_loader(JI + 1);
     load_ops(O, j_tag);
     f4 xt = {0.f, 0.f, 0.f, 0.f}, ev = {0.f, 0.f, 0.f, 0.f};
     if constexpr ((flags & (CD_X0 | CD_PRE_HEAD | CD_POST_RECH | CD_POST_OUT)) != 0)
-      load_extra(xt, ev, j_tag); // (behind the progress check above: the loader has published this job)
+      load_extra(xt, ev, j_tag);
+    const f4 Sa = sa[JI], Sb = sb[JI];
+    if constexpr (J.kind == IL_EXCH)
+      asm volatile("" ::"v"(Sa));
+    else
+      asm volatile("" ::"v"(Sa), "v"(Sb)); // one wait for the whole slot (the oldest requests in flight)
     if constexpr ((flags & CD_X0) != 0)
     {
+      cond = inp; // this block's input sample (requested a block ago)
+      // next block's (offset beyond the launch's frames -> 0)
+      inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((blk + 1) * (kBlock * 4)), 0));
       x = ev * cond;
       head = f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -219,24 +190,19 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
       const unsigned off = ok ? __umul24(widx, (unsigned)J.row_b) + gl16 + (unsigned)J.ring_b : kOob;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(il::u4, x), rsrc, (int)off, 0, WT ? 17 : 0);
     }
-    // requests of the job D ahead into the slot just consumed, then the next job's operands
-    {
-      constexpr int TJ = (JI + D) % NJ;
-      constexpr int AHEAD = JI + D >= NJ ? 1 : 0;
-      fetch(slot[JI % D], std::integral_constant<int, TJ>{}, std::integral_constant<int, AHEAD>{}, !AHEAD || blk + 1 < n_blocks, tl, gl16);
-    }
-    ready = progress_load(); // for the next job
+    // the same job of the NEXT block: its requests go into the slot just consumed
+    fetch(sa[JI], sb[JI], j_tag, std::integral_constant<int, 1>{}, blk + 1 < n_blocks, tl, gl16);
     auto slice = [&](const f4& r) { return NK == 4 ? r : (hi_pair ? f4{r[2], r[3], 0.f, 0.f} : f4{r[0], r[1], 0.f, 0.f}); };
     f4 bt0, bt1;
     if constexpr (J.kind == IL_HIST)
     {
-      bt0 = slice(S.a);
-      bt1 = slice(S.b);
+      bt0 = slice(Sa);
+      bt1 = slice(Sb);
     }
     else if constexpr (J.kind == IL_DPP)
     {
       bt0 = bt1 = f4{0.f, 0.f, 0.f, 0.f};
-      il::dpp_taps<NK, J.dil / 4>(x, slice(S.a), slice(S.b), bt0, bt1);
+      il::dpp_taps<NK, J.dil / 4>(x, slice(Sa), slice(Sb), bt0, bt1);
     }
     else
     {
@@ -245,7 +211,7 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
       if (gl16 <= g16max)
       {
         lds_st4(lds, wb + (unsigned)(kBlock + tl) * kIlWinRowB + gl16, x);
-        lds_st4(lds, wb + (unsigned)tl * kIlWinRowB + gl16, S.a);
+        lds_st4(lds, wb + (unsigned)tl * kIlWinRowB + gl16, Sa);
       }
       lds_barrier();
       const unsigned chan = NK == 4 ? min(gl16, g16max) : v_gh8;
@@ -291,16 +257,15 @@ __global__ __launch_bounds__(320) void nam_a1_p2_kernel(const float* __restrict_
       y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[3][s + 1], z[s + 1], y1, 0, 0, 0);
     }
     x = y0 + y1;
-    float yout = 0.0f;
     if constexpr ((flags & CD_POST_OUT) != 0)
-      yout = head_scale * (mfma_n<NK>(xt, head, f4{0.f, 0.f, 0.f, 0.f}) + ev)[0];
-    else if constexpr ((flags & CD_POST_RECH) != 0)
-      x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
     {
-      const bool ok = (flags & CD_POST_OUT) && gl16 == 0 && tl < nvalid;
+      const float yout = head_scale * (mfma_n<NK>(xt, head, f4{0.f, 0.f, 0.f, 0.f}) + ev)[0];
+      const bool ok = gl16 == 0 && tl < nvalid;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob,
                                             uni(blk * (kBlock * 4)), 0);
     }
+    else if constexpr ((flags & CD_POST_RECH) != 0)
+      x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
   };
 
 #pragma unroll 1
@@ -331,7 +296,7 @@ hipError_t launch_p2_inst(const A1Args& a, int n_blocks, hipStream_t stream)
       return e;
     configured = true;
   }
-  hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT>), dim3(n_blocks), dim3(320), p2::kLdsBytes, stream, a.blob, a);
+  hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT>), dim3(n_blocks), dim3(256), p2::kLdsBytes, stream, a.blob, a);
   return hipGetLastError();
 }
 template <int C0, int C1>
