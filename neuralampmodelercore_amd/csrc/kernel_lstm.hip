@@ -435,6 +435,189 @@ __global__ __launch_bounds__(64) void nam_lstm_mfma_reg_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small LSTMs (hidden <= 4: lstm.nam has 3 units), one GATE ROW PER LANE: a stream is a 16-lane DPP row, lane
+// q = 4 u + k of the row computes gate k (i, f, g, o) of hidden unit u — one dot product of length I + H and ONE
+// activation per lane and time step instead of a whole unit's 16 MACs + 5 activations (the 16-streams-per-wavefront
+// MFMA kernel above: ~110 instructions per step on one wave; with a lone wave per SIMD the instruction count IS the
+// time). The four gates of a unit meet through quad_perm DPP moves (c and h are replicated in the quad), the
+// hidden state goes back to all 16 lanes through row_newbcast DPP moves; sigmoid = 0.5 tanh(x / 2) + 0.5 lets every
+// lane run the same activation code with per-lane constants. 4 streams per wavefront, one wavefront per workgroup:
+// 1,024 streams = 256 workgroups = every CU (the MFMA kernel keeps 64 wavefronts busy). I/O tiles go through LDS for
+// coalescing exactly as in the other LSTM kernels; state layout [layer][h | c][H] is shared with them.
+// Reference: NAM/lstm.cpp:31-68 (cell), :103-168 (process), gate order i, f, g, o; fast forms :48-58.
+// ------------------------------------------------------------------------------------------------
+namespace lrow
+{
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) // lane N of the 16-lane row -> every lane of the row
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) // lane K of the quad -> every lane of the quad
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+template <bool FAST>
+__device__ __forceinline__ float tanh_like(float x)
+{
+  return FAST ? mf::fast_tanh_hw(x) : mf::tanh_hw(x);
+}
+} // namespace lrow
+
+template <int NL, int NI, bool FAST>
+__global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restrict__ blob, const LSTMArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int row = lane >> 4, q = lane & 15;
+  const int u = q >> 2, k = q & 3; // hidden unit, gate (i, f, g, o)
+  const int s0 = blockIdx.x * 4;
+  const bool live = s0 + row < a.n_streams;
+  const int stream = live ? (a.stream_map ? a.stream_map[s0 + row] : s0 + row) : 0;
+  const int H = a.hidden;
+  const int in_ch = a.in_ch, out_ch = a.out_ch;
+  float* xin = lds; // [in_ch][4 rows][65]
+  float* yout = xin + in_ch * 4 * 65; // [out_ch][4 rows][65]
+  const bool unit = u < H;
+
+  // this lane's gate row of every layer: bias, input weights, recurrent weights (zero rows for the padding unit)
+  float wb[NL], wi[NL][NL == 1 ? NI : 4], wh[NL][4];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    const int I = l == 0 ? NI : H;
+    const float* __restrict__ W = blob + a.layer_w[l] + (size_t)(k * H + (unit ? u : 0)) * (I + H);
+    wb[l] = unit ? blob[a.layer_b[l] + k * H + u] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < (NL == 1 ? NI : 4); e++)
+      wi[l][e] = (unit && e < I) ? W[e] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      wh[l][j] = (unit && j < H) ? W[I + j] : 0.0f;
+  }
+  // head: lane q of the row computes output channel q
+  float hw[4], hb = q < out_ch ? blob[a.head_b + q] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    hw[j] = (q < out_ch && j < H) ? blob[a.head_w + q * H + j] : 0.0f;
+  // sigmoid(x) = 0.5 tanh(x / 2) + 0.5 for gates i, f, o; tanh for g: act(x) = A T(B x) + C
+  const float cA = k == 2 ? 1.0f : 0.5f, cB = cA, cC = k == 2 ? 0.0f : 0.5f;
+
+  float* st = a.state + (size_t)stream * a.state_stride;
+  float h[NL], c[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    h[l] = (live && unit) ? st[(l * 2 + 0) * H + u] : 0.0f;
+    c[l] = (live && unit) ? st[(l * 2 + 1) * H + u] : 0.0f;
+  }
+  // h of every unit of every layer in every lane of the row (the recurrent operand of the next step)
+  float hbc[NL][4];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    hbc[l][0] = lrow::row_bcast<0>(h[l]);
+    hbc[l][1] = lrow::row_bcast<4>(h[l]);
+    hbc[l][2] = lrow::row_bcast<8>(h[l]);
+    hbc[l][3] = lrow::row_bcast<12>(h[l]);
+  }
+
+  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  {
+    const int nvalid = min(kBlock, a.n_frames - f0);
+    // coalesced input tile: row r = stream of position s0 + r, lane = frame
+    for (int ch = 0; ch < in_ch; ch++)
+      for (int r = 0; r < 4; r++)
+      {
+        const int s = __shfl(stream, r * 16);
+        float v = 0.0f;
+        if (a.in && s0 + r < a.n_streams && lane < nvalid)
+          v = a.in[((size_t)s * in_ch + ch) * a.io_stride + f0 + lane];
+        xin[(ch * 4 + r) * 65 + lane] = v;
+      }
+    // the row's input(s), read two steps ahead so that an LDS round trip is never on the recurrence
+    const int xrow = row * 65;
+    float xa[NI], xb[NI];
+#pragma unroll
+    for (int e = 0; e < NI; e++)
+    {
+      xa[e] = xin[(min(e, in_ch - 1) * 4) * 65 + xrow];
+      xb[e] = xin[(min(e, in_ch - 1) * 4) * 65 + xrow + 1];
+    }
+    const int ybase = (min(q, out_ch - 1) * 4 + row) * 65;
+    for (int t = 0; t < nvalid; t++)
+    {
+      float xn[NI];
+#pragma unroll
+      for (int e = 0; e < NI; e++)
+        xn[e] = xin[(min(e, in_ch - 1) * 4) * 65 + xrow + min(t + 2, kBlock - 1)];
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+      {
+        // gate pre-activation of this lane's row: b + Wi . in + Wh . h(t - 1)
+        float pre = wb[l];
+        if (l == 0)
+        {
+#pragma unroll
+          for (int e = 0; e < NI; e++)
+            pre = fmaf(wi[0][e], xa[e], pre);
+        }
+        else
+        {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            pre = fmaf(wi[l][e], hbc[l - 1][e], pre); // the layer below's h(t), just broadcast
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          pre = fmaf(wh[l][j], hbc[l][j], pre);
+        const float g = fmaf(cA, lrow::tanh_like<FAST>(cB * pre), cC);
+        // the unit's four gates meet in every lane of its quad
+        const float gi = lrow::quad_bcast<0>(g), gf = lrow::quad_bcast<1>(g), gg = lrow::quad_bcast<2>(g),
+                    go = lrow::quad_bcast<3>(g);
+        const float cn = fmaf(gf, c[l], gi * gg);
+        const float hn = go * lrow::tanh_like<FAST>(cn);
+        c[l] = cn;
+        h[l] = hn;
+        hbc[l][0] = lrow::row_bcast<0>(hn);
+        hbc[l][1] = lrow::row_bcast<4>(hn);
+        hbc[l][2] = lrow::row_bcast<8>(hn);
+        hbc[l][3] = lrow::row_bcast<12>(hn);
+      }
+      // head: y = Wh . h_top(t) + bh (lane q = output channel q)
+      float y = hb;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        y = fmaf(hw[j], hbc[NL - 1][j], y);
+      if (q < out_ch)
+        yout[ybase + t] = y;
+#pragma unroll
+      for (int e = 0; e < NI; e++)
+      {
+        xa[e] = xb[e];
+        xb[e] = xn[e];
+      }
+    }
+    if (a.out)
+      for (int ch = 0; ch < out_ch; ch++)
+        for (int r = 0; r < 4; r++)
+        {
+          const int s = __shfl(stream, r * 16);
+          if (s0 + r < a.n_streams && lane < nvalid)
+            a.out[((size_t)s * out_ch + ch) * a.io_stride + f0 + lane] = yout[(ch * 4 + r) * 65 + lane];
+        }
+  }
+  if (live && unit && k == 0)
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      st[(l * 2 + 0) * H + u] = h[l];
+      st[(l * 2 + 1) * H + u] = c[l];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // State initialisation
 // ------------------------------------------------------------------------------------------------
 __global__ void nam_fill_state_kernel(float* state, long state_stride, const int* stream_map, int n_streams,
@@ -510,6 +693,34 @@ hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream)
     return hipGetLastError();
   }
   hipLaunchKernelGGL(nam_lstm_mfma_kernel, dim3(n_blocks), dim3(64), a.mf_lds_bytes, stream, a.blob, a);
+  return hipGetLastError();
+}
+
+bool lstm_row_eligible(const LSTMArgs& a)
+{
+  return a.hidden >= 1 && a.hidden <= 4 && a.n_layers >= 1 && a.n_layers <= 2 && a.input_size >= 1 && a.input_size <= 2
+         && a.in_ch == a.input_size && a.out_ch >= 1 && a.out_ch <= 16;
+}
+
+hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream)
+{
+  if (!lstm_row_eligible(a))
+    return hipErrorInvalidValue;
+  const int n_blocks = (a.n_streams + 3) / 4;
+  const int lds_bytes = (a.in_ch + a.out_ch) * 4 * 65 * (int)sizeof(float);
+#define NAM_LSTM_ROW(NL, NI) \
+  if (a.fast) \
+    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, true>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a); \
+  else \
+    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a)
+  switch (a.n_layers * 10 + a.input_size)
+  {
+    case 11: NAM_LSTM_ROW(1, 1); break;
+    case 12: NAM_LSTM_ROW(1, 2); break;
+    case 21: NAM_LSTM_ROW(2, 1); break;
+    default: NAM_LSTM_ROW(2, 2); break;
+  }
+#undef NAM_LSTM_ROW
   return hipGetLastError();
 }
 

@@ -89,6 +89,8 @@ hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, i
                           hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);
 hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream);
+hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream); // hidden <= 4: one gate row per lane
+bool lstm_row_eligible(const LSTMArgs& a);
 int lstm_lds_bytes(const LSTMArgs& a);
 hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,
                              int n_init, int state_floats, hipStream_t stream);

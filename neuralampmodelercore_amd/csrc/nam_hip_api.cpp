@@ -247,6 +247,9 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
     }
   }
   const LSTMPlan& L = p.lstm;
+  if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && L.hidden >= 1 && L.hidden <= 4
+      && L.n_layers <= 2 && L.input_size >= 1 && L.input_size <= 2 && L.in_ch == L.input_size && L.out_ch <= 16)
+    return "nam_lstm_row_kernel";
   if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
     return (L.input_size <= 4 && L.n_layers <= 2 && L.mf_nt <= 6) ? "nam_lstm_mfma_reg_kernel" : "nam_lstm_mfma_kernel";
   return "nam_lstm_kernel";
@@ -408,8 +411,11 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.mf_layer_tiles[i] = L.mf_layer_tiles[i];
       a.mf_layer_bias[i] = L.mf_layer_bias[i];
     }
-    // AUTO: the matrix-core kernel (16 streams per wavefront); NAM_HIP_KERNEL_GENERIC: lanes = streams
-    if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
+    // AUTO: small cells (hidden <= 4) one gate row per lane, else the matrix-core kernel (16 streams per wavefront);
+    // NAM_HIP_KERNEL_A1_MFMA forces the matrix-core kernel; NAM_HIP_KERNEL_GENERIC: lanes = streams
+    if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && lstm_row_eligible(a))
+      NAM_HIP_CHECK(launch_lstm_row(a, s));
+    else if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
       NAM_HIP_CHECK(launch_lstm_mfma(a, s));
     else
     {
@@ -939,6 +945,18 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
   if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_IL)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
+  bool all_lstm = true;
+  for (const auto& g : batch->groups)
+    all_lstm = all_lstm && g.plan->arch == ARCH_LSTM;
+  if (all_lstm)
+  {
+    // LSTM batches: AUTO (gate-row kernel for small cells, else matrix cores), GENERIC (lanes = streams),
+    // A1_MFMA (force the matrix-core kernel)
+    if (kernel == NAM_HIP_KERNEL_A1 || kernel == NAM_HIP_KERNEL_A1_IL)
+      return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: WaveNet kernels cannot run an LSTM");
+    batch->kernel = kernel;
+    return NAM_HIP_OK;
+  }
   if (kernel >= NAM_HIP_KERNEL_A1)
   {
     // every submodel must have an A1 plan; the MFMA kernels must exist for the full-width submodel (narrower

@@ -24,6 +24,7 @@ MODELS = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable
           "synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed",  # synth_*: make_synthetic_models.py
           "synth_a1_lite", "synth_a1_c14", "synth_a1_feather",  # channel counts that are not multiples of 4 (zero-padded for the MFMA kernel)
           "A2", "slimmable_container",  # SlimmableContainer files: the default (last) submodel
+          "synth_lstm_h4x2",  # a small LSTM cell (gate-row kernel)
           "synth_posthead",  # post-stack head, two output channels (mono input)
           "synth_leakyhardtanh",  # LeakyHardtanh, object / string forms, driven past both knees
           "synth_kt_c8", "synth_kt_c16", "synth_kt_c12", "synth_kt_c4"]  # per-layer kernel sizes, head rechannel with taps

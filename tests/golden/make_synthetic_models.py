@@ -169,6 +169,10 @@ LSTMS = {
     "synth_lstm_io": dict(num_layers=1, input_size=2, hidden=8, out_channels=3, seed=32),
     # two layers of 10 (3 unit tiles): the register-resident kernel's layer-to-layer path
     "synth_lstm_h10x2": dict(num_layers=2, input_size=1, hidden=10, out_channels=1, seed=33),
+    # small cells for the gate-row kernel (hidden <= 4): two layers of 4 (full 16-lane rows, layer-to-layer broadcasts),
+    # and one layer of 2 with 2 inputs / 3 outputs (padding units, one output channel per lane)
+    "synth_lstm_h4x2": dict(num_layers=2, input_size=1, hidden=4, out_channels=1, seed=34),
+    "synth_lstm_h2io": dict(num_layers=1, input_size=2, hidden=2, out_channels=3, seed=35),
 }
 
 

@@ -505,11 +505,13 @@ def test_post_stack_head_and_multichannel_io(nam_lib, oracle, name, in_ch, fast_
     b.close()
 
 
-@pytest.mark.parametrize("name,in_ch", [("lstm", 1), ("synth_lstm_h18x2", 1), ("synth_lstm_io", 2), ("synth_lstm_h10x2", 1)])
-@pytest.mark.parametrize("kernel", ["mfma", "lanes"])
+@pytest.mark.parametrize("name,in_ch", [("lstm", 1), ("synth_lstm_h18x2", 1), ("synth_lstm_io", 2), ("synth_lstm_h10x2", 1),
+                                        ("synth_lstm_h4x2", 1), ("synth_lstm_h2io", 2)])
+@pytest.mark.parametrize("kernel", ["auto", "mfma", "lanes"])
 def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
-    """Both LSTM kernels — matrix-core (16 streams per wavefront; AUTO) and lanes-are-streams (GENERIC) —
-    against the oracle: partial wavefronts, several unit tiles with a ragged last one, two layers, 2-in / 3-out."""
+    """The LSTM kernels — gate row per lane (hidden <= 4: AUTO for lstm.nam and the two small fixtures), matrix-core
+    (16 streams per wavefront: AUTO otherwise, or forced), lanes-are-streams (GENERIC) — against the oracle: partial
+    wavefronts / rows, padding units, several unit tiles with a ragged last one, two layers, 2-in / 3-out."""
     nam = nam_lib
     n_streams, n = 37, 64 * 3 + 11
     rng = np.random.default_rng(71)
@@ -519,9 +521,14 @@ def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
         b = model.batch(n_streams, 64)
         if kernel == "lanes":
             b.set_kernel(nam.KERNEL_GENERIC)
+        elif kernel == "mfma":
+            b.set_kernel(nam.KERNEL_A1_MFMA)
+        small = name in ("lstm", "synth_lstm_h4x2", "synth_lstm_h2io")
+        want = {"lanes": "nam_lstm_kernel", "mfma": "nam_lstm_mfma", "auto": "nam_lstm_row_kernel" if small else "nam_lstm_mfma"}[kernel]
+        assert b.kernel_name().startswith(want), (b.kernel_name(), want)
         b.Reset(prewarm=True)
         y = b.process_stream(x, 64)
-        for s in (0, 1, 15, 16, 31, 32, 36):
+        for s in (0, 1, 2, 3, 4, 15, 16, 31, 32, 35, 36):
             r = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
             r.Reset(48000.0, 64)
             ref = r.process_stream(x[s], 64)
