@@ -465,7 +465,7 @@ __device__ __forceinline__ float tanh_like(float x)
 }
 } // namespace lrow
 
-template <int NL, int NI, bool FAST>
+template <int NL, int NI, int NH, bool FAST>
 __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restrict__ blob, const LSTMArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -475,14 +475,14 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
   const int s0 = blockIdx.x * 4;
   const bool live = s0 + row < a.n_streams;
   const int stream = live ? (a.stream_map ? a.stream_map[s0 + row] : s0 + row) : 0;
-  const int H = a.hidden;
+  constexpr int H = NH; // hidden units (compile time: no broadcast / FMA is spent on padding units)
   const int in_ch = a.in_ch, out_ch = a.out_ch;
   float* xin = lds; // [in_ch][4 rows][65]
   float* yout = xin + in_ch * 4 * 65; // [out_ch][4 rows][65]
   const bool unit = u < H;
 
   // this lane's gate row of every layer: bias, input weights, recurrent weights (zero rows for the padding unit)
-  float wb[NL], wi[NL][NL == 1 ? NI : 4], wh[NL][4];
+  float wb[NL], wi[NL][NL == 1 ? NI : NH], wh[NL][NH];
 #pragma unroll
   for (int l = 0; l < NL; l++)
   {
@@ -490,17 +490,17 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
     const float* __restrict__ W = blob + a.layer_w[l] + (size_t)(k * H + (unit ? u : 0)) * (I + H);
     wb[l] = unit ? blob[a.layer_b[l] + k * H + u] : 0.0f;
 #pragma unroll
-    for (int e = 0; e < (NL == 1 ? NI : 4); e++)
+    for (int e = 0; e < (NL == 1 ? NI : NH); e++)
       wi[l][e] = (unit && e < I) ? W[e] : 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      wh[l][j] = (unit && j < H) ? W[I + j] : 0.0f;
+    for (int j = 0; j < NH; j++)
+      wh[l][j] = unit ? W[I + j] : 0.0f;
   }
   // head: lane q of the row computes output channel q
-  float hw[4], hb = q < out_ch ? blob[a.head_b + q] : 0.0f;
+  float hw[NH], hb = q < out_ch ? blob[a.head_b + q] : 0.0f;
 #pragma unroll
-  for (int j = 0; j < 4; j++)
-    hw[j] = (q < out_ch && j < H) ? blob[a.head_w + q * H + j] : 0.0f;
+  for (int j = 0; j < NH; j++)
+    hw[j] = q < out_ch ? blob[a.head_w + q * H + j] : 0.0f;
   // sigmoid(x) = 0.5 tanh(x / 2) + 0.5 for gates i, f, o; tanh for g: act(x) = A T(B x) + C
   const float cA = k == 2 ? 1.0f : 0.5f, cB = cA, cC = k == 2 ? 0.0f : 0.5f;
 
@@ -513,15 +513,19 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
     c[l] = (live && unit) ? st[(l * 2 + 1) * H + u] : 0.0f;
   }
   // h of every unit of every layer in every lane of the row (the recurrent operand of the next step)
-  float hbc[NL][4];
+  float hbc[NL][NH];
+  auto bcast_units = [&](float (&dst)[NH], float v) {
+    dst[0] = lrow::row_bcast<0>(v);
+    if constexpr (NH > 1)
+      dst[1] = lrow::row_bcast<4>(v);
+    if constexpr (NH > 2)
+      dst[2] = lrow::row_bcast<8>(v);
+    if constexpr (NH > 3)
+      dst[3] = lrow::row_bcast<12>(v);
+  };
 #pragma unroll
   for (int l = 0; l < NL; l++)
-  {
-    hbc[l][0] = lrow::row_bcast<0>(h[l]);
-    hbc[l][1] = lrow::row_bcast<4>(h[l]);
-    hbc[l][2] = lrow::row_bcast<8>(h[l]);
-    hbc[l][3] = lrow::row_bcast<12>(h[l]);
-  }
+    bcast_units(hbc[l], h[l]);
 
   for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
   {
@@ -566,11 +570,11 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
         else
         {
 #pragma unroll
-          for (int e = 0; e < 4; e++)
-            pre = fmaf(wi[l][e], hbc[l - 1][e], pre); // the layer below's h(t), just broadcast
+          for (int e = 0; e < NH; e++)
+            pre = fmaf(wi[l][e], hbc[l > 0 ? l - 1 : 0][e], pre); // the layer below's h(t), just broadcast
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NH; j++)
           pre = fmaf(wh[l][j], hbc[l][j], pre);
         const float g = fmaf(cA, lrow::tanh_like<FAST>(cB * pre), cC);
         // the unit's four gates meet in every lane of its quad
@@ -580,15 +584,12 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
         const float hn = go * lrow::tanh_like<FAST>(cn);
         c[l] = cn;
         h[l] = hn;
-        hbc[l][0] = lrow::row_bcast<0>(hn);
-        hbc[l][1] = lrow::row_bcast<4>(hn);
-        hbc[l][2] = lrow::row_bcast<8>(hn);
-        hbc[l][3] = lrow::row_bcast<12>(hn);
+        bcast_units(hbc[l], hn);
       }
       // head: y = Wh . h_top(t) + bh (lane q = output channel q)
       float y = hb;
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int j = 0; j < NH; j++)
         y = fmaf(hw[j], hbc[NL - 1][j], y);
       if (q < out_ch)
         yout[ybase + t] = y;
@@ -708,11 +709,19 @@ hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream)
     return hipErrorInvalidValue;
   const int n_blocks = (a.n_streams + 3) / 4;
   const int lds_bytes = (a.in_ch + a.out_ch) * 4 * 65 * (int)sizeof(float);
-#define NAM_LSTM_ROW(NL, NI) \
+#define NAM_LSTM_ROW_H(NL, NI, NH) \
   if (a.fast) \
-    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, true>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a); \
+    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, NH, true>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a); \
   else \
-    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a)
+    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, NH, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a)
+#define NAM_LSTM_ROW(NL, NI) \
+  switch (a.hidden) \
+  { \
+    case 1: NAM_LSTM_ROW_H(NL, NI, 1); break; \
+    case 2: NAM_LSTM_ROW_H(NL, NI, 2); break; \
+    case 3: NAM_LSTM_ROW_H(NL, NI, 3); break; \
+    default: NAM_LSTM_ROW_H(NL, NI, 4); break; \
+  }
   switch (a.n_layers * 10 + a.input_size)
   {
     case 11: NAM_LSTM_ROW(1, 1); break;
@@ -721,6 +730,7 @@ hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream)
     default: NAM_LSTM_ROW(2, 2); break;
   }
 #undef NAM_LSTM_ROW
+#undef NAM_LSTM_ROW_H
   return hipGetLastError();
 }
 
