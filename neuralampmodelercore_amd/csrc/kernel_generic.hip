@@ -30,8 +30,14 @@ namespace namhip
 // ------------------------------------------------------------------------------------------------
 
 // One OP_CONV: dst[co][t] = (bias[co]) + sum_k sum_ci W[k][ci][co] * tap_k[ci][t]
-// tap_k[ci][t] = src frame (t - L), L = (K-1-k)*dil: from the LDS block when t-L >= 0, else from the
-// stream's history ring in HBM (frames of earlier blocks). Afterwards the block is appended to the ring.
+// tap_k[ci][t] = src frame (t - L), L = (K-1-k)*dil: from the LDS block when t-L >= 0, else from the stream's
+// history — staged in LDS by OP_STAGE (small lookbacks) or read from the ring in HBM. Afterwards the block is appended
+// to the ring. Weight rows are padded to a multiple of four input channels (plan.cpp).
+//
+// Latency structure (what the time of this kernel is made of: one wavefront per SIMD, nothing else to switch to):
+// input channels are consumed FOUR AT A TIME — the four activation reads and the 4 x CB weight reads of a chunk are
+// all issued before the first FMA, so a chunk costs one LDS round trip; a loop over single channels paid one per
+// channel (and one HBM round trip per tap and channel for history).
 template <int CB, bool WLDS>
 __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float* __restrict__ blob, const float* wlds,
                                         float* st, int* wpos_tbl, const int lane, const int nvalid)
@@ -39,8 +45,13 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
   const float* src = lds + op.src;
   float* dst = lds + op.dst;
   const int cin = op.cin, cout = op.cout, cpad = op.cout_pad, K = op.k;
+  const int cin_pad = (cin + 3) & ~3;
   const bool has_ring = op.state >= 0;
+  const bool staged = has_ring && (op.flag & 4);
+  const int film = has_ring ? 0 : op.flag; // (a conv with taps never carries a FiLM epilogue)
   const int R = op.ring;
+  const int lookback = (K - 1) * op.dil;
+  const float* hist = lds + op.aux; // staged: [lookback][cin]
   int wp = 0;
   float* ring = nullptr;
   if (has_ring)
@@ -51,87 +62,106 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
   for (int co0 = 0; co0 < cpad; co0 += CB)
   {
     float acc[CB];
+    if (op.b >= 0)
+    {
 #pragma unroll
-    for (int j = 0; j < CB; j++)
-      acc[j] = 0.0f;
+      for (int j = 0; j < CB; j++)
+        acc[j] = WLDS ? wlds[op.b + co0 + j] : blob[op.b + co0 + j];
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < CB; j++)
+        acc[j] = 0.0f;
+    }
     for (int k = 0; k < K; k++)
     {
       const int L = (K - 1 - k) * op.dil;
-      const float* __restrict__ wk = blob + op.w + (size_t)k * cin * cpad + co0;
-      const float* wkl = wlds + op.w + (size_t)k * cin * cpad + co0; // the same weights in LDS (WLDS)
-      // acc[j] += W[k][ci][co0 + j] * x: weights as SGPR operands (scalar loads) or, with WLDS, as broadcast
-      // 16-byte LDS reads
-      auto fma_row = [&](int ci, float x) {
-        if constexpr (WLDS)
+      const int tl = lane - L;
+      const bool in_block = tl >= 0;
+      const int lidx = in_block ? tl : 0;
+      int ridx = wp + tl; // ring row of frame t - L (only used by lanes before the block)
+      if (ridx < 0)
+        ridx += R;
+      if (in_block)
+        ridx = 0; // keep the masked-off address in range
+      const int hrow = in_block ? 0 : (lookback + tl) * cin; // staged history row of frame t - L
+      const int wk = op.w + k * cin_pad * cpad + co0;
+      for (int ci0 = 0; ci0 < cin; ci0 += 4)
+      {
+        float x[4];
+        if (L == 0)
         {
-          float wv[CB];
 #pragma unroll
-          for (int j = 0; j < CB; j += 4)
+          for (int u = 0; u < 4; u++)
+            x[u] = src[min(ci0 + u, cin - 1) * kBlock + lane];
+        }
+        else if (staged)
+        {
+#pragma unroll
+          for (int u = 0; u < 4; u++)
           {
-            const mf_f4 q = *reinterpret_cast<const mf_f4*>(wkl + (size_t)ci * cpad + j);
-            wv[j] = q[0], wv[j + 1] = q[1], wv[j + 2] = q[2], wv[j + 3] = q[3];
+            const int ci = min(ci0 + u, cin - 1);
+            const float xl = src[ci * kBlock + lidx];
+            const float xh = hist[hrow + ci];
+            x[u] = in_block ? xl : xh;
           }
-#pragma unroll
-          for (int j = 0; j < CB; j++)
-            acc[j] = fmaf(wv[j], x, acc[j]);
         }
         else
         {
 #pragma unroll
-          for (int j = 0; j < CB; j++)
-            acc[j] = fmaf(wk[(size_t)ci * cpad + j], x, acc[j]);
+          for (int u = 0; u < 4; u++)
+          {
+            const int ci = min(ci0 + u, cin - 1);
+            const float xl = src[ci * kBlock + lidx];
+            const float xr = ring[(size_t)ridx * cin + ci];
+            x[u] = in_block ? xl : xr;
+          }
         }
-      };
-      if (L == 0)
-      {
-        for (int ci = 0; ci < cin; ci++)
-          fma_row(ci, src[ci * kBlock + lane]);
-      }
-      else if (L >= kBlock)
-      {
-        int idx = wp + lane - L;
-        if (idx < 0)
-          idx += R;
-        for (int ci = 0; ci < cin; ci++)
-          fma_row(ci, ring[(size_t)idx * cin + ci]);
-      }
-      else
-      {
-        const int tl = lane - L;
-        const bool in_block = tl >= 0;
-        int idx = wp + tl;
-        if (idx < 0)
-          idx += R;
-        if (in_block)
-          idx = 0; // keep the masked-off address in range
-        const int lidx = in_block ? tl : 0;
-        for (int ci = 0; ci < cin; ci++)
-        {
-          const float xl = src[ci * kBlock + lidx];
-          const float xr = ring[(size_t)idx * cin + ci];
-          fma_row(ci, in_block ? xl : xr);
-        }
-      }
-    }
-    if (op.b >= 0)
-    {
-      const float* __restrict__ bias = blob + op.b + co0;
+        // weights of the four channels (rows beyond cin are zero, so the clamped duplicates above add nothing)
+        float wv[4][CB];
 #pragma unroll
-      for (int j = 0; j < CB; j++)
-        acc[j] += WLDS ? wlds[op.b + co0 + j] : bias[j];
+        for (int u = 0; u < 4; u++)
+        {
+          if constexpr (WLDS)
+          {
+#pragma unroll
+            for (int j = 0; j < CB; j += 4)
+            {
+              const mf_f4 q = *reinterpret_cast<const mf_f4*>(wlds + wk + (ci0 + u) * cpad + j);
+              wv[u][j] = q[0], wv[u][j + 1] = q[1], wv[u][j + 2] = q[2], wv[u][j + 3] = q[3];
+            }
+          }
+          else
+          {
+#pragma unroll
+            for (int j = 0; j < CB; j++)
+              wv[u][j] = blob[wk + (ci0 + u) * cpad + j];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int j = 0; j < CB; j++)
+            acc[j] = fmaf(wv[u][j], x[u], acc[j]);
+      }
     }
-    if (op.flag)
+    if (film)
     {
       // FiLM epilogue (film.h:76-204): the block holds the scales of `per` channels, then (flag 2) their shifts
-      const int per = op.flag == 2 ? CB / 2 : CB;
+      const int per = film == 2 ? CB / 2 : CB;
       const int c0 = co0 / CB * per;
       const float* xs = lds + op.aux;
+      float tv[CB];
+#pragma unroll
+      for (int j = 0; j < CB; j++)
+        tv[j] = xs[min(c0 + (j % per), cout - 1) * kBlock + lane];
 #pragma unroll
       for (int j = 0; j < CB; j++)
         if (j < per && c0 + j < cout)
         {
-          float y = xs[(c0 + j) * kBlock + lane] * acc[j];
-          if (op.flag == 2)
+          float y = tv[j] * acc[j];
+          if (film == 2)
             y += acc[(j + CB / 2) % CB];
           dst[(c0 + j) * kBlock + lane] = y;
         }
@@ -150,13 +180,52 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
     if (widx >= R)
       widx -= R;
     if (lane < nvalid)
-      for (int ci = 0; ci < cin; ci++)
-        ring[(size_t)widx * cin + ci] = src[ci * kBlock + lane];
+      for (int ci0 = 0; ci0 < cin; ci0 += 4)
+      {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          v[u] = src[min(ci0 + u, cin - 1) * kBlock + lane];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (ci0 + u < cin)
+            ring[(size_t)widx * cin + ci0 + u] = v[u];
+      }
     int nwp = wp + nvalid;
     if (nwp >= R)
       nwp -= R;
     if (lane == 0)
       wpos_tbl[op.ring_id] = nwp;
+  }
+}
+
+// Elementwise ops over `n` channel rows, four rows per round trip: f(c, v[]) gets the clamped row values of every
+// operand; results are stored for rows < n.
+template <int NSRC, class F>
+__device__ __forceinline__ void rows4(float* lds, int dst, const int (&srcs)[NSRC], int n, int lane, F&& f)
+{
+  for (int c0 = 0; c0 < n; c0 += 4)
+  {
+    float v[NSRC][4];
+#pragma unroll
+    for (int s = 0; s < NSRC; s++)
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        v[s][u] = lds[srcs[s] + min(c0 + u, n - 1) * kBlock + lane];
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+      float a[NSRC];
+#pragma unroll
+      for (int s = 0; s < NSRC; s++)
+        a[s] = v[s][u];
+      r[u] = f(min(c0 + u, n - 1), a);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (c0 + u < n)
+        lds[dst + (c0 + u) * kBlock + lane] = r[u];
   }
 }
 
@@ -201,6 +270,40 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
           for (int c = 0; c < op.cout; c++)
             lds[op.dst + c * kBlock + lane] = (in && lane < nvalid) ? in[(size_t)c * a.io_stride + f0 + lane] : 0.0f;
           break;
+        case OP_STAGE:
+        {
+          // a run of op.cout staging ops (this one first): request every ring's last `lookback` frames, then write
+          // them to LDS — one memory round trip for all of them. Frame-major in both places: element e of the
+          // history is float ((wp - lookback) * cin + e) mod (R * cin) of the ring.
+          constexpr int kMax = 16; // plan.cpp: Builder::kMaxStages
+          const int n = op.cout;
+          float v[kMax];
+#pragma unroll
+          for (int i = 0; i < kMax; i++)
+            if (i < n)
+            {
+              const NamOp so = ops[pc + i];
+              const int wp = uni(wpos_tbl[so.ring_id]);
+              const int span = so.ring * so.cin;
+              int e = (wp - so.k) * so.cin + lane;
+              if (e < 0)
+                e += span;
+              if (e >= span)
+                e -= span;
+              v[i] = lane < so.cin * so.k ? st[so.state + e] : 0.0f;
+            }
+#pragma unroll
+          for (int i = 0; i < kMax; i++)
+            if (i < n)
+            {
+              const NamOp so = ops[pc + i];
+              if (lane < so.cin * so.k)
+                lds[so.dst + lane] = v[i];
+            }
+          pc += n - 1;
+          next_op = ops[pc + 1];
+          break;
+        }
         case OP_STORE_OUT:
           if (out && lane < nvalid)
             for (int c = 0; c < op.cin; c++)
@@ -213,25 +316,21 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
             op_conv<4, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
           break;
         case OP_FILM:
-          for (int c = 0; c < op.cout; c++)
-          {
-            const float x = lds[op.src + c * kBlock + lane];
-            const float sc = lds[op.aux + c * kBlock + lane];
-            float y = x * sc;
-            if (op.flag)
-              y += lds[op.aux + (op.cout + c) * kBlock + lane];
-            lds[op.dst + c * kBlock + lane] = y;
-          }
+        {
+          const int srcs[3] = {op.src, op.aux, op.aux + (op.flag ? op.cout * kBlock : 0)};
+          const bool shift = op.flag != 0;
+          rows4<3>(lds, op.dst, srcs, op.cout, lane, [&](int, const float(&v)[3]) { return shift ? fmaf(v[0], v[1], v[2]) : v[0] * v[1]; });
           break;
+        }
         case OP_ACT:
         {
           const float p0 = blob[op.w], p1 = blob[op.w + 1], p2 = blob[op.w + 2], p3 = blob[op.w + 3];
           const int ns = op.ring;
+          const int srcs[1] = {op.dst};
           // one dispatch per op, not per channel row (the compare cascade of d_act_rt is ~25 scalar instructions)
           auto rows = [&](auto type_tag) {
             constexpr int T = decltype(type_tag)::value;
-            for (int c = 0; c < op.cout; c++)
-            {
+            rows4<1>(lds, op.dst, srcs, op.cout, lane, [&](int c, const float(&v)[1]) {
               float slope = 0.0f;
               if constexpr (T == ACT_PRELU)
               {
@@ -239,9 +338,8 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
                 const long pos = (long)(f0 + lane) * op.cout + c;
                 slope = blob[op.w + 4 + (int)(pos % ns)];
               }
-              const float x = lds[op.dst + c * kBlock + lane];
-              lds[op.dst + c * kBlock + lane] = d_act<T>(x, p0, p1, p2, p3, slope);
-            }
+              return d_act<T>(v[0], p0, p1, p2, p3, slope);
+            });
           };
 #define NAM_ACT_ROWS(T) \
   case T: rows(std::integral_constant<int, T>{}); break;
@@ -260,8 +358,7 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
             NAM_ACT_ROWS(ACT_SOFTSIGN)
             NAM_ACT_ROWS(ACT_FASTSIGMOID)
             case ACT_LUT: // FastLUTActivation: table behind the four parameters (device_common.h: d_lut)
-              for (int c = 0; c < op.cout; c++)
-                lds[op.dst + c * kBlock + lane] = d_lut(blob + op.w, lds[op.dst + c * kBlock + lane]);
+              rows4<1>(lds, op.dst, srcs, op.cout, lane, [&](int, const float(&v)[1]) { return d_lut(blob + op.w, v[0]); });
               break;
             case ACT_IDENTITY: break;
             default: __builtin_trap(); break;
@@ -275,40 +372,45 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
           const int B = op.cout;
           const float a0 = blob[op.w], a1 = blob[op.w + 1], a2 = blob[op.w + 2], a3 = blob[op.w + 3];
           const float g0 = blob[op.b], g1 = blob[op.b + 1], g2 = blob[op.b + 2], g3 = blob[op.b + 3];
-          for (int c = 0; c < B; c++)
-          {
-            const float pre = lds[op.dst + c * kBlock + lane];
-            const float gin = lds[op.dst + (c + B) * kBlock + lane];
+          const int srcs[2] = {op.dst, op.dst + B * kBlock};
+          rows4<2>(lds, op.dst, srcs, B, lane, [&](int c, const float(&v)[2]) {
+            const float pre = v[0], gin = v[1];
             const float s1 = (op.k == ACT_PRELU) ? blob[op.w + 4 + c % op.ring] : 0.0f;
             const float s2 = (op.dil == ACT_PRELU) ? blob[op.b + 4 + c % op.ring_id] : 0.0f;
             const float av = op.k == ACT_LUT ? d_lut(blob + op.w, pre) : d_act_rt(op.k, pre, a0, a1, a2, a3, s1);
             const float gv = op.dil == ACT_LUT ? d_lut(blob + op.b, gin) : d_act_rt(op.dil, gin, g0, g1, g2, g3, s2);
-            lds[op.dst + c * kBlock + lane] = (op.flag == GATING_GATED) ? av * gv : gv * av + (1.0f - gv) * pre;
-          }
+            return (op.flag == GATING_GATED) ? av * gv : gv * av + (1.0f - gv) * pre;
+          });
           break;
         }
         case OP_ADD:
-          for (int c = 0; c < op.cout; c++)
-            lds[op.dst + c * kBlock + lane] = lds[op.src + c * kBlock + lane] + lds[op.aux + c * kBlock + lane];
+        {
+          const int srcs[2] = {op.src, op.aux};
+          rows4<2>(lds, op.dst, srcs, op.cout, lane, [&](int, const float(&v)[2]) { return v[0] + v[1]; });
           break;
+        }
         case OP_COPY:
-          for (int c = 0; c < op.cout; c++)
-            lds[op.dst + c * kBlock + lane] = lds[op.src + c * kBlock + lane];
+        {
+          const int srcs[1] = {op.src};
+          rows4<1>(lds, op.dst, srcs, op.cout, lane, [&](int, const float(&v)[1]) { return v[0]; });
           break;
+        }
         case OP_ZERO:
           for (int c = 0; c < op.cout; c++)
             lds[op.dst + c * kBlock + lane] = 0.0f;
           break;
         case OP_SCALE:
         {
-          const float s = blob[op.w];
-          for (int c = 0; c < op.cout; c++)
-            lds[op.dst + c * kBlock + lane] = s * lds[op.src + c * kBlock + lane];
+          const float sc = blob[op.w];
+          const int srcs[1] = {op.src};
+          rows4<1>(lds, op.dst, srcs, op.cout, lane, [&](int, const float(&v)[1]) { return sc * v[0]; });
           break;
         }
         default: break;
       }
-      __syncthreads();
+      // One wavefront per workgroup: LDS operations of a wavefront execute in order, so the next op sees this op's rows
+      // without a barrier or a wait; the optimiser only has to keep the accesses in program order.
+      asm volatile("" ::: "memory");
     }
   }
 }

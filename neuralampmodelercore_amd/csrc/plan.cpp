@@ -70,13 +70,14 @@ struct Builder
   {
     const int cb = (cout >= 8) ? 8 : 4;
     const int cout_pad = (cout + cb - 1) / cb * cb;
-    const int woff = blob_reserve((size_t)K * cin * cout_pad);
+    const int cin_pad = (cin + 3) / 4 * 4; // zero rows: the kernel reads input channels four at a time
+    const int woff = blob_reserve((size_t)K * cin_pad * cout_pad);
     const int opg = cout / groups, ipg = cin / groups;
     for (int g = 0; g < groups; g++)
       for (int i = 0; i < opg; i++)
         for (int j = 0; j < ipg; j++)
           for (int k = 0; k < K; k++)
-            plan.blob[(size_t)woff + ((size_t)k * cin + (g * ipg + j)) * cout_pad + (g * opg + i)] = *(w++);
+            plan.blob[(size_t)woff + ((size_t)k * cin_pad + (g * ipg + j)) * cout_pad + (g * opg + i)] = *(w++);
     int boff = -1;
     if (bias)
     {
@@ -102,7 +103,55 @@ struct Builder
       op.state = state_floats;
       op.ring_id = plan.n_rings++;
       state_floats += cin * op.ring;
+      // small histories are copied to LDS once per block (OP_STAGE) instead of being read tap by tap from HBM
+      if (cin * lookback <= kBlock && (int)stages.size() < kMaxStages)
+      {
+        plan.ops.back().flag = 4;
+        plan.ops.back().aux = hist_floats; // relative to the history area; fixed up by finish_stages()
+        StageRec r;
+        r.conv_op = (int)plan.ops.size() - 1;
+        r.hist = hist_floats;
+        stages.push_back(r);
+        hist_floats += (cin * lookback + 3) / 4 * 4;
+      }
     }
+  }
+
+  // ---- history staging (OP_STAGE) ----
+  static constexpr int kMaxStages = 16;
+  struct StageRec
+  {
+    int conv_op, hist;
+  };
+  std::vector<StageRec> stages;
+  int hist_floats = 0;
+  // Called once the whole program is emitted: places the history area behind the activation rows, points the staged
+  // convs at it and inserts the run of OP_STAGE ops behind OP_LOAD_IN (position `at`).
+  void finish_stages(size_t at)
+  {
+    if (stages.empty())
+      return;
+    const int base = rows.high * kBlock;
+    std::vector<NamOp> run;
+    for (const StageRec& r : stages)
+    {
+      NamOp& c = plan.ops[(size_t)r.conv_op];
+      c.aux = base + r.hist;
+      NamOp s;
+      std::memset(&s, 0, sizeof(s));
+      s.type = OP_STAGE;
+      s.w = s.b = -1;
+      s.dst = base + r.hist;
+      s.cin = c.cin;
+      s.k = (c.k - 1) * c.dil; // lookback in frames
+      s.state = c.state;
+      s.ring = c.ring;
+      s.ring_id = c.ring_id;
+      run.push_back(s);
+    }
+    run[0].cout = (int)run.size();
+    plan.ops.insert(plan.ops.begin() + (long)at, run.begin(), run.end());
+    rows.high += (hist_floats + kBlock - 1) / kBlock;
   }
 
   // FiLM (film.h:76-204): scale/shift = Conv1x1(cond) + bias; dst = src * scale (+ shift)
@@ -120,7 +169,7 @@ struct Builder
       const int c = o < dim ? o : o - dim;
       return (c / per) * cb + (o < dim ? 0 : per) + c % per;
     };
-    const int woff = blob_reserve((size_t)cond_dim * cout_pad);
+    const int woff = blob_reserve((size_t)((cond_dim + 3) / 4 * 4) * cout_pad); // input rows padded to a multiple of 4
     const int opg = cout / f.groups, ipg = cond_dim / f.groups;
     for (int g = 0; g < f.groups; g++)
       for (int i = 0; i < opg; i++)
@@ -1211,6 +1260,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
     op.src = out_rows;
     op.cin = plan.out_channels;
   }
+  b.finish_stages(1); // history staging ops right behind OP_LOAD_IN
   b.push(OP_END);
   b.push(OP_END); // the interpreter reads one descriptor ahead
   plan.lds_rows = b.rows.high;

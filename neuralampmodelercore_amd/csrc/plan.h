@@ -39,7 +39,10 @@ enum OpType : int32_t
   OP_ADD = 7, // dst = src + aux
   OP_COPY = 8, // dst = src
   OP_ZERO = 9, // dst = 0
-  OP_SCALE = 10 // dst = blob[w] * src
+  OP_SCALE = 10, // dst = blob[w] * src
+  OP_STAGE = 11 // block start: the last `k` frames (= lookback) of ring `state` -> LDS floats [dst, dst + cin * k), frame-major;
+                // emitted as a run (cout of the first = length of the run) so that every ring's rows are requested before
+                // the first one is waited for: one memory round trip per block instead of one per tap and channel
 };
 
 struct NamOp // 16 x int32 = 64 bytes, fetched with one scalar load
@@ -59,7 +62,8 @@ struct NamOp // 16 x int32 = 64 bytes, fetched with one scalar load
   int32_t state; // conv: float offset of this conv's ring inside the per-stream state, -1 = no ring
   int32_t ring; // conv: ring length R (frames); act/gate: number of PReLU slopes (primary)
   int32_t ring_id; // conv: index into the per-stream write-position table; gate: #slopes (secondary)
-  int32_t flag; // FILM: 1 = shift present; GATE: 1 = gated, 2 = blended
+  int32_t flag; // conv with FiLM epilogue: 1 = scale, 2 = scale + shift; GATE: 1 = gated, 2 = blended;
+                // conv with a ring: 4 = history staged in LDS by OP_STAGE at float offset `aux` (frame-major [lookback][cin])
 };
 static_assert(sizeof(NamOp) == 64, "NamOp must stay 64 bytes");
 
