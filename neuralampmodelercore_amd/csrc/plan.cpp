@@ -1270,7 +1270,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
   // per-stream state: [write positions: n_rings ints, padded to 64 words][rings...]
   const int table = (plan.n_rings + kBlock - 1) / kBlock * kBlock;
   for (auto& op : plan.ops)
-    if (op.type == OP_CONV && op.state >= 0)
+    if ((op.type == OP_CONV || op.type == OP_STAGE) && op.state >= 0)
       op.state += table;
   plan.state_floats = (table + b.state_floats + kBlock - 1) / kBlock * kBlock;
   if (plan.state_floats == 0)
