@@ -29,21 +29,65 @@ namespace namhip
 // Generic interpreter
 // ------------------------------------------------------------------------------------------------
 
+// ------------------------------------------------------------------------------------------------
+// Where the time of this kernel goes: ONE wavefront per SIMD and nothing to switch to, so every instruction costs
+// its issue slot and every dependent memory round trip is exposed. The first interpreter (round 1) spent 16 k scalar
+// and 9 k vector instructions per 64-frame block of wavenet_a2_max for 2.3 k FMAs, with one LDS round trip per input
+// channel and one HBM round trip per history tap and channel. This one is built around three rules:
+//   * every tensor owns a multiple of FOUR rows and every weight matrix is zero-padded to match (plan.cpp), so rows
+//     are read, combined and written four at a time with compile-time trip counts — no per-row tests or clamps;
+//   * an op's operands are all requested before the first one is used: a conv block costs one LDS round trip per
+//     8 input channels (CI4 = 1 or 2 four-row chunks, CB = 4 .. 16 accumulators: template instances picked by a
+//     switch), an elementwise op one per four rows;
+//   * history is staged into LDS once per block by OP_STAGE (one HBM round trip for all rings).
+// LDS is zero-filled at launch so that padding rows only ever hold finite values.
+// ------------------------------------------------------------------------------------------------
+
+// acc[0 .. CB) += W[rows ci0 .. ci0 + 4 CI4)[CB] . x, x = the four-row chunks at `xrow` (LDS float offsets, lane
+// included), weights at float offset `wk` (row pitch cpad) in the LDS / global copy
+template <int CI4, int CB, bool WLDS, class XF>
+__device__ __forceinline__ void conv_chunk(float (&acc)[CB], const float* __restrict__ blob, const float* wlds, int wk,
+                                           int cpad, XF&& xf)
+{
+  float x[4 * CI4];
+#pragma unroll
+  for (int u = 0; u < 4 * CI4; u++)
+    x[u] = xf(u);
+  float wv[4 * CI4][CB];
+#pragma unroll
+  for (int u = 0; u < 4 * CI4; u++)
+  {
+    if constexpr (WLDS)
+    {
+#pragma unroll
+      for (int j = 0; j < CB; j += 4)
+      {
+        const mf_f4 q = *reinterpret_cast<const mf_f4*>(wlds + wk + u * cpad + j);
+        wv[u][j] = q[0], wv[u][j + 1] = q[1], wv[u][j + 2] = q[2], wv[u][j + 3] = q[3];
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < CB; j++)
+        wv[u][j] = blob[wk + u * cpad + j];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4 * CI4; u++)
+#pragma unroll
+    for (int j = 0; j < CB; j++)
+      acc[j] = fmaf(wv[u][j], x[u], acc[j]);
+}
+
 // One OP_CONV: dst[co][t] = (bias[co]) + sum_k sum_ci W[k][ci][co] * tap_k[ci][t]
 // tap_k[ci][t] = src frame (t - L), L = (K-1-k)*dil: from the LDS block when t-L >= 0, else from the stream's
 // history — staged in LDS by OP_STAGE (small lookbacks) or read from the ring in HBM. Afterwards the block is appended
-// to the ring. Weight rows are padded to a multiple of four input channels (plan.cpp).
-//
-// Latency structure (what the time of this kernel is made of: one wavefront per SIMD, nothing else to switch to):
-// input channels are consumed FOUR AT A TIME — the four activation reads and the 4 x CB weight reads of a chunk are
-// all issued before the first FMA, so a chunk costs one LDS round trip; a loop over single channels paid one per
-// channel (and one HBM round trip per tap and channel for history).
+// to the ring. CB = op.cb accumulators per output block (the whole conv when cout <= 16).
 template <int CB, bool WLDS>
 __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float* __restrict__ blob, const float* wlds,
                                         float* st, int* wpos_tbl, const int lane, const int nvalid)
 {
-  const float* src = lds + op.src;
-  float* dst = lds + op.dst;
   const int cin = op.cin, cout = op.cout, cpad = op.cout_pad, K = op.k;
   const int cin_pad = (cin + 3) & ~3;
   const bool has_ring = op.state >= 0;
@@ -51,6 +95,7 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
   const int film = has_ring ? 0 : op.flag; // (a conv with taps never carries a FiLM epilogue)
   const int R = op.ring;
   const int lookback = (K - 1) * op.dil;
+  const float* src = lds + op.src + lane;
   const float* hist = lds + op.aux; // staged: [lookback][cin]
   int wp = 0;
   float* ring = nullptr;
@@ -77,101 +122,94 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
     for (int k = 0; k < K; k++)
     {
       const int L = (K - 1 - k) * op.dil;
-      const int tl = lane - L;
-      const bool in_block = tl >= 0;
-      const int lidx = in_block ? tl : 0;
-      int ridx = wp + tl; // ring row of frame t - L (only used by lanes before the block)
-      if (ridx < 0)
-        ridx += R;
-      if (in_block)
-        ridx = 0; // keep the masked-off address in range
-      const int hrow = in_block ? 0 : (lookback + tl) * cin; // staged history row of frame t - L
-      const int wk = op.w + k * cin_pad * cpad + co0;
-      for (int ci0 = 0; ci0 < cin; ci0 += 4)
+      const int wk0 = op.w + k * cin_pad * cpad + co0;
+      if (L == 0)
       {
-        float x[4];
-        if (L == 0)
+        // current frame: rows straight from the block (eight input channels per round trip, then four)
+        int ci0 = 0;
+        for (; ci0 + 8 <= cin_pad; ci0 += 8)
+          conv_chunk<2, CB, WLDS>(acc, blob, wlds, wk0 + ci0 * cpad, cpad, [&](int u) { return src[(ci0 + u) * kBlock]; });
+        if (ci0 < cin_pad)
+          conv_chunk<1, CB, WLDS>(acc, blob, wlds, wk0 + ci0 * cpad, cpad, [&](int u) { return src[(ci0 + u) * kBlock]; });
+      }
+      else
+      {
+        const int tl = lane - L;
+        const bool in_block = tl >= 0;
+        const float* srow = lds + op.src + (in_block ? tl : 0);
+        if (staged)
         {
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            x[u] = src[min(ci0 + u, cin - 1) * kBlock + lane];
-        }
-        else if (staged)
-        {
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            const int ci = min(ci0 + u, cin - 1);
-            const float xl = src[ci * kBlock + lidx];
-            const float xh = hist[hrow + ci];
-            x[u] = in_block ? xl : xh;
-          }
+          const float* hrow = hist + (in_block ? 0 : (lookback + tl) * cin);
+          for (int ci0 = 0; ci0 < cin_pad; ci0 += 4)
+            conv_chunk<1, CB, WLDS>(acc, blob, wlds, wk0 + ci0 * cpad, cpad, [&](int u) {
+              const float xl = srow[(ci0 + u) * kBlock];
+              const float xh = hrow[ci0 + u]; // (past the last channel: the next frame's row or the next history, finite)
+              return in_block ? xl : xh;
+            });
         }
         else
         {
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            const int ci = min(ci0 + u, cin - 1);
-            const float xl = src[ci * kBlock + lidx];
-            const float xr = ring[(size_t)ridx * cin + ci];
-            x[u] = in_block ? xl : xr;
-          }
+          int ridx = wp + tl; // ring row of frame t - L (only used by lanes before the block)
+          if (ridx < 0)
+            ridx += R;
+          if (in_block)
+            ridx = 0; // keep the masked-off address in range
+          for (int ci0 = 0; ci0 < cin_pad; ci0 += 4)
+            conv_chunk<1, CB, WLDS>(acc, blob, wlds, wk0 + ci0 * cpad, cpad, [&](int u) {
+              const float xl = srow[(ci0 + u) * kBlock];
+              const float xr = ring[(size_t)ridx * cin + min(ci0 + u, cin - 1)];
+              return in_block ? xl : xr;
+            });
         }
-        // weights of the four channels (rows beyond cin are zero, so the clamped duplicates above add nothing)
-        float wv[4][CB];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-        {
-          if constexpr (WLDS)
-          {
-#pragma unroll
-            for (int j = 0; j < CB; j += 4)
-            {
-              const mf_f4 q = *reinterpret_cast<const mf_f4*>(wlds + wk + (ci0 + u) * cpad + j);
-              wv[u][j] = q[0], wv[u][j + 1] = q[1], wv[u][j + 2] = q[2], wv[u][j + 3] = q[3];
-            }
-          }
-          else
-          {
-#pragma unroll
-            for (int j = 0; j < CB; j++)
-              wv[u][j] = blob[wk + (ci0 + u) * cpad + j];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int j = 0; j < CB; j++)
-            acc[j] = fmaf(wv[u][j], x[u], acc[j]);
       }
     }
     if (film)
     {
       // FiLM epilogue (film.h:76-204): the block holds the scales of `per` channels, then (flag 2) their shifts
-      const int per = film == 2 ? CB / 2 : CB;
-      const int c0 = co0 / CB * per;
-      const float* xs = lds + op.aux;
-      float tv[CB];
+      constexpr int PER_S = CB / 2;
+      const int c0 = film == 2 ? co0 / 2 : co0;
+      const float* xs = lds + op.aux + c0 * kBlock + lane;
+      float* d = lds + op.dst + c0 * kBlock + lane;
+      const int rows_left = ((cout + 3) & ~3) - c0; // (a FiLM over more than 8 / 16 channels: the last block is partial)
+      if (film == 2)
+      {
+        float tv[PER_S];
 #pragma unroll
-      for (int j = 0; j < CB; j++)
-        tv[j] = xs[min(c0 + (j % per), cout - 1) * kBlock + lane];
+        for (int j = 0; j < PER_S; j++)
+          tv[j] = xs[j * kBlock];
 #pragma unroll
-      for (int j = 0; j < CB; j++)
-        if (j < per && c0 + j < cout)
-        {
-          float y = tv[j] * acc[j];
-          if (film == 2)
-            y += acc[(j + CB / 2) % CB];
-          dst[(c0 + j) * kBlock + lane] = y;
-        }
+        for (int j = 0; j < PER_S; j++)
+          if (PER_S <= 4 || j < rows_left)
+            d[j * kBlock] = fmaf(tv[j], acc[j], acc[j + PER_S]);
+      }
+      else
+      {
+        float tv[CB];
+#pragma unroll
+        for (int j = 0; j < CB; j++)
+          tv[j] = xs[j * kBlock];
+#pragma unroll
+        for (int j = 0; j < CB; j++)
+          if (CB <= 4 || j < rows_left)
+            d[j * kBlock] = tv[j] * acc[j];
+      }
     }
     else
     {
+      float* d = lds + op.dst + co0 * kBlock + lane;
+      if (co0 + CB <= ((cout + 3) & ~3))
+      {
 #pragma unroll
-      for (int j = 0; j < CB; j++)
-        if (co0 + j < cout)
-          dst[(co0 + j) * kBlock + lane] = acc[j];
+        for (int j = 0; j < CB; j++)
+          d[j * kBlock] = acc[j];
+      }
+      else // (only the last block of a conv with more than 16 outputs)
+      {
+#pragma unroll
+        for (int j = 0; j < CB; j++)
+          if (co0 + j < cout)
+            d[j * kBlock] = acc[j];
+      }
     }
   }
   if (has_ring)
@@ -179,18 +217,20 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
     int widx = wp + lane;
     if (widx >= R)
       widx -= R;
-    if (lane < nvalid)
-      for (int ci0 = 0; ci0 < cin; ci0 += 4)
-      {
-        float v[4];
+    for (int ci0 = 0; ci0 < cin; ci0 += 4)
+    {
+      float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          v[u] = src[min(ci0 + u, cin - 1) * kBlock + lane];
+      for (int u = 0; u < 4; u++)
+        v[u] = src[(ci0 + u) * kBlock];
+      if (lane < nvalid)
+      {
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (ci0 + u < cin)
             ring[(size_t)widx * cin + ci0 + u] = v[u];
       }
+    }
     int nwp = wp + nvalid;
     if (nwp >= R)
       nwp -= R;
@@ -199,8 +239,8 @@ __device__ __forceinline__ void op_conv(const NamOp& op, float* lds, const float
   }
 }
 
-// Elementwise ops over `n` channel rows, four rows per round trip: f(c, v[]) gets the clamped row values of every
-// operand; results are stored for rows < n.
+// Elementwise ops over `n` channel rows (their tensors own pad4(n) rows), four rows per round trip: f(c, v[]) gets the
+// row values of every operand and returns the value of dst row c.
 template <int NSRC, class F>
 __device__ __forceinline__ void rows4(float* lds, int dst, const int (&srcs)[NSRC], int n, int lane, F&& f)
 {
@@ -211,7 +251,7 @@ __device__ __forceinline__ void rows4(float* lds, int dst, const int (&srcs)[NSR
     for (int s = 0; s < NSRC; s++)
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        v[s][u] = lds[srcs[s] + min(c0 + u, n - 1) * kBlock + lane];
+        v[s][u] = lds[srcs[s] + (c0 + u) * kBlock + lane];
     float r[4];
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -220,12 +260,11 @@ __device__ __forceinline__ void rows4(float* lds, int dst, const int (&srcs)[NSR
 #pragma unroll
       for (int s = 0; s < NSRC; s++)
         a[s] = v[s][u];
-      r[u] = f(min(c0 + u, n - 1), a);
+      r[u] = f(c0 + u, a);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (c0 + u < n)
-        lds[dst + (c0 + u) * kBlock + lane] = r[u];
+      lds[dst + (c0 + u) * kBlock + lane] = r[u];
   }
 }
 
@@ -246,6 +285,9 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
       *reinterpret_cast<mf_f4*>(wdst + i) = *reinterpret_cast<const mf_f4*>(blob + i);
     __syncthreads();
   }
+  // activation rows + history area: zero, so that padding rows (never written by LOAD_IN / exact-size stores) are finite
+  for (int i = lane; i < a.w_lds_off; i += 64)
+    lds[i] = 0.0f;
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
   float* st = a.state + (size_t)stream * a.state_stride;
   int* wpos_tbl = reinterpret_cast<int*>(st);
@@ -310,10 +352,13 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
               out[(size_t)c * a.io_stride + f0 + lane] = lds[op.src + c * kBlock + lane];
           break;
         case OP_CONV:
-          if (op.cb == 8)
-            op_conv<8, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
-          else
-            op_conv<4, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid);
+          switch (op.cb)
+          {
+            case 4: op_conv<4, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid); break;
+            case 8: op_conv<8, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid); break;
+            case 12: op_conv<12, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid); break;
+            default: op_conv<16, WLDS>(op, lds, blob, wlds, st, wpos_tbl, lane, nvalid); break;
+          }
           break;
         case OP_FILM:
         {

@@ -24,6 +24,9 @@ struct RowAlloc
   int high = 0;
   int alloc(int rows)
   {
+    // every tensor owns a multiple of four rows: the kernel reads, computes and writes rows four at a time without
+    // per-row tests (its weights / biases are zero-padded to match, so the padding rows hold zeros or finite scratch)
+    rows = (rows + 3) / 4 * 4;
     const int r = top;
     top += rows;
     high = std::max(high, top);
@@ -68,7 +71,8 @@ struct Builder
   // Dense conv (K >= 1) consuming weights from the flat stream. Returns nothing; dst rows must exist.
   void conv(const float*& w, int dst, int src, int cin, int cout, int K, int dil, int groups, bool bias)
   {
-    const int cb = (cout >= 8) ? 8 : 4;
+    // outputs are produced in register blocks of `cb` = pad4(cout) channels (one block up to 16 outputs)
+    const int cb = std::min((cout + 3) / 4 * 4, 16);
     const int cout_pad = (cout + cb - 1) / cb * cb;
     const int cin_pad = (cin + 3) / 4 * 4; // zero rows: the kernel reads input channels four at a time
     const int woff = blob_reserve((size_t)K * cin_pad * cout_pad);
@@ -162,8 +166,9 @@ struct Builder
   void film(const float*& w, const FilmSpec& f, int dst, int src, int cond, int cond_dim, int dim)
   {
     const int cout = (f.shift ? 2 : 1) * dim;
-    const int cb = (cout >= 8) ? 8 : 4;
-    const int per = f.shift ? cb / 2 : cb; // channels per register block
+    // channels per register block: pad4(dim), at most 8 with a shift (16 accumulators) / 16 without
+    const int per = std::min((dim + 3) / 4 * 4, f.shift ? 8 : 16);
+    const int cb = f.shift ? 2 * per : per;
     const int cout_pad = (dim + per - 1) / per * cb;
     auto col = [&](int o) {
       const int c = o < dim ? o : o - dim;
@@ -1263,7 +1268,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
   b.finish_stages(1); // history staging ops right behind OP_LOAD_IN
   b.push(OP_END);
   b.push(OP_END); // the interpreter reads one descriptor ahead
-  plan.lds_rows = b.rows.high;
+  plan.lds_rows = b.rows.high + 4; // + 4 spare rows: the kernel's four-row reads may run past the last tensor
   while (plan.blob.size() % 4)
     plan.blob.push_back(0.0f);
   plan.generic_blob_floats = (int)plan.blob.size();
