@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
     "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_render_f32", "nam_hip_batch_synchronize",
     "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams", "nam_hip_batch_kernel_name",
+    "nam_hip_batch_set_persistent", "nam_hip_batch_flush",
     "nam_hip_batch_debug_timeline",
 ]
 
@@ -136,6 +137,8 @@ def load_library():
     L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
     L.nam_hip_batch_get_kernel.argtypes = [vp]
     L.nam_hip_batch_n_streams.argtypes = [vp]
+    L.nam_hip_batch_set_persistent.argtypes = [vp, ci]
+    L.nam_hip_batch_flush.argtypes = [vp, vp]
     L.nam_hip_batch_kernel_name.argtypes = [vp]
     L.nam_hip_batch_kernel_name.restype = ctypes.c_char_p
     L.nam_hip_batch_debug_timeline.argtypes = [vp, ci, vp]
@@ -264,6 +267,14 @@ class Batch:
 
     def get_kernel(self) -> int:
         return _check(self._L.nam_hip_batch_get_kernel(self._h))
+
+    def set_persistent(self, enable: bool = True) -> bool:
+        """Persistent block mode (include/nam_hip.h): True if the batch will use it."""
+        return _check(self._L.nam_hip_batch_set_persistent(self._h, 1 if enable else 0)) == 1
+
+    def flush(self, stream: int = 0):
+        """Wait until every buffer submitted in persistent mode is rendered (``stream``: the hipStream_t they were issued on)."""
+        _check(self._L.nam_hip_batch_flush(self._h, ctypes.c_void_p(stream)))
 
     def kernel_name(self) -> str:
         """The __global__ function the batch's largest stream group runs (the name rocprofv3 reports)."""

@@ -20,7 +20,14 @@ namespace namhip
 // Same state layout, rings and write positions as every other A1 kernel; same numerics (the MFMAs and the
 // activation code are the same, only the control flow is resolved by the compiler).
 // ================================================================================================
-template <int C0, int C1, int ACT_T, bool WT>
+// PERSIST (block mode without kernel boundaries): the launch stays resident and consumes COMMANDS — one per 64-frame
+// buffer, `(seq << 32) | frame offset` written into a device-memory ring by hipStreamWriteValue64 on the caller's
+// stream (nam_hip_api.cpp: persistent session). Wave 0 fetches command k + 1 while block k is still computing and
+// the workgroup agrees on it at the end of the block (one extra barrier); with the ring empty the workgroup
+// publishes its progress behind a system-scope release fence, then polls (bounded: a session that is never fed
+// expires by itself). What a launch per buffer costs on top of the jobs — dispatch, kernarg and write-position
+// round trips, weights into LDS, the write-through drain — is paid once per session instead of once per buffer.
+template <int C0, int C1, int ACT_T, bool WT, bool PERSIST>
 __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict__ blob, const A1Args a)
 {
   using namespace mf;
@@ -34,7 +41,7 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
   const int w = uni(tid >> 6);
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
   float* st = a.state + (size_t)stream * a.state_stride;
-  const int n_blocks = (a.n_frames + kBlock - 1) / kBlock;
+  const int n_blocks = PERSIST ? (1 << 30) : (a.n_frames + kBlock - 1) / kBlock;
 
   const int g = lane >> 4;
   const int j = lane & 15;
@@ -48,8 +55,10 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
   const unsigned v_lane16 = (unsigned)lane * 16u;
   const bool hi_pair = (g >> 1) != 0;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st, 0, (int)(a.state_stride * 4), 0x00020000);
-  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(in ? in : st), 0, in ? a.n_frames * 4 : 0, 0x00020000);
-  const auto rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out ? out : st), 0, out ? a.n_frames * 4 : 0, 0x00020000);
+  // (persistent sessions address a whole resident window of the stream's row: commands carry frame offsets into it)
+  const int io_bytes = PERSIST ? 0x7ffffff0 : a.n_frames * 4;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(in ? in : st), 0, in ? io_bytes : 0, 0x00020000);
+  const auto rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out ? out : st), 0, out ? io_bytes : 0, 0x00020000);
   int* wpos_tbl = reinterpret_cast<int*>(st);
   int wposv = lane < NJ ? wpos_tbl[lane] : 0; // lane r = write position of ring r (ring r = job r)
   const int ring_len_v = 2 * (1 << (lane % p2::kLayers)) + kBlock;
@@ -113,7 +122,48 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     constexpr int U = decltype(u_tag)::value;
     fetch(sa[U], sb[U], std::integral_constant<int, U>{}, std::integral_constant<int, 0>{}, true, t, v_g16);
   };
-  inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, 0, 0));
+  // ---- persistent session: command ring -------------------------------------------------------------------
+  unsigned seq = a.p_first_seq; // commands consumed so far
+  unsigned boff = 0; // byte offset of the current block's frames in the stream's row (non-persistent: blk * 256)
+  int* const cmd_lds = reinterpret_cast<int*>(lds_p2) + p2::kFlagB / 4; // [0..1] = command agreed on by the workgroup
+  constexpr unsigned kExit = 0xffffffffu;
+  auto ring_load = [&](unsigned s_) {
+    return __hip_atomic_load(a.p_ring + (s_ & (unsigned)a.p_ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  // wave 0 waits (bounded) for command `want`; returns its low word, or kExit on EXIT / expiry
+  auto wait_cmd = [&](unsigned want) {
+    unsigned lo = kExit;
+    const unsigned long long t0 = wall_clock64();
+    for (;;)
+    {
+      const unsigned long long v = ring_load(want - 1);
+      if ((unsigned)(v >> 32) == want)
+      {
+        lo = (unsigned)v;
+        break;
+      }
+      if (wall_clock64() - t0 > 200000000ull) // ~2 s at 100 MHz: nobody feeds this session any more
+        break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    return lo;
+  };
+  if constexpr (PERSIST)
+  {
+    unsigned lo = 0;
+    if (w == 0)
+    {
+      lo = wait_cmd(seq + 1);
+      if (lane == 0)
+        cmd_lds[0] = (int)lo;
+    }
+    lds_barrier();
+    lo = (unsigned)uni(cmd_lds[0]);
+    if (lo == kExit)
+      return; // (nothing consumed: state untouched)
+    boff = lo * 4u;
+  }
+  inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), 0));
   il::for_each_index(prologue, std::make_integer_sequence<int, NJ>{});
   // the weights (requested before the ring rows, so they are here first)
 #pragma unroll
@@ -150,6 +200,9 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
   // behind its ring append, its requests and its tap shuffles.
   Ops O;
 
+  unsigned long long spec_cmd = 0; // persistent: this wave's early look at the next command
+  bool spec_ok = false;
+  unsigned spec_off = 0;
   // one job, everything about it known at compile time
   auto job = [&](auto j_tag) {
     constexpr int JI = decltype(j_tag)::value;
@@ -177,8 +230,8 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     if constexpr ((flags & CD_X0) != 0)
     {
       cond = inp; // this block's input sample (requested a block ago)
-      // next block's (offset beyond the launch's frames -> 0)
-      inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((blk + 1) * (kBlock * 4)), 0));
+      if constexpr (!PERSIST) // next block's (offset beyond the launch's frames -> 0)
+        inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((blk + 1) * (kBlock * 4)), 0));
       x = ev * cond;
       head = f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -191,7 +244,15 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(il::u4, x), rsrc, (int)off, 0, WT ? 17 : 0);
     }
     // the same job of the NEXT block: its requests go into the slot just consumed
-    fetch(sa[JI], sb[JI], j_tag, std::integral_constant<int, 1>{}, blk + 1 < n_blocks, tl, gl16);
+    fetch(sa[JI], sb[JI], j_tag, std::integral_constant<int, 1>{}, PERSIST || blk + 1 < n_blocks, tl, gl16);
+    if constexpr (PERSIST && JI == 8)
+      spec_cmd = ring_load(seq + 1); // command of the NEXT block, looked at in job 12 (speculative, per wave)
+    if constexpr (PERSIST && JI == 12)
+    {
+      spec_ok = (unsigned)(spec_cmd >> 32) == seq + 2 && (unsigned)spec_cmd != kExit;
+      spec_off = spec_ok ? (unsigned)spec_cmd * 4u : 0u;
+      inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((int)spec_off), 0));
+    }
     auto slice = [&](const f4& r) { return NK == 4 ? r : (hi_pair ? f4{r[2], r[3], 0.f, 0.f} : f4{r[0], r[1], 0.f, 0.f}); };
     f4 bt0, bt1;
     if constexpr (J.kind == IL_HIST)
@@ -262,7 +323,7 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
       const float yout = head_scale * (mfma_n<NK>(xt, head, f4{0.f, 0.f, 0.f, 0.f}) + ev)[0];
       const bool ok = gl16 == 0 && tl < nvalid;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob,
-                                            uni(blk * (kBlock * 4)), 0);
+                                            uni((int)boff), 0);
     }
     else if constexpr ((flags & CD_POST_RECH) != 0)
       x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
@@ -276,32 +337,95 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     if (wposv >= ring_len_v)
       wposv -= ring_len_v;
     blk++;
-    nvalid = min(kBlock, a.n_frames - blk * kBlock);
+    if constexpr (!PERSIST)
+    {
+      nvalid = min(kBlock, a.n_frames - blk * kBlock);
+      boff = (unsigned)blk * (kBlock * 4u);
+    }
+    else
+    {
+      seq++;
+      // the workgroup agrees on the next command: wave 0's view (it may differ from another wave's early look)
+      if (w == 0)
+      {
+        const unsigned long long v = ring_load(seq);
+        const bool ready = (unsigned)(v >> 32) == seq + 1;
+        if (lane == 0)
+        {
+          cmd_lds[0] = ready ? (int)(unsigned)v : 0;
+          cmd_lds[1] = ready ? 1 : 0;
+          if ((seq & 15u) == 0u) // progress for the host's ring bookkeeping (not a completion signal: no fence)
+            __hip_atomic_store(a.p_prog + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      lds_barrier();
+      unsigned lo = (unsigned)uni(cmd_lds[0]);
+      bool ready = uni(cmd_lds[1]) != 0;
+      if (!ready)
+      {
+        // ring empty: everything this workgroup has written becomes visible, THEN its completion count; then wait
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        lds_barrier();
+        if (w == 0)
+        {
+          if (lane == 0)
+            __hip_atomic_store(a.p_done + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          lo = wait_cmd(seq + 1);
+          if (lane == 0)
+            cmd_lds[0] = (int)lo;
+        }
+        lds_barrier();
+        lo = (unsigned)uni(cmd_lds[0]);
+        ready = lo != kExit;
+      }
+      lds_barrier(); // (cmd_lds is rewritten at the end of the next block; the exchange windows are untouched)
+      if (!ready || lo == kExit)
+        break;
+      boff = lo * 4u;
+      if (!(spec_ok && spec_off == boff)) // the early look missed: request the input sample now (exposed)
+        inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), 0));
+    }
   }
   if (w == 0 && lane < NJ)
     wpos_tbl[lane] = wposv;
+  if constexpr (PERSIST)
+  {
+    // session end (EXIT command or expiry): state and outputs visible, then the final count with the EXITED bit
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    lds_barrier();
+    if (w == 0 && lane == 0)
+      __hip_atomic_store(a.p_done + blockIdx.x, seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 namespace
 {
-template <int C0, int C1, int ACT_T, bool WT>
+template <int C0, int C1, int ACT_T, bool WT, bool PERSIST = false>
 hipError_t launch_p2_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 {
   static bool configured = false;
   if (!configured)
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_p2_kernel<C0, C1, ACT_T, WT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p2::kLdsBytes);
     if (e != hipSuccess)
       return e;
     configured = true;
   }
-  hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT>), dim3(n_blocks), dim3(256), p2::kLdsBytes, stream, a.blob, a);
+  hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(256), p2::kLdsBytes, stream, a.blob, a);
   return hipGetLastError();
 }
 template <int C0, int C1>
 hipError_t launch_p2_shape(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
+  if (a.p_ring) // persistent session (plain write-back stores: there is no kernel boundary to drain for)
+  {
+    if (act == ACT_FASTTANH)
+      return launch_p2_inst<C0, C1, ACT_FASTTANH, false, true>(a, n_blocks, stream);
+    if (act == ACT_TANH)
+      return launch_p2_inst<C0, C1, ACT_TANH, false, true>(a, n_blocks, stream);
+    return launch_p2_inst<C0, C1, -1, false, true>(a, n_blocks, stream);
+  }
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
   if (act == ACT_FASTTANH)
     return wt ? launch_p2_inst<C0, C1, ACT_FASTTANH, true>(a, n_blocks, stream) : launch_p2_inst<C0, C1, ACT_FASTTANH, false>(a, n_blocks, stream);

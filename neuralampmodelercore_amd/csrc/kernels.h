@@ -56,6 +56,13 @@ struct A1Args
   int il_jobs, il_real_jobs, il_depth, il_exch;
   int il_consts_b, il_xt_b, il_tiles_b, il_flag_b, il_lds_bytes;
   int act; // the arrays' activation type when it is uniform (nam_a1_p2_kernel's run-time-dispatch instantiation)
+  // persistent session of nam_a1_p2_kernel (nullptr = ordinary launch): command ring in device memory, ring size - 1,
+  // commands consumed before this launch, per-workgroup progress / completion words in host-mapped memory
+  unsigned long long* p_ring;
+  int p_ring_mask;
+  unsigned p_first_seq;
+  unsigned* p_prog;
+  unsigned* p_done;
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -104,6 +105,28 @@ struct WidthGroup
 };
 } // namespace
 
+namespace
+{
+// Persistent block mode (nam_hip_batch_set_persistent): one resident launch of nam_a1_p2_kernel per session, fed one
+// command per 64-frame buffer through a device-memory ring (kernel_a1_p2.hip, PERSIST).
+constexpr unsigned kPRing = 1024; // commands in flight at most (power of two)
+struct PersistSession
+{
+  bool enabled = false; // the caller opted in
+  bool active = false; // a resident launch is consuming commands
+  unsigned long long* d_ring = nullptr; // device memory: (seq << 32) | frame offset
+  unsigned* h_words = nullptr; // host-mapped: [0, n_wg) progress, [n_wg, 2 n_wg) completion (bit 31 = exited)
+  unsigned* d_words = nullptr; // the same words as the device sees them
+  hipStream_t kstream = nullptr; // the resident launch's own stream (nothing else may be enqueued behind it)
+  hipEvent_t order = nullptr; // makes the launch wait for what the caller had enqueued before the first buffer
+  unsigned seq = 0; // commands submitted in this session
+  const float* in_base = nullptr;
+  float* out_base = nullptr;
+  long stride = 0;
+  int n_wg = 0;
+};
+} // namespace
+
 struct nam_hip_batch
 {
   const nam_hip_model* model = nullptr;
@@ -124,6 +147,8 @@ struct nam_hip_batch
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
+  PersistSession ps;
+  bool ps_launching = false; // launch_group is starting the session's resident launch
 };
 
 namespace
@@ -170,8 +195,12 @@ int ensure_state(nam_hip_batch* b, WidthGroup& g)
 }
 
 // Wait for everything the batch may still have in flight: its own stream and the last caller-supplied one.
+int persist_stop(nam_hip_batch* b);
+
 hipError_t quiesce(nam_hip_batch* b)
 {
+  if (b->ps.active && persist_stop(b) != NAM_HIP_OK) // a resident launch owns the streams' state until it has left
+    return hipErrorUnknown;
   hipError_t e = b->stream ? hipStreamSynchronize(b->stream) : hipSuccess;
   if (b->last_ext_stream && b->last_ext_stream != b->stream)
   {
@@ -233,9 +262,13 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 
 // Name of the __global__ function launch_group runs for this group (what rocprofv3 --kernel-trace reports, without
 // template arguments): lets callers attribute measurements to the right kernel.
+bool persist_eligible(const nam_hip_batch* b);
+
 const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
 {
   const Plan& p = *g.plan;
+  if (b->ps.enabled && persist_eligible(b))
+    return "nam_a1_p2_kernel"; // persistent block mode
   if (p.arch == ARCH_WAVENET)
   {
     switch (pick_kernel(b, g))
@@ -293,6 +326,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.r1_off = a.xt_off = a.n_xt = a.lds_tiles_b = a.lds_xt_b = a.lds_cond_b = a.lds_bytes = a.prefetch = 0;
       a.il_jobs = a.il_real_jobs = a.il_depth = a.il_exch = 0;
       a.il_consts_b = a.il_xt_b = a.il_tiles_b = a.il_flag_b = a.il_lds_bytes = a.act = 0;
+      a.p_ring = nullptr;
+      a.p_ring_mask = 0;
+      a.p_first_seq = 0;
+      a.p_prog = a.p_done = nullptr;
       if (kernel == NAM_HIP_KERNEL_A1_IL)
       {
         int act = p.a1.arr[0].act;
@@ -313,6 +350,14 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
         a.il_flag_b = p.a1.il_flag_b;
         a.il_lds_bytes = p.a1.il_lds_bytes;
         a.act = act;
+        if (b->ps_launching)
+        {
+          a.p_ring = b->ps.d_ring;
+          a.p_ring_mask = (int)kPRing - 1;
+          a.p_first_seq = 0;
+          a.p_prog = b->ps.d_words;
+          a.p_done = b->ps.d_words + n;
+        }
         if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
           NAM_HIP_CHECK(launch_a1_p2(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
         else
@@ -455,6 +500,164 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
       return rc;
   }
   return NAM_HIP_OK;
+}
+
+// ---- persistent block mode -------------------------------------------------------------------------------------
+bool persist_eligible(const nam_hip_batch* b)
+{
+  const WidthGroup& g = b->groups[b->model->full_width];
+  return b->ps.enabled && !b->il_generic && g.plan->arch == ARCH_WAVENET && g.plan->a1.valid && g.plan->a1.il_ok
+         && g.plan->a1.p2_ok && (int)g.streams.size() == b->n_streams && g.d_map == nullptr
+         && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL);
+}
+
+// Waits (host side) until every workgroup of the session has consumed all submitted commands and made its results
+// visible; `need_exit`: until it has left the kernel.
+int persist_wait(nam_hip_batch* b, bool need_exit)
+{
+  PersistSession& ps = b->ps;
+  const unsigned* done = ps.h_words + ps.n_wg;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long it = 0;; it++)
+  {
+    bool all = true;
+    bool expired = false;
+    for (int w = 0; w < ps.n_wg && all; w++)
+    {
+      const unsigned v = __atomic_load_n(&done[w], __ATOMIC_ACQUIRE);
+      const bool exited = (v & 0x80000000u) != 0;
+      if (exited && (v & 0x7fffffffu) < ps.seq)
+        expired = true; // the session expired (it was not fed for ~2 s) before consuming everything
+      all = need_exit ? exited : ((v & 0x7fffffffu) >= ps.seq);
+    }
+    if (expired)
+      return fail(NAM_HIP_ERR_DEVICE, "persistent session expired before consuming every submitted buffer");
+    if (all)
+      return NAM_HIP_OK;
+    if ((it & 1023) == 1023
+        && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
+      return fail(NAM_HIP_ERR_DEVICE, "persistent session did not respond within 10 s");
+  }
+}
+
+int persist_stop(nam_hip_batch* b)
+{
+  PersistSession& ps = b->ps;
+  if (!ps.active)
+    return NAM_HIP_OK;
+  // EXIT is just the next command (slots are claimed by sequence number, so it cannot overtake a buffer)
+  NAM_HIP_CHECK(hipStreamWriteValue64(b->stream, ps.d_ring + (ps.seq & (kPRing - 1)),
+                                      ((unsigned long long)(ps.seq + 1) << 32) | 0xffffffffull, 0));
+  const hipError_t e = hipStreamSynchronize(ps.kstream); // (bounded: an unfed session expires by itself)
+  ps.active = false;
+  NAM_HIP_CHECK(e);
+  NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
+  return NAM_HIP_OK;
+}
+
+int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride, hipStream_t caller)
+{
+  PersistSession& ps = b->ps;
+  WidthGroup& g = b->groups[b->model->full_width];
+  const int n = (int)g.streams.size();
+  if (!ps.d_ring)
+  {
+    NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long)));
+    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_words), 2 * (size_t)b->n_streams * sizeof(unsigned),
+                                hipHostMallocMapped | hipHostMallocCoherent));
+    NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_words), ps.h_words, 0));
+    NAM_HIP_CHECK(hipStreamCreateWithFlags(&ps.kstream, hipStreamNonBlocking));
+    NAM_HIP_CHECK(hipEventCreateWithFlags(&ps.order, hipEventDisableTiming));
+  }
+  NAM_HIP_CHECK(hipMemsetAsync(ps.d_ring, 0, kPRing * sizeof(unsigned long long), ps.kstream));
+  std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
+  ps.seq = 0;
+  ps.in_base = d_in;
+  ps.out_base = d_out;
+  ps.stride = stride;
+  ps.n_wg = n;
+  // the resident launch starts behind whatever the caller (and the batch's own stream) had enqueued so far
+  NAM_HIP_CHECK(hipEventRecord(ps.order, caller));
+  NAM_HIP_CHECK(hipStreamWaitEvent(ps.kstream, ps.order, 0));
+  if (caller != b->stream)
+  {
+    NAM_HIP_CHECK(hipEventRecord(ps.order, b->stream));
+    NAM_HIP_CHECK(hipStreamWaitEvent(ps.kstream, ps.order, 0));
+  }
+  const int keep = b->kernel;
+  b->kernel = NAM_HIP_KERNEL_A1_IL;
+  b->ps_launching = true;
+  const int rc = launch_group(b, g, nullptr, n, d_in, d_out, kBlock, stride, ps.kstream);
+  b->ps_launching = false;
+  b->kernel = keep;
+  if (rc != NAM_HIP_OK)
+    return rc;
+  ps.active = true;
+  return NAM_HIP_OK;
+}
+
+// One 64-frame buffer for every stream of the batch through the resident launch. Falls back (returns 1) when this call
+// cannot be expressed as a command of the session.
+int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_frames, long stride, hipStream_t caller)
+{
+  PersistSession& ps = b->ps;
+  if (n_frames != kBlock)
+    return 1;
+  if (ps.active)
+  {
+    const long off_in = d_in - ps.in_base, off_out = d_out - ps.out_base;
+    if (stride != ps.stride || off_in != off_out || off_in < 0 || off_in > 0x3fffffffl)
+    {
+      const int rc = persist_stop(b); // a different window: the session ends, the next one starts here
+      if (rc != NAM_HIP_OK)
+        return rc;
+    }
+  }
+  if (!ps.active)
+  {
+    const int rc = persist_start(b, d_in, d_out, stride, caller);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  // never lap the kernel by a whole ring: the workgroups report their progress every 16 commands
+  if (ps.seq >= kPRing / 2 && (ps.seq & 63u) == 0u)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long it = 0;; it++)
+    {
+      unsigned lo = ~0u;
+      for (int w = 0; w < ps.n_wg; w++)
+      {
+        const unsigned pv = __atomic_load_n(&ps.h_words[w], __ATOMIC_RELAXED);
+        const unsigned dv = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_RELAXED) & 0x7fffffffu;
+        lo = std::min(lo, std::max(pv, dv));
+      }
+      if (ps.seq - lo < kPRing - 128)
+        break;
+      if ((it & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
+        return fail(NAM_HIP_ERR_DEVICE, "persistent session stalled (command ring full for 10 s)");
+    }
+  }
+  const unsigned long long cmd = ((unsigned long long)(ps.seq + 1) << 32) | (unsigned long long)(unsigned)(d_in - ps.in_base);
+  NAM_HIP_CHECK(hipStreamWriteValue64(caller, ps.d_ring + (ps.seq & (kPRing - 1)), cmd, 0));
+  ps.seq++;
+  WidthGroup& g = b->groups[b->model->full_width];
+  g.state_family = state_family_of(*g.plan, NAM_HIP_KERNEL_A1_IL);
+  return NAM_HIP_OK;
+}
+
+void persist_free(nam_hip_batch* b)
+{
+  PersistSession& ps = b->ps;
+  if (ps.d_ring)
+    (void)hipFree(ps.d_ring);
+  if (ps.h_words)
+    (void)hipHostFree(ps.h_words);
+  if (ps.kstream)
+    (void)hipStreamDestroy(ps.kstream);
+  if (ps.order)
+    (void)hipEventDestroy(ps.order);
+  ps = PersistSession();
 }
 
 void free_group(WidthGroup& g)
@@ -718,6 +921,7 @@ void nam_hip_batch_destroy(nam_hip_batch* batch)
     return;
   (void)hipSetDevice(batch->device);
   (void)quiesce(batch);
+  persist_free(batch);
   for (auto& g : batch->groups)
     free_group(g);
   if (batch->d_in)
@@ -828,6 +1032,22 @@ int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float*
   hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : batch->stream;
   if (hip_stream)
     batch->last_ext_stream = s;
+  if (batch->ps.enabled && persist_eligible(batch))
+  {
+    // fresh state has the layout either kernel family writes; anything else must already be the A1 family's
+    WidthGroup& g0 = batch->groups[batch->model->full_width];
+    if (g0.state_family >= 0 && g0.state_family != state_family_of(*g0.plan, NAM_HIP_KERNEL_A1_IL))
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "persistent mode: the state was written by the generic kernel; reset first");
+    const int rc = persist_submit(batch, d_in, d_out, n_frames, (long)frame_stride, s);
+    if (rc <= 0)
+      return rc; // submitted (0) or failed (< 0)
+  }
+  if (batch->ps.active) // this call is not a 64-frame buffer of the session: the resident launch hands the state back first
+  {
+    const int rc = persist_stop(batch);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
   for (auto& g : batch->groups)
   {
     if (g.streams.empty())
@@ -854,6 +1074,12 @@ int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out,
   const int rc = nam_hip_batch_process_device(batch, batch->d_in, batch->d_out, n_frames, n_frames, nullptr);
   if (rc != NAM_HIP_OK)
     return rc;
+  if (batch->ps.active) // persistent mode: the buffer is done when every workgroup has published its count
+  {
+    const int rw = persist_wait(batch, false);
+    if (rw != NAM_HIP_OK)
+      return rw;
+  }
   NAM_HIP_CHECK(hipMemcpyAsync(out, batch->d_out, out_bytes, hipMemcpyDeviceToHost, batch->stream));
   NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
   return NAM_HIP_OK;
@@ -924,6 +1150,12 @@ int nam_hip_batch_process_f64(nam_hip_batch* batch, const double* in, double* ou
   const int rc = nam_hip_batch_process_device(batch, batch->d_in, batch->d_out, n_frames, n_frames, nullptr);
   if (rc != NAM_HIP_OK)
     return rc;
+  if (batch->ps.active)
+  {
+    const int rw = persist_wait(batch, false);
+    if (rw != NAM_HIP_OK)
+      return rw;
+  }
   NAM_HIP_CHECK(
     hipMemcpyAsync(batch->h_stage, batch->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, batch->stream));
   NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
@@ -938,13 +1170,49 @@ int nam_hip_batch_synchronize(nam_hip_batch* batch)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_synchronize: null batch");
   NAM_HIP_CHECK(hipSetDevice(batch->device));
   NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  if (batch->ps.active)
+    return persist_wait(batch, false);
   return NAM_HIP_OK;
+}
+
+int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable)
+{
+  if (!batch)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_persistent: null batch");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  if (!enable && batch->ps.active)
+  {
+    const int rc = persist_stop(batch);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
+  batch->ps.enabled = enable != 0;
+  return (batch->ps.enabled && persist_eligible(batch)) ? 1 : 0;
+}
+
+int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream)
+{
+  if (!batch)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_flush: null batch");
+  NAM_HIP_CHECK(hipSetDevice(batch->device));
+  if (!batch->ps.active)
+    return NAM_HIP_OK;
+  // the doorbells were enqueued on the caller's stream: they are only guaranteed to have been rung once it has drained
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : batch->stream;
+  NAM_HIP_CHECK(hipStreamSynchronize(s));
+  return persist_wait(batch, false);
 }
 
 int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
   if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_IL)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
+  if (batch->ps.active)
+  {
+    const int rc = persist_stop(batch);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
   bool all_lstm = true;
   for (const auto& g : batch->groups)
     all_lstm = all_lstm && g.plan->arch == ARCH_LSTM;

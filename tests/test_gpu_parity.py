@@ -847,3 +847,46 @@ def test_interleaved_mfma_kernel_headline_shape_and_determinism(nam_lib, oracle)
         b.close()
     for yy in outs[1:]:
         np.testing.assert_array_equal(outs[0], yy)
+
+
+def test_persistent_block_mode_matches_oracle(nam_lib, oracle):
+    """Persistent block mode (nam_hip_batch_set_persistent): one resident launch of nam_a1_p2_kernel consumes one
+    doorbell per 64-frame buffer. Device-pointer calls walking a resident window, then the blocking host path (fixed
+    staging buffers: a new session), a call that is not a 64-frame buffer (falls back to a launch and back), Reset in
+    the middle, and leaving the mode: every stream against the oracle throughout."""
+    torch = pytest.importorskip("torch")
+    nam = nam_lib
+    n_streams, block, nb = 7, 64, 12
+    x = stream_bank(n_streams, block * nb + 40, seed=321)
+    for name in ("wavenet_a1_standard", "synth_a1_feather"):
+        model = nam.get_dsp(model_path(name), fast_tanh=True)
+        refs = [_oracle_run(oracle, name, x[s], block, True) for s in range(n_streams)]
+        b = model.batch(n_streams, block)
+        assert b.set_persistent(True) and b.kernel_name() == "nam_a1_p2_kernel"
+        b.Reset(prewarm=True)
+        xd = torch.from_numpy(x[:, None, :]).cuda()
+        yd = torch.zeros_like(xd)
+        T = xd.shape[2]
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        for k in range(6):  # device pointers, walking the resident window: one session, six commands
+            b.process_device(xd.data_ptr() + k * block * 4, yd.data_ptr() + k * block * 4, block, T, st.cuda_stream)
+        b.flush(st.cuda_stream)
+        torch.cuda.synchronize()
+        y = yd.cpu().numpy()
+        parts = [y[:, :, :6 * block]]
+        for k in range(6, 9):  # host path: staging buffers = another window -> the session restarts transparently
+            parts.append(b.process(x[:, k * block:(k + 1) * block]))
+        parts.append(b.process(x[:, 9 * block:9 * block + 40]))  # 40 frames: an ordinary launch
+        y = np.concatenate(parts, axis=-1)
+        for s in range(n_streams):
+            r = refs[s][:, :9 * block + 40]
+            assert float(np.max(np.abs(r - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), (name, s)
+        b.Reset(prewarm=True)  # ends the session, state starts over
+        y2 = np.concatenate([b.process(x[:, k * block:(k + 1) * block]) for k in range(3)], axis=-1)
+        assert not b.set_persistent(False)
+        y3 = b.process(x[:, 3 * block:4 * block])  # launches again
+        b.close()
+        y2 = np.concatenate([y2, y3], axis=-1)
+        for s in range(n_streams):
+            assert float(np.max(np.abs(refs[s][:, :4 * block] - y2[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(refs[s])))), (name, s)
