@@ -123,6 +123,10 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     fetch(sa[U], sb[U], std::integral_constant<int, U>{}, std::integral_constant<int, 0>{}, true, t, v_g16);
   };
   // ---- persistent session: command ring -------------------------------------------------------------------
+  // Input samples of a persistent session bypass L1 / L2 (sc0 sc1): the caller may rewrite the same input buffer between
+  // two commands (the blocking host path copies every buffer into one staging area), and without a kernel boundary
+  // nothing invalidates the line this CU read a buffer ago.
+  constexpr int kInAux = PERSIST ? 17 : 0;
   unsigned seq = a.p_first_seq; // commands consumed so far
   unsigned boff = 0; // byte offset of the current block's frames in the stream's row (non-persistent: blk * 256)
   int* const cmd_lds = reinterpret_cast<int*>(lds_p2) + p2::kFlagB / 4; // [0..1] = command agreed on by the workgroup
@@ -160,10 +164,15 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     lds_barrier();
     lo = (unsigned)uni(cmd_lds[0]);
     if (lo == kExit)
-      return; // (nothing consumed: state untouched)
+    {
+      // nothing consumed, state untouched; still tell the host that this workgroup has left
+      if (w == 0 && lane == 0)
+        __hip_atomic_store(a.p_done + blockIdx.x, seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     boff = lo * 4u;
   }
-  inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), 0));
+  inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), kInAux));
   il::for_each_index(prologue, std::make_integer_sequence<int, NJ>{});
   // the weights (requested before the ring rows, so they are here first)
 #pragma unroll
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     {
       spec_ok = (unsigned)(spec_cmd >> 32) == seq + 2 && (unsigned)spec_cmd != kExit;
       spec_off = spec_ok ? (unsigned)spec_cmd * 4u : 0u;
-      inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((int)spec_off), 0));
+      inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((int)spec_off), kInAux));
     }
     auto slice = [&](const f4& r) { return NK == 4 ? r : (hi_pair ? f4{r[2], r[3], 0.f, 0.f} : f4{r[0], r[1], 0.f, 0.f}); };
     f4 bt0, bt1;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
         break;
       boff = lo * 4u;
       if (!(spec_ok && spec_off == boff)) // the early look missed: request the input sample now (exposed)
-        inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), 0));
+        inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), kInAux));
     }
   }
   if (w == 0 && lane < NJ)

@@ -566,10 +566,17 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_words), 2 * (size_t)b->n_streams * sizeof(unsigned),
                                 hipHostMallocMapped | hipHostMallocCoherent));
     NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_words), ps.h_words, 0));
-    NAM_HIP_CHECK(hipStreamCreateWithFlags(&ps.kstream, hipStreamNonBlocking));
+    // Its own hardware queue: HIP multiplexes streams of one priority onto a few hardware queues, and a doorbell
+    // enqueued on a stream that shares the resident launch's queue would wait behind it for ever. Streams of the
+    // highest priority get a queue of their own.
+    int prio_lo = 0, prio_hi = 0;
+    NAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    NAM_HIP_CHECK(hipStreamCreateWithPriority(&ps.kstream, hipStreamNonBlocking, prio_hi));
     NAM_HIP_CHECK(hipEventCreateWithFlags(&ps.order, hipEventDisableTiming));
   }
+  // (the ring is clean before the first doorbell can be rung: a doorbell travels on another stream)
   NAM_HIP_CHECK(hipMemsetAsync(ps.d_ring, 0, kPRing * sizeof(unsigned long long), ps.kstream));
+  NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
   std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
   ps.seq = 0;
   ps.in_base = d_in;
