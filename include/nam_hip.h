@@ -192,7 +192,9 @@ NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);
  * calls were issued on; NULL = the batch's own). No-op outside persistent mode. */
 NAM_HIP_API int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream);
 
-/* Wait for everything enqueued on the batch's own stream. */
+/* Wait for everything enqueued on the batch's own stream (and on the last caller-supplied one). Ends a persistent
+ * session: afterwards nothing of the batch is running on the device (a device-wide hipDeviceSynchronize would
+ * otherwise wait for the resident launch to expire). */
 NAM_HIP_API int nam_hip_batch_synchronize(nam_hip_batch* batch);
 
 /* Choose the kernel (NAM_HIP_KERNEL_*); AUTO picks the fastest kernel the model allows

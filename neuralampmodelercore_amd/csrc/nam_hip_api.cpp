@@ -531,7 +531,11 @@ int persist_wait(nam_hip_batch* b, bool need_exit)
       all = need_exit ? exited : ((v & 0x7fffffffu) >= ps.seq);
     }
     if (expired)
+    {
+      (void)hipStreamSynchronize(ps.kstream);
+      ps.active = false;
       return fail(NAM_HIP_ERR_DEVICE, "persistent session expired before consuming every submitted buffer");
+    }
     if (all)
       return NAM_HIP_OK;
     if ((it & 1023) == 1023
@@ -610,6 +614,16 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   PersistSession& ps = b->ps;
   if (n_frames != kBlock)
     return 1;
+  if (ps.active && (__atomic_load_n(&ps.h_words[ps.n_wg], __ATOMIC_ACQUIRE) & 0x80000000u))
+  {
+    // the resident launch has left by itself (not fed for ~2 s, e.g. behind a device-wide synchronisation): every
+    // command it was given has been consumed (persist_wait reports the other case), so a new session simply starts
+    const int rw = persist_wait(b, true);
+    if (rw != NAM_HIP_OK)
+      return rw;
+    NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
+    ps.active = false;
+  }
   if (ps.active)
   {
     const long off_in = d_in - ps.in_base, off_out = d_out - ps.out_base;
@@ -1176,9 +1190,9 @@ int nam_hip_batch_synchronize(nam_hip_batch* batch)
   if (!batch)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_synchronize: null batch");
   NAM_HIP_CHECK(hipSetDevice(batch->device));
-  NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
-  if (batch->ps.active)
-    return persist_wait(batch, false);
+  // "nothing of this batch is running on the device any more": a persistent session ends here (its resident launch
+  // would otherwise keep a device-wide hipDeviceSynchronize waiting until it expires)
+  NAM_HIP_CHECK(quiesce(batch));
   return NAM_HIP_OK;
 }
 
