@@ -283,10 +283,11 @@ class HipEngine:
 
     def sync(self):
         if self.persistent:
-            # the contract's device-wide synchronize needs the resident launch gone: wait for the submitted buffers, then
-            # end the session (the next step starts a new one — inside the timed region, where it belongs)
+            # every submitted buffer consumed and visible; the session's launch leaves by itself once the ring is empty,
+            # so the contract's device-wide synchronize below does not block on it (the next step's doorbell starts a
+            # launch again — inside the timed region, where it belongs)
             self.batch.flush(self.stream.cuda_stream)
-            self.batch.synchronize()
+            self.t_flushed = time.perf_counter()
         self.torch.cuda.synchronize(self.dev)
 
     def kernel_name(self):
@@ -341,7 +342,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--reps", type=int, default=11, help="timed regions of exactly --steps steps; value = the median region")
+    ap.add_argument("--reps", type=int, default=None,
+                    help="timed regions of exactly --steps steps, each behind its own --warmup untimed steps; value = the "
+                         "median region. Default: 11, more for short regions (about 30 ms of timed work, at most 101)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (see the module docstring)")
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (weak scaling); default from --config")
     ap.add_argument("--block", type=int, default=64)
@@ -394,7 +397,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     model_path = os.path.join(ROOT, "tests", "golden", "models", model_name + ".nam")
-    block, K, W, R = args.block, args.steps, args.warmup, max(1, args.reps)
+    block, K, W = args.block, args.steps, args.warmup
+    # repetitions: an odd count; short regions (the driver's --steps 20 is 0.3 ms) get more of them
+    R = max(1, args.reps) if args.reps is not None else min(101, max(11, int(30e-3 / max(K * 15e-6, 1e-9)) | 1))
     T = (W + K) * block
 
     # ---- one-time weight broadcast: rank 0 reads the file, the text travels once over RCCL ----
@@ -442,41 +447,58 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t]
 
+    scratch = None
     if args.dry_run:
         engine = StubEngine(torch, block)
     else:
-        if args.spinup_ms > 0:  # clocks up, on a scratch batch whose state is thrown away
-            scratch = HipEngine(nam, torch, model, n_local, block, local_rank, args.kernel, local_classes)  # (launch per step)
-            scratch.bind(x, y)
-            t_end = time.perf_counter() + args.spinup_ms / 1e3
-            while time.perf_counter() < t_end:
-                scratch.run_steps(0, min(W + K, 64), "block")
-                scratch.sync()
-            scratch.close()
-            y.zero_()
+        if args.spinup_ms > 0:  # (launch per step / resident launches; never the persistent mode)
+            scratch = HipEngine(nam, torch, model, n_local, block, local_rank, args.kernel, local_classes)
         engine = HipEngine(nam, torch, model, n_local, block, local_rank, args.kernel, local_classes,
                            persistent=bool(args.persistent) and args.launch == "block")
     engine.bind(x, y)
+    if not args.dry_run and scratch is not None:
+        # Spin-up, right in front of the repetitions: continuous untimed GPU work on a SCRATCH batch (the measured batch's
+        # state is not touched; the output window is zeroed again afterwards). The device takes tens of milliseconds of
+        # load to reach its sustained clocks, and the driver-shaped run (--steps 20 --warmup 5: 0.3 ms per repetition)
+        # would otherwise be measured entirely inside that ramp (tools/persist_region_probe.py: the same 20-step region
+        # 246 us at the start of a process, 226 us 20 ms later).
+        scratch.bind(x, y)
+        t_end = time.perf_counter() + args.spinup_ms / 1e3
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                scratch.run_steps(0, min(W + K, 64), "resident")
+            scratch.sync()
+        y.zero_()
+        engine.sync()
 
-    # ---- W warm-up steps, then R timed regions of exactly K steps (the window W..W+K is re-read, state runs on) ----
-    engine.run_steps(0, W, args.launch)
-    regions = []
+    # ---- R times: W untimed warm-up steps, then a timed region of exactly K steps between barrier + synchronize pairs
+    # (warm-up walks blocks 0..W of the window, the region blocks W..W+K; the streams' state runs on across repetitions).
+    # All bookkeeping (max over ranks) happens after the last repetition, so that nothing but the fence sits between a
+    # repetition's warm-up and its timed steps.
+    raw = []
     got_dev = None
     n_chk = min(T, 64 * 40)
+    pers = getattr(engine, "persistent", False)
     for rep in range(R):
+        engine.run_steps(0, W, args.launch)
         fence(engine)
         t0 = time.perf_counter()
-        e0 = engine.event()
+        e0 = None if pers else engine.event()
         engine.run_steps(W, K, args.launch)
         t_enq = time.perf_counter() - t0
-        e1 = engine.event()
+        e1 = None if pers else engine.event()
         fence(engine)
         wall = time.perf_counter() - t0
-        gpu_s = wall if getattr(engine, "persistent", False) else engine.elapsed_ms(e0, e1) / 1e3
-        wall_max, gpu_s_max = reduce_max([wall, gpu_s])
-        regions.append({"wall_s": wall_max, "gpu_s": gpu_s_max, "enqueue_s": t_enq})
+        # the K steps' own time: HIP events on the launch stream around the K launches — or, in persistent block mode
+        # (the work runs on the session's stream, not between two events of the caller's), the host clock from before
+        # the first command until the host has seen every workgroup publish the last buffer (launch latency included)
+        gpu_s = (engine.t_flushed - t0) if pers else engine.elapsed_ms(e0, e1) / 1e3
+        raw.append((wall, gpu_s, t_enq))
         if rep == 0:
             got_dev = y[0, 0, :n_chk].clone()  # parity sample: blocks 0..W+K of the FIRST pass over the window
+    red = reduce_max([v for r_ in raw for v in r_[:2]])
+    regions = [{"wall_s": red[2 * i], "gpu_s": red[2 * i + 1], "enqueue_s": raw[i][2],
+                "flushed_s": raw[i][1] if pers else None} for i in range(R)]
     order = sorted(range(R), key=lambda i: regions[i]["wall_s"])
     med = regions[order[R // 2]]
     wall_med, gpu_s_med = med["wall_s"], med["gpu_s"]
@@ -516,6 +538,7 @@ def main():
             for s in range(n_lat):
                 engine.run_steps(W + s, 1, "block")
                 evs.append(engine.event())
+            fence_local()
             d = sorted(engine.elapsed_ms(evs[i], evs[i + 1]) * 1e3 for i in range(n_lat))
             note = "us between consecutive HIP events on the launch stream, one launch per step (event overhead included)"
         fence_local()
@@ -620,6 +643,9 @@ def main():
                             "ms_per_step_min": round(regions[order[0]]["wall_s"] * 1e3 / K, 6),
                             "ms_per_step_max": round(regions[order[-1]]["wall_s"] * 1e3 / K, 6)},
             "host_enqueue_us_per_step": round(med["enqueue_s"] / K * 1e6, 2),
+            "region_us": {"enqueued": round(med["enqueue_s"] * 1e6, 1),
+                          "results_visible_to_host": None if med["flushed_s"] is None else round(med["flushed_s"] * 1e6, 1),
+                          "after_device_synchronize": round(med["wall_s"] * 1e6, 1)},
             # The WaveNet path is bound by history traffic through HBM / Infinity Cache (the per-stream state cannot stay
             # in LDS): e.g. a1_standard 8 TB/s / 3,848 B / 48 kHz = 43 k xRT, below its fp32 ceiling of 123 k xRT.
             "roofline": {
@@ -653,6 +679,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model_path, bool(args.fast_tanh), block)
         print(json.dumps(out), flush=True)
     engine.close()
+    if scratch is not None:
+        scratch.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -20,13 +20,15 @@ namespace namhip
 // Same state layout, rings and write positions as every other A1 kernel; same numerics (the MFMAs and the
 // activation code are the same, only the control flow is resolved by the compiler).
 // ================================================================================================
-// PERSIST (block mode without kernel boundaries): the launch stays resident and consumes COMMANDS — one per 64-frame
-// buffer, `(seq << 32) | frame offset` written into a device-memory ring by hipStreamWriteValue64 on the caller's
-// stream (nam_hip_api.cpp: persistent session). Wave 0 fetches command k + 1 while block k is still computing and
-// the workgroup agrees on it at the end of the block (one extra barrier); with the ring empty the workgroup
-// publishes its progress behind a system-scope release fence, then polls (bounded: a session that is never fed
-// expires by itself). What a launch per buffer costs on top of the jobs — dispatch, kernarg and write-position
-// round trips, weights into LDS, the write-through drain — is paid once per session instead of once per buffer.
+// PERSIST (block mode without a kernel boundary per buffer): the launch consumes COMMANDS — one per 64-frame buffer,
+// `(seq << 32) | frame offset`, written into a device-memory ring by hipStreamWriteValue64 on the caller's stream
+// (nam_hip_api.cpp: persistent session) — for as long as the next one is already there. Wave 0 looks at command k + 1
+// while block k is still computing and the workgroup agrees on it at the end of the block (one extra barrier). With
+// the ring empty the workgroup makes its results visible (system-scope release), publishes how many commands it has
+// consumed and LEAVES: it never waits, so nothing can hang and a device-wide synchronise simply returns when the
+// buffers rung so far are done; the host starts the next launch with the next doorbell. While doorbells arrive faster
+// than blocks are computed (3-6 us vs 10 us) a whole run of buffers is one launch: dispatch, kernarg and
+// write-position round trips, weights into LDS and the write-through drain are paid once per run, not per buffer.
 template <int C0, int C1, int ACT_T, bool WT, bool PERSIST>
 __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict__ blob, const A1Args a)
 {
@@ -127,53 +129,76 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
   // two commands (the blocking host path copies every buffer into one staging area), and without a kernel boundary
   // nothing invalidates the line this CU read a buffer ago.
   constexpr int kInAux = PERSIST ? 17 : 0;
-  unsigned seq = a.p_first_seq; // commands consumed so far
+  unsigned seq = 0; // commands consumed so far
   unsigned boff = 0; // byte offset of the current block's frames in the stream's row (non-persistent: blk * 256)
   int* const cmd_lds = reinterpret_cast<int*>(lds_p2) + p2::kFlagB / 4; // [0..1] = command agreed on by the workgroup
-  constexpr unsigned kExit = 0xffffffffu;
   auto ring_load = [&](unsigned s_) {
     return __hip_atomic_load(a.p_ring + (s_ & (unsigned)a.p_ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
   // wave 0 waits (bounded) for command `want`; returns its low word, or kExit on EXIT / expiry
-  auto wait_cmd = [&](unsigned want) {
-    unsigned lo = kExit;
-    const unsigned long long t0 = wall_clock64();
-    for (;;)
+  // the workgroup leaves: results visible, then its consumed-command count (device copy for the next launch of this
+  // workgroup, host copy for the host), exited bit set
+  // (The session's output samples are stored write-through at system scope, so "every store of this wave has been
+  // acknowledged" is all the count has to wait for: a release fence here would first write back the L2's dirty
+  // history rows — megabytes that only the next launch needs, and the end of this one takes care of those.)
+  auto leave = [&](bool fence) {
+    if (fence)
     {
-      const unsigned long long v = ring_load(want - 1);
-      if ((unsigned)(v >> 32) == want)
-      {
-        lo = (unsigned)v;
-        break;
-      }
-      if (wall_clock64() - t0 > 200000000ull) // ~2 s at 100 MHz: nobody feeds this session any more
-        break;
-      __builtin_amdgcn_s_sleep(16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
     }
-    return lo;
+    if (w == 0 && lane == 0)
+    {
+      a.p_cons[blockIdx.x] = seq;
+      __hip_atomic_store(a.p_done + blockIdx.x, seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   };
+  // every ring request of the first block (they depend on the state only, not on the command)
+  il::for_each_index(prologue, std::make_integer_sequence<int, NJ>{});
   if constexpr (PERSIST)
   {
-    unsigned lo = 0;
-    if (w == 0)
+    // commands this workgroup has consumed in earlier launches of the session — by value when the host knows that
+    // every workgroup stands at the same count (p_seq0 >= 0), and then the first command comes by value as well
+    const bool by_value = a.p_seq0 >= 0;
+    seq = by_value ? (unsigned)a.p_seq0 : a.p_cons[blockIdx.x];
+    bool ready = true;
+    unsigned lo = (unsigned)a.p_cmd0;
+    if (!by_value)
     {
-      lo = wait_cmd(seq + 1);
-      if (lane == 0)
-        cmd_lds[0] = (int)lo;
+      if (w == 0)
+      {
+        // The host starts this launch right behind the doorbell it rang, on another hardware queue: the doorbell may
+        // land a few microseconds after the launch. Wave 0 looks for it for a bounded time (a.p_grace ticks of the
+        // 100 MHz clock; never unbounded: a device-wide synchronize must not depend on a doorbell being delivered).
+        unsigned long long v = ring_load(seq);
+        if (a.p_grace > 0 && (unsigned)(v >> 32) != seq + 1)
+        {
+          const long long t_end = (long long)wall_clock64() + a.p_grace;
+          do
+          {
+            __builtin_amdgcn_s_sleep(8);
+            v = ring_load(seq);
+          } while ((unsigned)(v >> 32) != seq + 1 && (long long)wall_clock64() < t_end);
+        }
+        if (lane == 0)
+        {
+          cmd_lds[0] = (int)(unsigned)v;
+          cmd_lds[1] = (unsigned)(v >> 32) == seq + 1 ? 1 : 0;
+        }
+      }
+      lds_barrier();
+      ready = uni(cmd_lds[1]) != 0;
+      lo = (unsigned)uni(cmd_lds[0]);
+      lds_barrier();
     }
-    lds_barrier();
-    lo = (unsigned)uni(cmd_lds[0]);
-    if (lo == kExit)
+    if (!ready)
     {
-      // nothing consumed, state untouched; still tell the host that this workgroup has left
-      if (w == 0 && lane == 0)
-        __hip_atomic_store(a.p_done + blockIdx.x, seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      leave(false); // nothing to do (the doorbell this launch was started for has been consumed by its predecessor)
       return;
     }
     boff = lo * 4u;
   }
   inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), kInAux));
-  il::for_each_index(prologue, std::make_integer_sequence<int, NJ>{});
   // the weights (requested before the ring rows, so they are here first)
 #pragma unroll
   for (int i = 0; i < kT4; i++)
@@ -254,12 +279,26 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     }
     // the same job of the NEXT block: its requests go into the slot just consumed
     fetch(sa[JI], sb[JI], j_tag, std::integral_constant<int, 1>{}, PERSIST || blk + 1 < n_blocks, tl, gl16);
-    if constexpr (PERSIST && JI == 8)
-      spec_cmd = ring_load(seq + 1); // command of the NEXT block, looked at in job 12 (speculative, per wave)
+    // Persistent session, the NEXT block's command (steady state: no barrier and no exposed load of its own):
+    // every wave looks at the ring in job 4; in job 9 wave 0 publishes what it saw in LDS; the exchange barriers of jobs
+    // 10 / 11 make that the whole workgroup's view, read back in job 12 — where the next block's input sample is
+    // requested from the offset everybody agreed on. (cmd_lds[0..1] is rewritten in job 9 of the next block, behind
+    // the barriers of its jobs 0 / 1.)
+    if constexpr (PERSIST && JI == 4)
+      spec_cmd = ring_load(seq + 1);
+    if constexpr (PERSIST && JI == 9)
+    {
+      const bool hit = (unsigned)(spec_cmd >> 32) == seq + 2;
+      if (w == 0 && lane == 0)
+      {
+        cmd_lds[0] = hit ? (int)(unsigned)spec_cmd : 0;
+        cmd_lds[1] = hit ? 1 : 0;
+      }
+    }
     if constexpr (PERSIST && JI == 12)
     {
-      spec_ok = (unsigned)(spec_cmd >> 32) == seq + 2 && (unsigned)spec_cmd != kExit;
-      spec_off = spec_ok ? (unsigned)spec_cmd * 4u : 0u;
+      spec_ok = uni(cmd_lds[1]) != 0;
+      spec_off = (unsigned)uni(cmd_lds[0]) * 4u;
       inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, tl * 4, uni((int)spec_off), kInAux));
     }
     auto slice = [&](const f4& r) { return NK == 4 ? r : (hi_pair ? f4{r[2], r[3], 0.f, 0.f} : f4{r[0], r[1], 0.f, 0.f}); };
@@ -332,7 +371,7 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
       const float yout = head_scale * (mfma_n<NK>(xt, head, f4{0.f, 0.f, 0.f, 0.f}) + ev)[0];
       const bool ok = gl16 == 0 && tl < nvalid;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob,
-                                            uni((int)boff), 0);
+                                            uni((int)boff), PERSIST ? 17 : 0);
     }
     else if constexpr ((flags & CD_POST_RECH) != 0)
       x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
@@ -354,57 +393,39 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     else
     {
       seq++;
-      // the workgroup agrees on the next command: wave 0's view (it may differ from another wave's early look)
-      if (w == 0)
+      if (w == 0 && lane == 0 && (seq & 15u) == 0u) // progress for the host's ring bookkeeping (no fence: not a completion signal)
+        __hip_atomic_store(a.p_prog + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (spec_ok) // (the same for every wave: read from LDS behind a barrier)
+        boff = spec_off;
+      else
       {
-        const unsigned long long v = ring_load(seq);
-        const bool ready = (unsigned)(v >> 32) == seq + 1;
-        if (lane == 0)
-        {
-          cmd_lds[0] = ready ? (int)(unsigned)v : 0;
-          cmd_lds[1] = ready ? 1 : 0;
-          if ((seq & 15u) == 0u) // progress for the host's ring bookkeeping (not a completion signal: no fence)
-            __hip_atomic_store(a.p_prog + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-      lds_barrier();
-      unsigned lo = (unsigned)uni(cmd_lds[0]);
-      bool ready = uni(cmd_lds[1]) != 0;
-      if (!ready)
-      {
-        // ring empty: everything this workgroup has written becomes visible, THEN its completion count; then wait
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        lds_barrier();
+        // the command was not there at job 4: look once more — wave 0's view, agreed on through LDS (words 2, 3:
+        // another wave may still be on its way to reading words 0, 1 in job 12)
         if (w == 0)
         {
+          const unsigned long long v = ring_load(seq);
+          const bool ready = (unsigned)(v >> 32) == seq + 1;
           if (lane == 0)
-            __hip_atomic_store(a.p_done + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          lo = wait_cmd(seq + 1);
-          if (lane == 0)
-            cmd_lds[0] = (int)lo;
+          {
+            cmd_lds[2] = ready ? (int)(unsigned)v : 0;
+            cmd_lds[3] = ready ? 1 : 0;
+          }
         }
         lds_barrier();
-        lo = (unsigned)uni(cmd_lds[0]);
-        ready = lo != kExit;
-      }
-      lds_barrier(); // (cmd_lds is rewritten at the end of the next block; the exchange windows are untouched)
-      if (!ready || lo == kExit)
-        break;
-      boff = lo * 4u;
-      if (!(spec_ok && spec_off == boff)) // the early look missed: request the input sample now (exposed)
+        const unsigned lo = (unsigned)uni(cmd_lds[2]);
+        const bool ready = uni(cmd_lds[3]) != 0;
+        lds_barrier();
+        if (!ready)
+          break; // ring empty: leave (below)
+        boff = lo * 4u;
         inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, t * 4, uni((int)boff), kInAux));
+      }
     }
   }
   if (w == 0 && lane < NJ)
     wpos_tbl[lane] = wposv;
   if constexpr (PERSIST)
-  {
-    // session end (EXIT command or expiry): state and outputs visible, then the final count with the EXITED bit
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    lds_barrier();
-    if (w == 0 && lane == 0)
-      __hip_atomic_store(a.p_done + blockIdx.x, seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+    leave(true);
 }
 
 namespace
@@ -427,7 +448,9 @@ hipError_t launch_p2_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 template <int C0, int C1>
 hipError_t launch_p2_shape(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
-  if (a.p_ring) // persistent session (plain write-back stores: there is no kernel boundary to drain for)
+  // persistent session: plain write-back ring appends (written through, the rows a block appends would be read back
+  // from memory instead of the L2 one block later: 27 us per block instead of 10.5, measured)
+  if (a.p_ring)
   {
     if (act == ACT_FASTTANH)
       return launch_p2_inst<C0, C1, ACT_FASTTANH, false, true>(a, n_blocks, stream);

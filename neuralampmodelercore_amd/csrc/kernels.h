@@ -60,9 +60,12 @@ struct A1Args
   // commands consumed before this launch, per-workgroup progress / completion words in host-mapped memory
   unsigned long long* p_ring;
   int p_ring_mask;
-  unsigned p_first_seq;
-  unsigned* p_prog;
+  unsigned* p_cons; // device memory: commands consumed per workgroup (where its next launch resumes)
+  unsigned* p_prog; // host-mapped: progress (every 16 commands), completion count | exited bit
   unsigned* p_done;
+  long long p_seq0; // >= 0: every workgroup has consumed exactly this many commands (p_cons is not read) ...
+  unsigned long long p_cmd0; // ... and this is the next command (the ring is not read for it)
+  int p_grace; // ticks (100 MHz) a fresh launch looks for its first doorbell before it leaves again
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 

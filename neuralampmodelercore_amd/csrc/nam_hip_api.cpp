@@ -113,10 +113,24 @@ constexpr unsigned kPRing = 1024; // commands in flight at most (power of two)
 struct PersistSession
 {
   bool enabled = false; // the caller opted in
-  bool active = false; // a resident launch is consuming commands
-  unsigned long long* d_ring = nullptr; // device memory: (seq << 32) | frame offset
+  bool active = false; // a window is registered; a launch of the session may be consuming commands
+  // the command ring: (seq << 32) | frame offset, in FINE-GRAINED device memory — local to the workgroups that poll
+  // it, and host-writable through the PCIe BAR (MI355X exposes all of HBM): the host stores a command itself when the
+  // caller's stream is idle (the usual real-time case: nothing to order behind; a posted write, ~0.1 us), else the
+  // store is enqueued on that stream (hipStreamWriteValue64: ~4 us of host time and a small kernel on the device)
+  unsigned long long* d_ring = nullptr;
+  bool host_store_ok = false; // the ring is fine-grained memory (else plain device memory: stream-ordered stores only)
   unsigned* h_words = nullptr; // host-mapped: [0, n_wg) progress, [n_wg, 2 n_wg) completion (bit 31 = exited)
   unsigned* d_words = nullptr; // the same words as the device sees them
+  unsigned* d_cons = nullptr; // device memory: commands consumed per workgroup (where its next launch resumes)
+  hipStream_t last_caller = nullptr; // the stream the last doorbell was rung on
+  int grace = 0; // A1Args::p_grace of the next launch
+  long long seq0 = -1; // A1Args::p_seq0 / p_cmd0 of the next launch
+  unsigned long long cmd0 = 0;
+  unsigned flushed = 0; // every workgroup has consumed exactly this many commands (valid while == seq)
+  bool flushed_valid = false;
+  bool outstanding = false; // a launch of the session may still be running
+  bool need_order = false; // the next launch must wait for the batch's own stream (session start)
   hipStream_t kstream = nullptr; // the resident launch's own stream (nothing else may be enqueued behind it)
   hipEvent_t order = nullptr; // makes the launch wait for what the caller had enqueued before the first buffer
   unsigned seq = 0; // commands submitted in this session
@@ -328,8 +342,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.il_consts_b = a.il_xt_b = a.il_tiles_b = a.il_flag_b = a.il_lds_bytes = a.act = 0;
       a.p_ring = nullptr;
       a.p_ring_mask = 0;
-      a.p_first_seq = 0;
-      a.p_prog = a.p_done = nullptr;
+      a.p_cons = a.p_prog = a.p_done = nullptr;
+      a.p_grace = 0;
+      a.p_seq0 = -1;
+      a.p_cmd0 = 0;
       if (kernel == NAM_HIP_KERNEL_A1_IL)
       {
         int act = p.a1.arr[0].act;
@@ -354,9 +370,12 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
         {
           a.p_ring = b->ps.d_ring;
           a.p_ring_mask = (int)kPRing - 1;
-          a.p_first_seq = 0;
+          a.p_cons = b->ps.d_cons;
           a.p_prog = b->ps.d_words;
           a.p_done = b->ps.d_words + n;
+          a.p_grace = b->ps.grace;
+          a.p_seq0 = b->ps.seq0;
+          a.p_cmd0 = b->ps.cmd0;
         }
         if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
           NAM_HIP_CHECK(launch_a1_p2(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
@@ -503,6 +522,7 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
 }
 
 // ---- persistent block mode -------------------------------------------------------------------------------------
+constexpr int kGraceUs = 40; // how long a fresh launch looks for the doorbell it was started for
 bool persist_eligible(const nam_hip_batch* b)
 {
   const WidthGroup& g = b->groups[b->model->full_width];
@@ -511,36 +531,82 @@ bool persist_eligible(const nam_hip_batch* b)
          && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL);
 }
 
-// Waits (host side) until every workgroup of the session has consumed all submitted commands and made its results
-// visible; `need_exit`: until it has left the kernel.
-int persist_wait(nam_hip_batch* b, bool need_exit)
+// (Re)starts the session's launch: every workgroup resumes behind the commands it has consumed so far and runs until
+// it finds the ring empty. `grace_us`: how long the launch looks for its first doorbell (rung just before, on the
+// caller's hardware queue, so it may land after the launch has started).
+int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned long long cmd0 = 0)
 {
   PersistSession& ps = b->ps;
-  const unsigned* done = ps.h_words + ps.n_wg;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (long it = 0;; it++)
+  WidthGroup& g = b->groups[b->model->full_width];
+  if (ps.need_order)
   {
-    bool all = true;
-    bool expired = false;
-    for (int w = 0; w < ps.n_wg && all; w++)
+    // the first launch of the session starts behind whatever the batch's own stream still has in flight (a reset, a
+    // prewarm, an ordinary launch)
+    NAM_HIP_CHECK(hipEventRecord(ps.order, b->stream));
+    NAM_HIP_CHECK(hipStreamWaitEvent(ps.kstream, ps.order, 0));
+    ps.need_order = false;
+  }
+  ps.grace = grace_us * 100;
+  ps.seq0 = seq0;
+  ps.cmd0 = cmd0;
+  // the workgroups set the top bit of their completion word when they leave: cleared here, "all set" = no launch of
+  // the session is running any more (cheaper for the host to look at than hipStreamQuery on a busy stream)
+  for (int w = 0; w < ps.n_wg; w++)
+    __atomic_and_fetch(&ps.h_words[ps.n_wg + w], 0x7fffffffu, __ATOMIC_RELAXED);
+  ps.outstanding = true;
+  const int keep = b->kernel;
+  b->kernel = NAM_HIP_KERNEL_A1_IL;
+  b->ps_launching = true;
+  const int rc = launch_group(b, g, nullptr, ps.n_wg, ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream);
+  b->ps_launching = false;
+  b->kernel = keep;
+  return rc;
+}
+
+// Blocks until every submitted command has been consumed by every workgroup and its results are visible.
+// `caller`: the stream the doorbells were rung on.
+int persist_flush(nam_hip_batch* b, hipStream_t caller)
+{
+  PersistSession& ps = b->ps;
+  if (!ps.active)
+    return NAM_HIP_OK;
+  // The workgroups publish their count (behind a release fence behind their last results) when they LEAVE — which
+  // they do as soon as they find the ring empty. The host watches those words rather than the launch's completion
+  // signal, which takes an interrupt round trip longer.
+  bool delivered = false;
+  int relaunches = 0;
+  for (;;)
+  {
+    unsigned lo = ~0u, all_left = 0x80000000u;
+    for (int w = 0; w < ps.n_wg; w++)
     {
-      const unsigned v = __atomic_load_n(&done[w], __ATOMIC_ACQUIRE);
-      const bool exited = (v & 0x80000000u) != 0;
-      if (exited && (v & 0x7fffffffu) < ps.seq)
-        expired = true; // the session expired (it was not fed for ~2 s) before consuming everything
-      all = need_exit ? exited : ((v & 0x7fffffffu) >= ps.seq);
+      const unsigned v = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_ACQUIRE);
+      lo = std::min(lo, v & 0x7fffffffu);
+      all_left &= v;
     }
-    if (expired)
+    if (ps.outstanding && !all_left)
+      continue; // the launch is still consuming
+    ps.outstanding = false;
+    if ((int)(lo - ps.seq) >= 0)
     {
-      (void)hipStreamSynchronize(ps.kstream);
-      ps.active = false;
-      return fail(NAM_HIP_ERR_DEVICE, "persistent session expired before consuming every submitted buffer");
-    }
-    if (all)
+      ps.flushed = ps.seq;
+      ps.flushed_valid = true;
       return NAM_HIP_OK;
-    if ((it & 1023) == 1023
-        && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
-      return fail(NAM_HIP_ERR_DEVICE, "persistent session did not respond within 10 s");
+    }
+    // no launch running, buffers outstanding: either the commands have not all been delivered yet or a workgroup
+    // left just before one landed. Make sure of the former, then run the launch again (it resumes where each stopped).
+    if (!delivered)
+    {
+      NAM_HIP_CHECK(hipStreamSynchronize(caller ? caller : b->stream));
+      if (ps.last_caller && ps.last_caller != caller)
+        NAM_HIP_CHECK(hipStreamSynchronize(ps.last_caller));
+      delivered = true;
+    }
+    if (++relaunches > 64)
+      return fail(NAM_HIP_ERR_DEVICE, "persistent session: submitted buffers were not consumed");
+    const int rc = persist_launch(b, 0);
+    if (rc != NAM_HIP_OK)
+      return rc;
   }
 }
 
@@ -549,81 +615,59 @@ int persist_stop(nam_hip_batch* b)
   PersistSession& ps = b->ps;
   if (!ps.active)
     return NAM_HIP_OK;
-  // EXIT is just the next command (slots are claimed by sequence number, so it cannot overtake a buffer)
-  NAM_HIP_CHECK(hipStreamWriteValue64(b->stream, ps.d_ring + (ps.seq & (kPRing - 1)),
-                                      ((unsigned long long)(ps.seq + 1) << 32) | 0xffffffffull, 0));
-  const hipError_t e = hipStreamSynchronize(ps.kstream); // (bounded: an unfed session expires by itself)
+  const int rc = persist_flush(b, ps.last_caller ? ps.last_caller : b->stream);
+  NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream)); // the state is the caller's again only when the launch has gone
   ps.active = false;
-  NAM_HIP_CHECK(e);
-  NAM_HIP_CHECK(hipStreamSynchronize(b->stream));
-  return NAM_HIP_OK;
+  return rc;
 }
 
-int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride, hipStream_t caller)
+int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride)
 {
   PersistSession& ps = b->ps;
   WidthGroup& g = b->groups[b->model->full_width];
   const int n = (int)g.streams.size();
   if (!ps.d_ring)
   {
-    NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long)));
+    ps.host_store_ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long),
+                                             hipDeviceMallocFinegrained) == hipSuccess;
+    if (!ps.host_store_ok)
+    {
+      (void)hipGetLastError();
+      NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long)));
+    }
+    NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_cons), (size_t)b->n_streams * sizeof(unsigned)));
     NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_words), 2 * (size_t)b->n_streams * sizeof(unsigned),
                                 hipHostMallocMapped | hipHostMallocCoherent));
     NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_words), ps.h_words, 0));
-    // Its own hardware queue: HIP multiplexes streams of one priority onto a few hardware queues, and a doorbell
-    // enqueued on a stream that shares the resident launch's queue would wait behind it for ever. Streams of the
-    // highest priority get a queue of their own.
+    // A stream of the highest priority has a hardware queue of its own: HIP multiplexes streams of one priority onto
+    // a few hardware queues, and a doorbell enqueued behind the session's launch on a shared queue would only be
+    // rung after the launch has left.
     int prio_lo = 0, prio_hi = 0;
     NAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     NAM_HIP_CHECK(hipStreamCreateWithPriority(&ps.kstream, hipStreamNonBlocking, prio_hi));
     NAM_HIP_CHECK(hipEventCreateWithFlags(&ps.order, hipEventDisableTiming));
+    NAM_HIP_CHECK(hipMemset(ps.d_ring, 0, kPRing * sizeof(unsigned long long)));
+    NAM_HIP_CHECK(hipDeviceSynchronize());
+    NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
+    std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
+    ps.seq = 0; // (sequence numbers run on across sessions: no ring slot ever needs clearing)
   }
-  // (the ring is clean before the first doorbell can be rung: a doorbell travels on another stream)
-  NAM_HIP_CHECK(hipMemsetAsync(ps.d_ring, 0, kPRing * sizeof(unsigned long long), ps.kstream));
-  NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
-  std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
-  ps.seq = 0;
   ps.in_base = d_in;
   ps.out_base = d_out;
   ps.stride = stride;
   ps.n_wg = n;
-  // the resident launch starts behind whatever the caller (and the batch's own stream) had enqueued so far
-  NAM_HIP_CHECK(hipEventRecord(ps.order, caller));
-  NAM_HIP_CHECK(hipStreamWaitEvent(ps.kstream, ps.order, 0));
-  if (caller != b->stream)
-  {
-    NAM_HIP_CHECK(hipEventRecord(ps.order, b->stream));
-    NAM_HIP_CHECK(hipStreamWaitEvent(ps.kstream, ps.order, 0));
-  }
-  const int keep = b->kernel;
-  b->kernel = NAM_HIP_KERNEL_A1_IL;
-  b->ps_launching = true;
-  const int rc = launch_group(b, g, nullptr, n, d_in, d_out, kBlock, stride, ps.kstream);
-  b->ps_launching = false;
-  b->kernel = keep;
-  if (rc != NAM_HIP_OK)
-    return rc;
   ps.active = true;
+  ps.need_order = true;
   return NAM_HIP_OK;
 }
 
-// One 64-frame buffer for every stream of the batch through the resident launch. Falls back (returns 1) when this call
-// cannot be expressed as a command of the session.
+// One 64-frame buffer for every stream of the batch through the session. Returns 1 when this call cannot be expressed
+// as a command of a session (the caller then launches as usual).
 int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_frames, long stride, hipStream_t caller)
 {
   PersistSession& ps = b->ps;
   if (n_frames != kBlock)
     return 1;
-  if (ps.active && (__atomic_load_n(&ps.h_words[ps.n_wg], __ATOMIC_ACQUIRE) & 0x80000000u))
-  {
-    // the resident launch has left by itself (not fed for ~2 s, e.g. behind a device-wide synchronisation): every
-    // command it was given has been consumed (persist_wait reports the other case), so a new session simply starts
-    const int rw = persist_wait(b, true);
-    if (rw != NAM_HIP_OK)
-      return rw;
-    NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
-    ps.active = false;
-  }
   if (ps.active)
   {
     const long off_in = d_in - ps.in_base, off_out = d_out - ps.out_base;
@@ -636,32 +680,87 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   }
   if (!ps.active)
   {
-    const int rc = persist_start(b, d_in, d_out, stride, caller);
+    const int rc = persist_start(b, d_in, d_out, stride);
     if (rc != NAM_HIP_OK)
       return rc;
   }
-  // never lap the kernel by a whole ring: the workgroups report their progress every 16 commands
-  if (ps.seq >= kPRing / 2 && (ps.seq & 63u) == 0u)
+  // never lap a workgroup by a whole ring (they report their progress every 16 commands and when they leave): the
+  // host waits here for the slowest one to move on — back-pressure, at the pace the device consumes
+  if ((ps.seq & 63u) == 0u)
   {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (long it = 0;; it++)
+    for (long spin = 0;; spin++)
     {
-      unsigned lo = ~0u;
+      unsigned lo = ~0u, all_left = 0x80000000u;
       for (int w = 0; w < ps.n_wg; w++)
       {
-        const unsigned pv = __atomic_load_n(&ps.h_words[w], __ATOMIC_RELAXED);
-        const unsigned dv = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_RELAXED) & 0x7fffffffu;
-        lo = std::min(lo, std::max(pv, dv));
+        const unsigned d = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_RELAXED);
+        lo = std::min(lo, std::max(__atomic_load_n(&ps.h_words[w], __ATOMIC_RELAXED), d & 0x7fffffffu));
+        all_left &= d;
       }
       if (ps.seq - lo < kPRing - 128)
         break;
-      if ((it & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
-        return fail(NAM_HIP_ERR_DEVICE, "persistent session stalled (command ring full for 10 s)");
+      if (!ps.outstanding || all_left) // nothing is consuming (a launch left early): the flush starts it again
+      {
+        const int rc = persist_flush(b, caller);
+        if (rc != NAM_HIP_OK)
+          return rc;
+      }
+      else if (spin > (1l << 26))
+        return fail(NAM_HIP_ERR_DEVICE, "persistent session stalled (command ring full)");
     }
   }
+  // Is a launch of the session needed? None running (none yet, or the last one found the ring empty and left: every
+  // workgroup has set the top bit of its completion word). A launch that is still running picks the command up
+  // itself, or leaves just before it lands, in which case the next call (or the flush) starts it again.
+  bool idle = !ps.outstanding;
+  bool uniform = idle && ps.flushed_valid && ps.flushed == ps.seq; // every workgroup has consumed exactly seq commands
+  if (!idle)
+  {
+    const unsigned left = ps.seq | 0x80000000u;
+    idle = uniform = true;
+    for (int w = 0; w < ps.n_wg && idle; w++)
+    {
+      const unsigned v = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_ACQUIRE);
+      idle = (v & 0x80000000u) != 0;
+      uniform = uniform && v == left;
+    }
+    uniform = uniform && idle;
+    if (idle)
+      ps.outstanding = false;
+  }
   const unsigned long long cmd = ((unsigned long long)(ps.seq + 1) << 32) | (unsigned long long)(unsigned)(d_in - ps.in_base);
-  NAM_HIP_CHECK(hipStreamWriteValue64(caller, ps.d_ring + (ps.seq & (kPRing - 1)), cmd, 0));
+  const unsigned slot = ps.seq & (kPRing - 1);
+  // Nothing in flight on the caller's stream: nothing to order the command behind, the host stores it itself (no
+  // device-side write operation, which costs the host ~4 us and the device a small kernel per buffer).
+  if (ps.host_store_ok && (!ps.last_caller || ps.last_caller == caller) && hipStreamQuery(caller) == hipSuccess)
+  {
+    __atomic_store_n(&ps.d_ring[slot], cmd, __ATOMIC_RELEASE);
+    __builtin_ia32_sfence(); // (the BAR mapping may be write-combining: push the store out now)
+    if (idle)
+    {
+      // (when every workgroup stands at the same count, that count and this command travel with the launch itself)
+      const int rc = uniform ? persist_launch(b, 0, (long long)ps.seq, cmd) : persist_launch(b, 0);
+      if (rc != NAM_HIP_OK)
+        return rc;
+    }
+  }
+  else
+  {
+    if (ps.last_caller && ps.last_caller != caller)
+      NAM_HIP_CHECK(hipStreamSynchronize(ps.last_caller)); // commands of two streams: keep them in order
+    // the launch first, the stream-ordered store behind it: the two travel on different hardware queues, and the
+    // launch looks for its first command for kGraceUs
+    if (idle)
+    {
+      const int rc = persist_launch(b, kGraceUs);
+      if (rc != NAM_HIP_OK)
+        return rc;
+    }
+    NAM_HIP_CHECK(hipStreamWriteValue64(caller, ps.d_ring + slot, cmd, 0));
+  }
   ps.seq++;
+  ps.flushed_valid = false;
+  ps.last_caller = caller;
   WidthGroup& g = b->groups[b->model->full_width];
   g.state_family = state_family_of(*g.plan, NAM_HIP_KERNEL_A1_IL);
   return NAM_HIP_OK;
@@ -672,6 +771,8 @@ void persist_free(nam_hip_batch* b)
   PersistSession& ps = b->ps;
   if (ps.d_ring)
     (void)hipFree(ps.d_ring);
+  if (ps.d_cons)
+    (void)hipFree(ps.d_cons);
   if (ps.h_words)
     (void)hipHostFree(ps.h_words);
   if (ps.kstream)
@@ -1097,7 +1198,7 @@ int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out,
     return rc;
   if (batch->ps.active) // persistent mode: the buffer is done when every workgroup has published its count
   {
-    const int rw = persist_wait(batch, false);
+    const int rw = persist_flush(batch, batch->stream);
     if (rw != NAM_HIP_OK)
       return rw;
   }
@@ -1173,7 +1274,7 @@ int nam_hip_batch_process_f64(nam_hip_batch* batch, const double* in, double* ou
     return rc;
   if (batch->ps.active)
   {
-    const int rw = persist_wait(batch, false);
+    const int rw = persist_flush(batch, batch->stream);
     if (rw != NAM_HIP_OK)
       return rw;
   }
@@ -1220,8 +1321,7 @@ int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream)
     return NAM_HIP_OK;
   // the doorbells were enqueued on the caller's stream: they are only guaranteed to have been rung once it has drained
   hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : batch->stream;
-  NAM_HIP_CHECK(hipStreamSynchronize(s));
-  return persist_wait(batch, false);
+  return persist_flush(batch, s);
 }
 
 int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)

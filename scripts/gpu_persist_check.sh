@@ -9,7 +9,7 @@ for args in "--persistent 1 --steps 20 --warmup 5" "--persistent 1 --steps 2000 
 import sys, json
 try:
     j = json.loads(sys.stdin.read().strip().splitlines()[-1])
-    print('$args', '| value', j['value'], 'us/step', round(j['ms_per_step']*1e3,2), 'frac', j['roofline']['frac'], 'resident', (j.get('resident_launch') or {}).get('value'), 'err', j['max_abs_err_vs_oracle'], 'kernel', j['config']['kernel'], 'persist', j['config']['persistent_block_mode'], 'lat', (j.get('latency_us') or {}).get('p50'), 'enq', j['host_enqueue_us_per_step'])
+    print('$args', '| value', j['value'], 'region', j.get('region_us'), 'us/step', round(j['ms_per_step']*1e3,2), 'frac', j['roofline']['frac'], 'resident', (j.get('resident_launch') or {}).get('value'), 'err', j['max_abs_err_vs_oracle'], 'kernel', j['config']['kernel'], 'persist', j['config']['persistent_block_mode'], 'lat', (j.get('latency_us') or {}).get('p50'), 'enq', j['host_enqueue_us_per_step'])
 except Exception as e:
     print('$args', 'FAILED', e)
 "

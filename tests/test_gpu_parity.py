@@ -890,3 +890,41 @@ def test_persistent_block_mode_matches_oracle(nam_lib, oracle):
         y2 = np.concatenate([y2, y3], axis=-1)
         for s in range(n_streams):
             assert float(np.max(np.abs(refs[s][:, :4 * block] - y2[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(refs[s])))), (name, s)
+
+
+def test_persistent_block_mode_stream_ordered_commands(nam_lib, oracle):
+    """Persistent block mode behind a BUSY caller stream: every buffer's input is produced on the stream (a delay plus
+    a copy into the window) right before process_device on the same stream, with no host synchronisation in between —
+    the command must be ordered behind the producer (the stream-ordered store, not the host's direct one). A
+    device-wide synchronize in the middle of the session must return (the launch leaves by itself when the ring is
+    empty), and the session carries on afterwards. 256 streams: one workgroup per CU, the headline shape."""
+    torch = pytest.importorskip("torch")
+    nam = nam_lib
+    name, n_streams, block, nb = "wavenet_a1_standard", 256, 64, 10
+    x = stream_bank(n_streams, block * nb, seed=77)
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    b = model.batch(n_streams, block)
+    assert b.set_persistent(True)
+    b.Reset(prewarm=True)
+    src = torch.from_numpy(x[:, None, :]).cuda()
+    xd = torch.zeros_like(src)
+    yd = torch.zeros_like(src)
+    T = xd.shape[2]
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        for k in range(nb):
+            if k % 3 != 2:
+                torch.cuda._sleep(200_000)  # ~0.1 ms: the stream is busy when the command is submitted
+            xd[:, :, k * block:(k + 1) * block].copy_(src[:, :, k * block:(k + 1) * block], non_blocking=True)
+            b.process_device(xd.data_ptr() + k * block * 4, yd.data_ptr() + k * block * 4, block, T, st.cuda_stream)
+            if k == 4:
+                torch.cuda.synchronize()  # session alive: must not block on it
+    b.flush(st.cuda_stream)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    b.close()
+    for s in (0, 1, 100, 255):
+        r = _oracle_run(oracle, name, x[s], block, True)
+        assert float(np.max(np.abs(r - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), s
+    assert np.isfinite(y).all()
