@@ -62,6 +62,11 @@ extern "C" {
                                   dilations 4..32 are DPP row shifts inside the wave and dilations >= 64 are the lane's own
                                   ring rows — 4 workgroup barriers per block for wavenet_a1_standard instead of 20; one
                                   loader wave stages the weights in LDS. Falls back to NAM_HIP_KERNEL_A1_MFMA */
+#define NAM_HIP_KERNEL_WN_REG 5 /* register-resident WaveNet kernel for narrow, feature-rich models (FiLMs, gating, grouped
+                                   1x1s, head1x1, a nested condition_dsp — example_models/wavenet_a2_max.nam): one wavefront
+                                   per stream, lane = frame, a layer = one unrolled function per instantiated shape; every
+                                   conv reaches at most 64 frames back. AUTO picks it when no A1 kernel takes the model;
+                                   falls back like AUTO when the model's shapes are not instantiated */
 
 typedef struct nam_hip_model nam_hip_model;
 typedef struct nam_hip_batch nam_hip_batch;

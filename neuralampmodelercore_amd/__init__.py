@@ -18,12 +18,12 @@ import numpy as np
 
 __all__ = [
     "NamHipError", "NamFileValidationError", "Model", "Batch", "get_dsp", "get_dsp_json", "lib_path", "load_library",
-    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_A1", "KERNEL_A1_MFMA", "KERNEL_A1_IL", "ABI_SYMBOLS",
+    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_A1", "KERNEL_A1_MFMA", "KERNEL_A1_IL", "KERNEL_WN_REG", "ABI_SYMBOLS",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_A1, KERNEL_A1_MFMA, KERNEL_A1_IL = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_A1, KERNEL_A1_MFMA, KERNEL_A1_IL, KERNEL_WN_REG = 0, 1, 2, 3, 4, 5
 
 ERR_INVALID_ARGUMENT, ERR_FILE, ERR_MODEL, ERR_UNSUPPORTED, ERR_DEVICE, ERR_TOO_MANY_FRAMES = -1, -2, -3, -4, -5, -6
 

@@ -90,6 +90,25 @@ struct LSTMArgs
   int mf_layer_bias[16];
 };
 
+struct WrArgs // nam_wn_reg_kernel (plan.h: WrPlan)
+{
+  const WrOp* ops;
+  int n_ops;
+  const float* blob; // weights as the kernel's LDS copy holds them (a multiple of 4 floats)
+  int blob_floats;
+  float* state;
+  long state_stride;
+  const int* stream_map;
+  const float* in; // nullptr = silence (prewarm)
+  float* out; // nullptr = discard
+  long io_stride;
+  int n_frames;
+  int in_ch, out_ch;
+  int hist_base; // LDS float offset of history row 0 (behind the weights)
+  int n_rows; // history rows: the sum of the layers' channel counts
+};
+
+hipError_t launch_wn_reg(const WrArgs& a, int n_streams, int lds_bytes, hipStream_t stream);
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);

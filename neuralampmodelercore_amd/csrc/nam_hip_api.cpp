@@ -94,13 +94,16 @@ struct WidthGroup
   float* d_blob = nullptr;
   NamOp* d_ops = nullptr;
   A1Plan* d_a1 = nullptr;
+  WrOp* d_wr_ops = nullptr; // nam_wn_reg_kernel's macro-ops and weights (plan.h: WrPlan)
+  float* d_wr_blob = nullptr;
   float* d_state = nullptr; // [n_streams][state_stride] (allocated when the first stream joins)
   float* d_init = nullptr; // LSTM initial state
   long state_stride = 0;
   std::vector<int> streams; // members, ascending
   int* d_map = nullptr; // device copy of `streams` (nullptr when the group is all streams in order)
-  // Which ring layout the state currently holds (only models whose A1 kernels run on zero-padded channels have two:
-  // plan.h, Plan::a1_padded_layout): -1 = freshly zeroed (either), 0 = the op program's, 1 = the padded A1 layout
+  // Which layout the state currently holds: -1 = freshly zeroed (any), 0 = the op program's rings (shared by the A1
+  // kernels unless they run on zero-padded channels: plan.h, Plan::a1_padded_layout), 1 = the padded A1 rings,
+  // 2 = nam_wn_reg_kernel's 64-frame conv-input histories
   int state_family = -1;
 };
 } // namespace
@@ -183,6 +186,13 @@ int upload_group(nam_hip_batch* b, WidthGroup& g)
       NAM_HIP_CHECK(hipMalloc(&g.d_a1, sizeof(A1Plan)));
       NAM_HIP_CHECK(hipMemcpy(g.d_a1, &p.a1, sizeof(A1Plan), hipMemcpyHostToDevice));
     }
+    if (p.wr.ok)
+    {
+      NAM_HIP_CHECK(hipMalloc(&g.d_wr_ops, p.wr.ops.size() * sizeof(WrOp)));
+      NAM_HIP_CHECK(hipMemcpy(g.d_wr_ops, p.wr.ops.data(), p.wr.ops.size() * sizeof(WrOp), hipMemcpyHostToDevice));
+      NAM_HIP_CHECK(hipMalloc(&g.d_wr_blob, p.wr.blob.size() * sizeof(float)));
+      NAM_HIP_CHECK(hipMemcpy(g.d_wr_blob, p.wr.blob.data(), p.wr.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   else if (p.arch == ARCH_LSTM)
   {
@@ -227,6 +237,8 @@ hipError_t quiesce(nam_hip_batch* b)
 
 int state_family_of(const Plan& p, int kernel)
 {
+  if (kernel == NAM_HIP_KERNEL_WN_REG)
+    return 2;
   return (p.a1_padded_layout && kernel != NAM_HIP_KERNEL_GENERIC) ? 1 : 0;
 }
 
@@ -256,10 +268,14 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
   const bool a1 = g.plan->a1.valid && g.d_a1;
   const bool mfma = a1 && (g.plan->a1.ws_ok || g.plan->a1.kt_ok);
   const bool il = a1 && g.plan->a1.il_ok;
-  const int fallback = a1 ? NAM_HIP_KERNEL_A1 : NAM_HIP_KERNEL_GENERIC;
+  const bool wr = g.plan->wr.ok && g.d_wr_ops;
+  // a model no A1 kernel takes (FiLMs, gating, a nested condition_dsp ...) runs with its activations in registers when
+  // its layers are among the instantiated shapes, else through the op interpreter
+  const int fallback = a1 ? NAM_HIP_KERNEL_A1 : (wr ? NAM_HIP_KERNEL_WN_REG : NAM_HIP_KERNEL_GENERIC);
   switch (b->kernel)
   {
     case NAM_HIP_KERNEL_GENERIC: return NAM_HIP_KERNEL_GENERIC;
+    case NAM_HIP_KERNEL_WN_REG: return wr ? NAM_HIP_KERNEL_WN_REG : fallback;
     case NAM_HIP_KERNEL_A1: return fallback;
     case NAM_HIP_KERNEL_A1_MFMA: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback;
     case NAM_HIP_KERNEL_A1_IL: return il ? NAM_HIP_KERNEL_A1_IL : (mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback);
@@ -288,6 +304,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
     switch (pick_kernel(b, g))
     {
       case NAM_HIP_KERNEL_GENERIC: return "nam_generic_kernel";
+      case NAM_HIP_KERNEL_WN_REG: return "nam_wn_reg_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
       case NAM_HIP_KERNEL_A1_IL: return (p.a1.p2_ok && !b->il_generic) ? "nam_a1_p2_kernel" : "nam_a1_il_kernel";
       default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
@@ -317,9 +334,30 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
     const int fam = state_family_of(p, kernel);
     if (g.state_family >= 0 && g.state_family != fam)
       return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
-                  "kernel change crosses state layouts (this model runs its A1 kernels on zero-padded channels): "
-                  "call nam_hip_batch_reset before switching between NAM_HIP_KERNEL_GENERIC and the A1 kernels");
+                  "kernel change crosses state layouts (the op program's rings, the A1 kernels' zero-padded rings and "
+                  "nam_wn_reg_kernel's conv-input histories differ): call nam_hip_batch_reset before switching");
     g.state_family = fam;
+    if (kernel == NAM_HIP_KERNEL_WN_REG)
+    {
+      WrArgs a;
+      a.ops = g.d_wr_ops;
+      a.n_ops = (int)p.wr.ops.size();
+      a.blob = g.d_wr_blob;
+      a.blob_floats = (int)p.wr.blob.size();
+      a.state = g.d_state;
+      a.state_stride = g.state_stride;
+      a.stream_map = d_map;
+      a.in = d_in;
+      a.out = d_out;
+      a.io_stride = io_stride;
+      a.n_frames = n_frames;
+      a.in_ch = p.in_channels;
+      a.out_ch = p.out_channels;
+      a.hist_base = (int)p.wr.blob.size();
+      a.n_rows = p.wr.state_floats / kBlock;
+      NAM_HIP_CHECK(launch_wn_reg(a, n, p.wr.lds_bytes, s));
+      return NAM_HIP_OK;
+    }
     if (kernel != NAM_HIP_KERNEL_GENERIC)
     {
       A1Args a;
@@ -788,6 +826,10 @@ void free_group(WidthGroup& g)
     (void)hipFree(g.d_blob);
   if (g.d_ops)
     (void)hipFree(g.d_ops);
+  if (g.d_wr_ops)
+    (void)hipFree(g.d_wr_ops);
+  if (g.d_wr_blob)
+    (void)hipFree(g.d_wr_blob);
   if (g.d_a1)
     (void)hipFree(g.d_a1);
   if (g.d_state)
@@ -953,7 +995,8 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
                                              : 0; // a container has no weights of its own
   info->fast_tanh = s.fast_tanh ? 1 : 0;
   info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0)
-                        | ((p.a1.valid && p.a1.il_ok) ? 4 : 0) | ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? 8 : 0);
+                        | ((p.a1.valid && p.a1.il_ok) ? 4 : 0) | ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? 8 : 0)
+                        | (p.wr.ok ? 16 : 0);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -1326,7 +1369,7 @@ int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream)
 
 int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
-  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_A1_IL)
+  if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_WN_REG)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
   if (batch->ps.active)
   {
@@ -1341,12 +1384,19 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
   {
     // LSTM batches: AUTO (gate-row kernel for small cells, else matrix cores), GENERIC (lanes = streams),
     // A1_MFMA (force the matrix-core kernel)
-    if (kernel == NAM_HIP_KERNEL_A1 || kernel == NAM_HIP_KERNEL_A1_IL)
+    if (kernel == NAM_HIP_KERNEL_A1 || kernel == NAM_HIP_KERNEL_A1_IL || kernel == NAM_HIP_KERNEL_WN_REG)
       return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: WaveNet kernels cannot run an LSTM");
     batch->kernel = kernel;
     return NAM_HIP_OK;
   }
-  if (kernel >= NAM_HIP_KERNEL_A1)
+  if (kernel == NAM_HIP_KERNEL_WN_REG)
+  {
+    const Plan& full = *batch->groups[batch->model->full_width].plan;
+    if (full.arch != ARCH_WAVENET || !full.wr.ok)
+      return fail(NAM_HIP_ERR_UNSUPPORTED, "nam_hip_batch_set_kernel: the register-resident WaveNet kernel cannot run this model ("
+                                             + full.wr.why + ")");
+  }
+  else if (kernel >= NAM_HIP_KERNEL_A1)
   {
     // every submodel must have an A1 plan; the MFMA kernels must exist for the full-width submodel (narrower
     // submodels of a container fall back to the VALU kernel: A2-Lite has 3 channels)
@@ -1368,8 +1418,9 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
     {
       batch->kernel = prev;
       return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
-                  "nam_hip_batch_set_kernel: this model runs its A1 kernels on zero-padded channels, whose history rings "
-                  "differ from the op program's; call nam_hip_batch_reset(batch, 0) first, then switch, then reset / prewarm");
+                  "nam_hip_batch_set_kernel: the state was written in another kernel family's layout (op program rings / "
+                  "zero-padded A1 rings / nam_wn_reg_kernel histories); call nam_hip_batch_reset(batch, 0) first, then "
+                  "switch, then reset / prewarm");
     }
   return NAM_HIP_OK;
 }

@@ -1244,6 +1244,257 @@ void validate_wavenet_geometry(const WaveNetSpec& wn)
 
 } // namespace
 
+// --------------------------------------------------------------------------------------------
+// nam_wn_reg_kernel: macro-op program + padded dense weights (plan.h: WrPlan)
+// --------------------------------------------------------------------------------------------
+namespace
+{
+struct WrBuilder
+{
+  WrPlan& wr;
+  int rows = 0; // history rows so far (one per conv-input channel of every layer)
+  explicit WrBuilder(WrPlan& w) : wr(w) {}
+
+  struct Unsupported : std::runtime_error
+  {
+    using std::runtime_error::runtime_error;
+  };
+
+  int reserve(int n)
+  {
+    const int off = (int)wr.blob.size();
+    wr.blob.resize((size_t)off + (size_t)wr_pad4(n), 0.0f);
+    return off;
+  }
+  WrOp& push(int type)
+  {
+    WrOp op;
+    std::memset(&op, 0, sizeof(op));
+    op.type = type;
+    op.shape = -1;
+    wr.ops.push_back(op);
+    return wr.ops.back();
+  }
+  // dense [cout][pad4(k_in)] at `dst`, from the reference's stream order (groups, out, in, tap); column = tap * cin + in
+  void dense(float* dst, const float*& w, int cin, int cout, int K, int groups)
+  {
+    const int row = wr_pad4(K * cin);
+    const int opg = cout / groups, ipg = cin / groups;
+    for (int g = 0; g < groups; g++)
+      for (int i = 0; i < opg; i++)
+        for (int j = 0; j < ipg; j++)
+          for (int k = 0; k < K; k++)
+            dst[(size_t)(g * opg + i) * row + (size_t)k * cin + (g * ipg + j)] = *(w++);
+  }
+  void act_block(float* dst, const ActSpec& a, int rows_n)
+  {
+    for (int i = 0; i < 4; i++)
+      dst[i] = a.p[i];
+    if (a.type == ACT_PRELU && !a.slopes.empty())
+      for (int c = 0; c < 16; c++)
+        dst[4 + c] = a.slopes[(size_t)c % a.slopes.size()];
+    (void)rows_n;
+  }
+
+  void net(const WaveNetSpec& wn, bool nested)
+  {
+    if (wn.with_head)
+      throw Unsupported("a post-stack head");
+    if (wn.in_channels > kWrRegs || wn.out_channels() > kWrRegs)
+      throw Unsupported("more than 8 input / output channels");
+    if ((long)wn.weights.size() != wn.expected_weight_count())
+      throw std::runtime_error("plan: WaveNet weight count mismatch");
+    int cond_dim = wn.in_channels;
+    if (wn.condition_dsp)
+    {
+      if (nested)
+        throw Unsupported("a condition_dsp inside a condition_dsp");
+      if (wn.condition_dsp->arch != ARCH_WAVENET)
+        throw Unsupported("a condition_dsp that is not a WaveNet");
+      const WaveNetSpec& c = wn.condition_dsp->wavenet;
+      if (c.in_channels != wn.in_channels)
+        throw Unsupported("a condition_dsp with another input width");
+      net(c, true);
+      cond_dim = c.out_channels();
+      WrOp& op = push(WR_SET_COND);
+      op.n_out = cond_dim;
+      op.scale = c.weights.back(); // model.cpp:670 — the last weight is the head scale
+    }
+    const float* w = wn.weights.data();
+    for (size_t ai = 0; ai < wn.arrays.size(); ai++)
+    {
+      const LayerArraySpec& A = wn.arrays[ai];
+      const int C = A.channels, B = A.bottleneck, HO = A.head_output_size();
+      if (A.condition_size != cond_dim)
+        throw std::runtime_error("plan: condition_size does not match the condition signal");
+      if (!A.layer1x1_active)
+        throw Unsupported("a layer without its 1x1");
+      if (A.head_kernel_size != 1)
+        throw Unsupported("a head rechannel with a kernel");
+      if (ai > 0 && wn.arrays[ai - 1].head_size != HO)
+        throw std::runtime_error("plan: head sizes of consecutive arrays do not chain");
+      {
+        WrOp& op = push(WR_ARRAY_BEGIN);
+        op.flags = ai == 0 ? 1 : 0;
+        op.n_in = A.input_size;
+        op.n_out = C;
+        op.shape = wr_pair_shape(A.input_size, C);
+        if (op.shape < 0)
+          throw Unsupported("a rechannel of " + std::to_string(A.input_size) + " -> " + std::to_string(C));
+        const int off = reserve(C * wr_pad4(A.input_size));
+        wr.ops.back().w = off;
+        dense(&wr.blob[(size_t)off], w, A.input_size, C, 1, 1);
+      }
+      for (int l = 0; l < A.num_layers(); l++)
+      {
+        const int gm = A.gating_modes[l];
+        const bool G = gm != GATING_NONE;
+        const int zc = G ? 2 * B : B, K = A.kernel_sizes[l], dil = A.dilations[l];
+        const int h1o = A.head1x1_active ? A.head1x1_out : 0;
+        if ((K - 1) * dil > kBlock)
+          throw Unsupported("a conv reaching more than 64 frames back");
+        const ActSpec& a1 = A.activations[l];
+        const ActSpec& a2 = A.secondary_activations[l];
+        if (a1.type == ACT_LUT || (G && a2.type == ACT_LUT))
+          throw Unsupported("a look-up-table activation");
+        // Activation::apply on the flat buffer indexes PReLU slopes by frame * rows + row (activations.h:283-297):
+        // only frame-independent when the slope count divides the row count
+        if (!G && a1.type == ACT_PRELU && !a1.slopes.empty() && zc % (int)a1.slopes.size() != 0)
+          throw Unsupported("a PReLU whose slope count does not divide the channel count");
+        if (zc > 16 || C > kWrRegs || HO > kWrRegs || cond_dim > kWrRegs)
+          throw Unsupported("a layer wider than the register files");
+        const int shape = wr_layer_shape(cond_dim, C, B, G, K, h1o);
+        if (shape < 0)
+          throw Unsupported("layer shape cond=" + std::to_string(cond_dim) + " C=" + std::to_string(C) + " B=" + std::to_string(B)
+                            + (G ? " gating" : "") + " K=" + std::to_string(K) + " head1x1=" + std::to_string(h1o));
+        const WrLayerLayout L = wr_layer_layout(cond_dim, C, B, G, K, h1o);
+        const int off = reserve(L.total);
+        float* d = &wr.blob[(size_t)off];
+        // the flat stream order is conv, mixin, layer1x1, head1x1, then the 8 FiLMs (model.cpp:152-181)
+        dense(d + L.conv, w, C, zc, K, A.groups_input);
+        for (int i = 0; i < zc; i++)
+          d[L.conv_b + i] = *(w++);
+        dense(d + L.mixin, w, cond_dim, zc, 1, A.groups_input_mixin);
+        dense(d + L.l1, w, B, C, 1, A.layer1x1_groups);
+        for (int i = 0; i < C; i++)
+          d[L.l1_b + i] = *(w++);
+        if (A.head1x1_active)
+        {
+          dense(d + L.h1, w, B, h1o, 1, A.head1x1_groups);
+          for (int i = 0; i < h1o; i++)
+            d[L.h1_b + i] = *(w++);
+        }
+        const int dims[FILM_COUNT] = {C, zc, cond_dim, zc, zc, B, C, h1o};
+        int flags = gm == GATING_BLENDED ? (1 << 16) : 0;
+        for (int k = 0; k < FILM_COUNT; k++)
+        {
+          bool on = A.film[k].active;
+          if (k == FILM_HEAD1X1_POST && !A.head1x1_active)
+            on = false;
+          if (!on)
+            continue;
+          const int D = dims[k], outc = (A.film[k].shift ? 2 : 1) * D;
+          // Conv1x1(cond -> outc, groups) + bias; rows [0, D) scale, [D, 2D) shift
+          dense(d + L.film[k], w, cond_dim, outc, 1, A.film[k].groups);
+          float* bias = d + L.film[k] + 2 * D * wr_pad4(cond_dim);
+          for (int i = 0; i < outc; i++)
+            bias[i] = *(w++);
+          flags |= 1 << k;
+          if (A.film[k].shift)
+            flags |= 1 << (8 + k);
+        }
+        act_block(d + L.act, a1, zc);
+        if (G)
+          act_block(d + L.act2, a2, B);
+        WrOp& op = push(WR_LAYER);
+        op.shape = shape;
+        op.w = off;
+        op.hist = rows * kWrPitch; // + the history area's base, added once the weights are complete
+        op.state = rows * kBlock;
+        op.dil = dil;
+        op.flags = flags;
+        op.act = a1.type;
+        op.act2 = G ? a2.type : ACT_IDENTITY;
+        rows += C;
+        wr.n_layers++;
+      }
+      {
+        WrOp& op = push(WR_ARRAY_END);
+        op.flags = A.head_bias ? 1 : 0;
+        op.n_in = HO;
+        op.n_out = A.head_size;
+        op.shape = wr_pair_shape(HO, A.head_size);
+        if (op.shape < 0)
+          throw Unsupported("a head rechannel of " + std::to_string(HO) + " -> " + std::to_string(A.head_size));
+        const int off = reserve(A.head_size * wr_pad4(HO) + wr_pad4(A.head_size));
+        wr.ops.back().w = off;
+        dense(&wr.blob[(size_t)off], w, HO, A.head_size, 1, 1);
+        if (A.head_bias)
+          for (int i = 0; i < A.head_size; i++)
+            wr.blob[(size_t)off + (size_t)A.head_size * wr_pad4(HO) + i] = *(w++);
+      }
+    }
+    const float head_scale = *(w++);
+    if (w != wn.weights.data() + wn.weights.size())
+      throw std::runtime_error("plan: internal error, weight stream not fully consumed (register-resident plan)");
+    if (!nested)
+    {
+      WrOp& op = push(WR_OUTPUT);
+      op.n_out = wn.out_channels();
+      op.scale = head_scale;
+    }
+  }
+};
+} // namespace
+
+int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out)
+{
+#define X(ID, COND, C, B, G, K, HO) \
+  if (cond == COND && channels == C && bottleneck == B && gating == G && kernel == K && head_out == HO) \
+    return ID;
+  WR_LAYER_SHAPES(X)
+#undef X
+  return -1;
+}
+
+int wr_pair_shape(int n_in, int n_out)
+{
+#define X(ID, IN, OUT) \
+  if (n_in == IN && n_out == OUT) \
+    return ID;
+  WR_PAIR_SHAPES(X)
+#undef X
+  return -1;
+}
+
+void build_wr(const WaveNetSpec& wn, Plan& plan)
+{
+  WrPlan wr;
+  try
+  {
+    WrBuilder b(wr);
+    b.net(wn, false);
+    const int hist_base = (int)wr.blob.size(); // history rows behind the weights
+    for (auto& op : wr.ops)
+      if (op.type == WR_LAYER)
+        op.hist += hist_base;
+    wr.hist_floats = b.rows * kWrPitch;
+    wr.state_floats = b.rows * kBlock;
+    wr.lds_bytes = (hist_base + wr.hist_floats) * 4;
+    if (wr.lds_bytes > 64 * 1024)
+      throw WrBuilder::Unsupported("more than 64 KB of weights and histories");
+    wr.ok = true;
+  }
+  catch (const WrBuilder::Unsupported& e)
+  {
+    wr = WrPlan{};
+    wr.why = e.what();
+  }
+  plan.wr = std::move(wr);
+  if (plan.wr.ok)
+    plan.state_floats = std::max(plan.state_floats, plan.wr.state_floats);
+}
+
 Plan build_wavenet_plan(const WaveNetSpec& wn)
 {
   validate_wavenet_geometry(wn);
@@ -1329,6 +1580,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
     build_a1_kt(plan);
     build_a1_il(plan);
   }
+  build_wr(wn, plan);
   return plan;
 }
 

@@ -361,6 +361,121 @@ struct A1Plan
   KtDesc kt_desc[kKtChunkMax];
 };
 
+// ---- register-resident WaveNet (nam_wn_reg_kernel) ----------------------------------------------------------------
+// For WaveNets whose every conv reaches back at most 64 frames ((K - 1) * dilation <= 64) and whose layers are a few
+// channels wide (the FiLM-heavy A2 "max" feature set, nested condition_dsp included): one wavefront per stream, lane =
+// frame, EVERY activation in registers — a layer is one fully unrolled function instantiated per shape
+// (kernel_wn_reg.hip: WR_SHAPES), run from a list of macro-ops (an array's rechannel, a layer, an array's head
+// rechannel, "the nested net's output becomes the condition", "store the output"). The only LDS traffic is the
+// weights (broadcast b128 reads) and each layer's conv input, kept 64 frames back for the taps.
+//   weights: `blob` is copied to LDS once per launch; per matrix [out][pad4(in)] row-major, zero padded; grouped convs
+//            expanded to dense (block-diagonal); a layer's block has a fixed layout given its shape (inactive FiLMs
+//            keep their zeroed slot), see kernel_wn_reg.hip: LayerLayout
+//   state:   per layer [C][64] floats: the last 64 frames of the layer's conv input (kernel_wn_reg.hip)
+enum WrOpType : int32_t
+{
+  WR_ARRAY_BEGIN = 0, // head accumulator = first array ? 0 : previous head output; x = rechannel(previous x | input)
+  WR_LAYER = 1,
+  WR_ARRAY_END = 2, // head output = head_rechannel(head accumulator) (+ bias)
+  WR_SET_COND = 3, // condition registers = scale * head output (the nested condition_dsp's result)
+  WR_OUTPUT = 4 // out[ch] = scale * head output[ch]
+};
+
+struct WrOp // 16 x int32 = 64 bytes
+{
+  int32_t type;
+  int32_t shape; // index into the kernel's instantiation table (WR_LAYER / WR_ARRAY_*: (in, out) pair)
+  int32_t w; // float offset of this op's weights in the blob (and in the LDS copy)
+  int32_t hist; // WR_LAYER: LDS float offset of the layer's history rows [C][128]; state offset = layer index * C * 64
+  int32_t state; // WR_LAYER: float offset of the layer's [C][64] block in the per-stream state
+  int32_t dil; // WR_LAYER: dilation
+  int32_t flags; // WR_LAYER: bit i = FiLM slot i active, bit 8 + i = it has a shift; bit 16 = blended (else gated) when the
+                 // shape is a gating one; WR_ARRAY_BEGIN: bit 0 = first array (head accumulator starts at 0, x from the
+                 // input); WR_ARRAY_END: bit 0 = bias
+  int32_t act, act2; // WR_LAYER: activation types (primary, secondary)
+  int32_t n_in, n_out; // WR_ARRAY_BEGIN: input size, channels; WR_ARRAY_END: head input size, head size; SET_COND/OUTPUT: count
+  float scale; // SET_COND / OUTPUT: head_scale
+  int32_t pad[4];
+};
+static_assert(sizeof(WrOp) == 64, "WrOp must stay 64 bytes");
+
+constexpr int kWrPitch = 128; // floats per history row: 64 frames back + the block's 64
+constexpr int kWrRegs = 8; // width of the register files (x, condition, head accumulator, head output)
+constexpr int kWrActFloats = 20; // per activation: p0..p3, then the PReLU slope of each of (up to) 16 rows
+
+struct WrPlan
+{
+  bool ok = false;
+  std::string why; // when !ok: the first unsupported thing
+  std::vector<WrOp> ops;
+  std::vector<float> blob;
+  int n_layers = 0;
+  int state_floats = 0; // per stream
+  int hist_floats = 0; // LDS floats for the history rows
+  int lds_bytes = 0; // weights + history
+};
+
+// The layer shapes kernel_wn_reg.hip instantiates — (id, condition size, channels, bottleneck, gating, kernel size,
+// head1x1 outputs; 0 = no head1x1) — and the (id, in, out) pairs of the array ops (rechannel, head rechannel).
+#define WR_LAYER_SHAPES(X) \
+  X(0, 8, 4, 4, false, 4, 4) /* wavenet_a2_max.nam: main array */ \
+  X(1, 1, 3, 6, true, 2, 6) /* its condition_dsp: array 0 (gated, grouped) */ \
+  X(2, 1, 4, 2, true, 3, 4) /* its condition_dsp: array 1 (blended / gated) */ \
+  X(3, 1, 4, 4, false, 3, 0) /* plain small stacks (no head1x1) */ \
+  X(4, 1, 3, 3, false, 3, 0) \
+  X(5, 1, 2, 2, false, 3, 0) \
+  X(6, 1, 8, 8, false, 3, 0) \
+  X(7, 3, 3, 3, false, 3, 0) /* example_models/wavenet_condition_dsp.nam */ \
+  X(8, 3, 4, 4, false, 3, 0) \
+  X(9, 3, 2, 2, false, 3, 0)
+#define WR_PAIR_SHAPES(X) \
+  X(0, 1, 3) X(1, 3, 4) X(2, 1, 4) X(3, 6, 4) X(4, 4, 8) X(5, 4, 1) X(6, 4, 4) X(7, 1, 2) X(8, 2, 1) X(9, 3, 1) X(10, 1, 8) \
+  X(11, 8, 1) X(12, 8, 4) X(13, 4, 2) X(14, 2, 2) X(15, 3, 3) X(16, 8, 8) X(17, 2, 4) X(18, 3, 2) X(19, 6, 1) X(20, 1, 1) X(21, 2, 3) X(22, 4, 3) X(23, 3, 8) X(24, 2, 8)
+// id of a shape, -1 = not instantiated
+int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out);
+int wr_pair_shape(int n_in, int n_out);
+// float count / offsets of a layer's weight block (shared by the planner and the kernel)
+struct WrLayerLayout
+{
+  int conv, conv_b, mixin, l1, l1_b, h1, h1_b, film[8], act, act2, total;
+};
+constexpr int wr_pad4(int n)
+{
+  return (n + 3) & ~3;
+}
+constexpr WrLayerLayout wr_layer_layout(int cond, int C, int B, bool gating, int K, int HO)
+{
+  WrLayerLayout L{};
+  const int zc = gating ? 2 * B : B;
+  int o = 0;
+  L.conv = o;
+  o += zc * wr_pad4(K * C);
+  L.conv_b = o;
+  o += wr_pad4(zc);
+  L.mixin = o;
+  o += zc * wr_pad4(cond);
+  L.l1 = o;
+  o += C * wr_pad4(B);
+  L.l1_b = o;
+  o += wr_pad4(C);
+  L.h1 = o;
+  o += HO * wr_pad4(B);
+  L.h1_b = o;
+  o += wr_pad4(HO);
+  const int dims[8] = {C, zc, cond, zc, zc, B, C, HO};
+  for (int k = 0; k < 8; k++)
+  {
+    L.film[k] = o; // [2 * D][pad4(cond)] then bias [pad4(2 * D)]
+    o += 2 * dims[k] * wr_pad4(cond) + wr_pad4(2 * dims[k]);
+  }
+  L.act = o;
+  o += kWrActFloats;
+  L.act2 = o;
+  o += kWrActFloats;
+  L.total = o;
+  return L;
+}
+
 // ---- LSTM ------------------------------------------------------------------------------------
 // blob layout per layer: W [4H][I+H] row-major, b [4H]; then head W [out][H], head b [out].
 // Per-stream state: for each layer h[H], c[H] (initialised from the weight stream, lstm.cpp:24-28).
@@ -406,6 +521,7 @@ struct Plan
   bool a1_padded_layout = false;
   A1Plan a1;
   LSTMPlan lstm;
+  WrPlan wr;
   std::string describe() const;
 };
 

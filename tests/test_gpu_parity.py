@@ -33,7 +33,7 @@ def _tol(fast_tanh):
 
 @pytest.mark.parametrize("name", WAVENETS)
 @pytest.mark.parametrize("fast_tanh", [True, False])
-@pytest.mark.parametrize("kernel", ["generic", "a1", "auto"])
+@pytest.mark.parametrize("kernel", ["generic", "a1", "auto", "wn_reg"])
 def test_wavenet_matches_oracle(nam_lib, oracle, name, fast_tanh, kernel):
     nam = nam_lib
     n_streams, block, n = 5, 64, 64 * 6
@@ -46,6 +46,11 @@ def test_wavenet_matches_oracle(nam_lib, oracle, name, fast_tanh, kernel):
         if not (model.info.has_a1_kernel & 1):
             pytest.skip("model is outside the A1 family")
         batch.set_kernel(nam.KERNEL_A1)
+    elif kernel == "wn_reg":
+        if not (model.info.has_a1_kernel & 16):
+            pytest.skip("model is outside the register-resident kernel's shapes")
+        batch.set_kernel(nam.KERNEL_WN_REG)
+        assert batch.kernel_name() == "nam_wn_reg_kernel"
     batch.Reset(prewarm=True)
     y = batch.process_stream(x, block)
     assert y.shape == (n_streams, model.NumOutputChannels(), n)
@@ -928,3 +933,55 @@ def test_persistent_block_mode_stream_ordered_commands(nam_lib, oracle):
         r = _oracle_run(oracle, name, x[s], block, True)
         assert float(np.max(np.abs(r - y[s]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), s
     assert np.isfinite(y).all()
+
+
+@pytest.mark.parametrize("name,in_ch", [("wavenet_a2_max", 1), ("wavenet_condition_dsp", 1), ("synth_leakyhardtanh", 1),
+                                        ("synth_multich", 3), ("wavenet", 1)])
+def test_register_resident_wavenet_kernel(nam_lib, oracle, name, in_ch):
+    """nam_wn_reg_kernel (every activation in registers, one wavefront per stream; what AUTO runs for wavenet_a2_max):
+    64-frame buffers, odd buffer sizes (the history shift by n < 64 frames), one long launch walking many blocks
+    (render), a mixed-length ragged render, and the state-layout guard against the op interpreter — all against the
+    oracle, both tanh modes where the model has a tanh."""
+    nam = nam_lib
+    n_streams, n = 6, 64 * 5 + 23
+    rng = np.random.default_rng(97)
+    x = rng.uniform(-0.6, 0.6, (n_streams, in_ch, n)).astype(np.float32)
+    for fast_tanh in (True, False):
+        model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+        assert model.info.has_a1_kernel & 16
+        refs = []
+        for s in range(n_streams):
+            r = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+            r.Reset(48000.0, 64)
+            refs.append(r.process_stream(x[s] if in_ch > 1 else x[s, 0], 64))
+        b = model.batch(n_streams, 64)
+        b.set_kernel(nam.KERNEL_WN_REG)
+        assert b.kernel_name() == "nam_wn_reg_kernel"
+        xin = x if in_ch > 1 else x[:, 0, :]
+        b.Reset(prewarm=True)
+        y = b.process_stream(xin, 64)
+        b.Reset(prewarm=True)
+        y_odd = np.concatenate([b.process(xin[..., a:a + m]) for a, m in
+                                [(0, 17), (17, 64), (81, 1), (82, 63), (145, 64), (209, 40), (249, 64), (313, n - 313)]], axis=-1)
+        b.Reset(prewarm=True)
+        lens = [n, 200, 64, 1, 129, 65]
+        yr = b.render([xin[s, ..., :m] for s, m in enumerate(lens)])
+        tol = _tol(fast_tanh)
+        for s in range(n_streams):
+            ref = refs[s].reshape(y[s].shape)
+            scale = max(1.0, float(np.max(np.abs(ref))))
+            assert float(np.max(np.abs(ref - y[s]))) <= tol * scale, (name, fast_tanh, s)
+            # the oracle runs 64-frame calls; other partitions of the same signal agree up to rounding (no PReLU whose
+            # slope index depends on the call boundaries reaches this kernel)
+            assert float(np.max(np.abs(ref - y_odd[s]))) <= tol * scale, (name, fast_tanh, s, "odd")
+            assert float(np.max(np.abs(ref[..., :lens[s]] - np.asarray(yr[s]).reshape(ref[..., :lens[s]].shape)))) <= tol * scale, (name, s, "render")
+        # the interpreter keeps rings, this kernel 64-frame histories: switching needs freshly reset state
+        with pytest.raises(nam.NamHipError):
+            b.set_kernel(nam.KERNEL_GENERIC)
+        b.Reset(prewarm=False)
+        b.set_kernel(nam.KERNEL_GENERIC)
+        b.Reset(prewarm=True)
+        yg = b.process_stream(xin, 64)
+        for s in range(n_streams):
+            assert float(np.max(np.abs(yg[s] - y[s]))) <= 2 * tol * max(1.0, float(np.max(np.abs(yg[s]))))
+        b.close()

@@ -45,12 +45,15 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
     ("synth_a1_mixed", 7),  # kernel size 3 everywhere, several arrays: the wave-specialised + interleaved MFMA kernels
     ("synth_a1_lite", 15), ("synth_a1_feather", 15), ("synth_a1_c14", 7),  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
     ("slimmable_wavenet", 1),  # 3 channels: VALU kernel only
-    ("wavenet_a2_max", 0), ("wavenet_condition_dsp", 0), ("synth_posthead", 0), ("synth_multich", 0),  # generic kernel
+    # FiLMs / gating / nested condition_dsp / multi-channel: the register-resident kernel (bit 4) where every layer is
+    # one of its instantiated shapes, else the op interpreter alone (a post-stack head)
+    ("wavenet_a2_max", 16), ("wavenet_condition_dsp", 16), ("synth_multich", 16), ("synth_leakyhardtanh", 16),
+    ("synth_posthead", 0), ("wavenet", 17),
     ("lstm", 0)])
 def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
     """has_a1_kernel: bit 0 = the VALU A1 kernel, bit 1 = one of the MFMA kernels (plan.cpp: build_a1 / build_a1_ws /
     build_a1_kt), bit 2 = the interleaved-frame MFMA kernel (build_a1_il), bit 3 = its compile-time-topology
-    form for the official sizes (plan.h: namespace p2). Decided on the host at load time, so it is checkable without a GPU."""
+    form for the official sizes (plan.h: namespace p2), bit 4 = nam_wn_reg_kernel (plan.cpp: build_wr). Decided on the host at load time, so it is checkable without a GPU."""
     assert nam_lib.get_dsp(model_path(name)).info.has_a1_kernel == bits
 
 
