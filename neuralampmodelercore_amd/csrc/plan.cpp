@@ -1275,16 +1275,27 @@ struct WrBuilder
     wr.ops.push_back(op);
     return wr.ops.back();
   }
-  // dense [cout][pad4(k_in)] at `dst`, from the reference's stream order (groups, out, in, tap); column = tap * cin + in
-  void dense(float* dst, const float*& w, int cin, int cout, int K, int groups)
+  // dense, transposed [K * cin][pad4(cout)] at `dst` (row = tap * cin + in), from the reference's stream order
+  // (groups, out, in, tap); `out0` / `out_n`: only outputs [out0, out0 + out_n) of the stream's `cout` land here, as
+  // columns 0.. (a FiLM's scale and shift halves are two matrices)
+  void dense(float* dst, const float*& w, int cin, int cout, int K, int groups, int out0 = 0, int out_n = -1, bool advance = true)
   {
-    const int row = wr_pad4(K * cin);
+    if (out_n < 0)
+      out_n = cout;
+    const int row = wr_pad4(out_n);
     const int opg = cout / groups, ipg = cin / groups;
+    const float* p = w;
     for (int g = 0; g < groups; g++)
       for (int i = 0; i < opg; i++)
         for (int j = 0; j < ipg; j++)
-          for (int k = 0; k < K; k++)
-            dst[(size_t)(g * opg + i) * row + (size_t)k * cin + (g * ipg + j)] = *(w++);
+          for (int k = 0; k < K; k++, p++)
+          {
+            const int o = g * opg + i - out0;
+            if (o >= 0 && o < out_n)
+              dst[(size_t)(k * cin + g * ipg + j) * row + o] = *p;
+          }
+    if (advance)
+      w = p;
   }
   void act_block(float* dst, const ActSpec& a, int rows_n)
   {
@@ -1341,7 +1352,7 @@ struct WrBuilder
         op.shape = wr_pair_shape(A.input_size, C);
         if (op.shape < 0)
           throw Unsupported("a rechannel of " + std::to_string(A.input_size) + " -> " + std::to_string(C));
-        const int off = reserve(C * wr_pad4(A.input_size));
+        const int off = reserve(A.input_size * wr_pad4(C));
         wr.ops.back().w = off;
         dense(&wr.blob[(size_t)off], w, A.input_size, C, 1, 1);
       }
@@ -1363,7 +1374,11 @@ struct WrBuilder
           throw Unsupported("a PReLU whose slope count does not divide the channel count");
         if (zc > 16 || C > kWrRegs || HO > kWrRegs || cond_dim > kWrRegs)
           throw Unsupported("a layer wider than the register files");
-        const int shape = wr_layer_shape(cond_dim, C, B, G, K, h1o);
+        int flags = gm == GATING_BLENDED ? (1 << 16) : 0;
+        for (int k = 0; k < FILM_COUNT; k++)
+          if (A.film[k].active && !(k == FILM_HEAD1X1_POST && !A.head1x1_active))
+            flags |= (1 << k) | (A.film[k].shift ? 1 << (8 + k) : 0);
+        const int shape = wr_layer_shape(cond_dim, C, B, G, K, h1o, flags, a1.type, G ? a2.type : (int)ACT_IDENTITY);
         if (shape < 0)
           throw Unsupported("layer shape cond=" + std::to_string(cond_dim) + " C=" + std::to_string(C) + " B=" + std::to_string(B)
                             + (G ? " gating" : "") + " K=" + std::to_string(K) + " head1x1=" + std::to_string(h1o));
@@ -1385,7 +1400,6 @@ struct WrBuilder
             d[L.h1_b + i] = *(w++);
         }
         const int dims[FILM_COUNT] = {C, zc, cond_dim, zc, zc, B, C, h1o};
-        int flags = gm == GATING_BLENDED ? (1 << 16) : 0;
         for (int k = 0; k < FILM_COUNT; k++)
         {
           bool on = A.film[k].active;
@@ -1393,15 +1407,17 @@ struct WrBuilder
             on = false;
           if (!on)
             continue;
-          const int D = dims[k], outc = (A.film[k].shift ? 2 : 1) * D;
-          // Conv1x1(cond -> outc, groups) + bias; rows [0, D) scale, [D, 2D) shift
-          dense(d + L.film[k], w, cond_dim, outc, 1, A.film[k].groups);
-          float* bias = d + L.film[k] + 2 * D * wr_pad4(cond_dim);
-          for (int i = 0; i < outc; i++)
-            bias[i] = *(w++);
-          flags |= 1 << k;
+          const int D = dims[k], outc = (A.film[k].shift ? 2 : 1) * D, D4 = wr_pad4(D);
+          // Conv1x1(cond -> outc, groups) + bias; outputs [0, D) scale, [D, 2D) shift: two matrices, two bias vectors
+          dense(d + L.film[k], w, cond_dim, outc, 1, A.film[k].groups, 0, D, !A.film[k].shift);
           if (A.film[k].shift)
-            flags |= 1 << (8 + k);
+            dense(d + L.film[k] + cond_dim * D4, w, cond_dim, outc, 1, A.film[k].groups, D, D);
+          float* bias = d + L.film[k] + 2 * cond_dim * D4;
+          for (int i = 0; i < D; i++)
+            bias[i] = *(w++);
+          if (A.film[k].shift)
+            for (int i = 0; i < D; i++)
+              bias[D4 + i] = *(w++);
         }
         act_block(d + L.act, a1, zc);
         if (G)
@@ -1426,12 +1442,12 @@ struct WrBuilder
         op.shape = wr_pair_shape(HO, A.head_size);
         if (op.shape < 0)
           throw Unsupported("a head rechannel of " + std::to_string(HO) + " -> " + std::to_string(A.head_size));
-        const int off = reserve(A.head_size * wr_pad4(HO) + wr_pad4(A.head_size));
+        const int off = reserve(HO * wr_pad4(A.head_size) + wr_pad4(A.head_size));
         wr.ops.back().w = off;
         dense(&wr.blob[(size_t)off], w, HO, A.head_size, 1, 1);
         if (A.head_bias)
           for (int i = 0; i < A.head_size; i++)
-            wr.blob[(size_t)off + (size_t)A.head_size * wr_pad4(HO) + i] = *(w++);
+            wr.blob[(size_t)off + (size_t)HO * wr_pad4(A.head_size) + i] = *(w++);
       }
     }
     const float head_scale = *(w++);
@@ -1447,10 +1463,13 @@ struct WrBuilder
 };
 } // namespace
 
-int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out)
+int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out, int flags, int act,
+                   int act2)
 {
-#define X(ID, COND, C, B, G, K, HO) \
-  if (cond == COND && channels == C && bottleneck == B && gating == G && kernel == K && head_out == HO) \
+  // `flags` as in WrOp::flags: bits 0-7 FiLM slots, 8-15 their shifts, bit 16 blended
+#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
+  if (cond == COND && channels == C && bottleneck == B && gating == G && kernel == K && head_out == HO \
+      && (FM < 0 || (flags == (FM | (SM << 8) | (BL << 16)) && act == A1 && act2 == A2))) \
     return ID;
   WR_LAYER_SHAPES(X)
 #undef X

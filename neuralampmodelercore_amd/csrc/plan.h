@@ -416,23 +416,35 @@ struct WrPlan
 };
 
 // The layer shapes kernel_wn_reg.hip instantiates — (id, condition size, channels, bottleneck, gating, kernel size,
-// head1x1 outputs; 0 = no head1x1) — and the (id, in, out) pairs of the array ops (rechannel, head rechannel).
+// head1x1 outputs (0 = no head1x1), FiLM mask, shift mask, blended, activation, secondary activation). A FiLM mask of
+// -1 leaves the FiLM slots, the blend and the activation types to run-time flags (wavefront-uniform branches); a
+// full description makes the layer one straight-line block the compiler can schedule weight reads across. The first
+// match wins: exact descriptions first.
 #define WR_LAYER_SHAPES(X) \
-  X(0, 8, 4, 4, false, 4, 4) /* wavenet_a2_max.nam: main array */ \
-  X(1, 1, 3, 6, true, 2, 6) /* its condition_dsp: array 0 (gated, grouped) */ \
-  X(2, 1, 4, 2, true, 3, 4) /* its condition_dsp: array 1 (blended / gated) */ \
-  X(3, 1, 4, 4, false, 3, 0) /* plain small stacks (no head1x1) */ \
-  X(4, 1, 3, 3, false, 3, 0) \
-  X(5, 1, 2, 2, false, 3, 0) \
-  X(6, 1, 8, 8, false, 3, 0) \
-  X(7, 3, 3, 3, false, 3, 0) /* example_models/wavenet_condition_dsp.nam */ \
-  X(8, 3, 4, 4, false, 3, 0) \
-  X(9, 3, 2, 2, false, 3, 0)
+  /* example_models/wavenet_a2_max.nam: main array; its condition_dsp's array 0 and the three layers of array 1 */ \
+  X(0, 8, 4, 4, false, 4, 4, 0xff, 0xff, 0, ACT_SOFTSIGN, ACT_IDENTITY) \
+  X(1, 1, 3, 6, true, 2, 6, 0xff, 0xff, 0, ACT_SILU, ACT_HARDSWISH) \
+  X(2, 1, 4, 2, true, 3, 4, 0xff, 0x00, 1, ACT_PRELU, ACT_LEAKYHARDTANH) \
+  X(3, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_PRELU, ACT_RELU) \
+  X(4, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_SOFTSIGN, ACT_SIGMOID) \
+  /* run-time flags: the same shapes with other FiLM sets / activations, plain small stacks (no head1x1), */ \
+  /* example_models/wavenet_condition_dsp.nam, multi-channel fixtures */ \
+  X(5, 8, 4, 4, false, 4, 4, -1, 0, 0, -1, -1) \
+  X(6, 1, 3, 6, true, 2, 6, -1, 0, 0, -1, -1) \
+  X(7, 1, 4, 2, true, 3, 4, -1, 0, 0, -1, -1) \
+  X(8, 1, 4, 4, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(9, 1, 3, 3, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(10, 1, 2, 2, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(11, 1, 8, 8, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(12, 3, 3, 3, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(13, 3, 4, 4, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(14, 3, 2, 2, false, 3, 0, -1, 0, 0, -1, -1)
 #define WR_PAIR_SHAPES(X) \
   X(0, 1, 3) X(1, 3, 4) X(2, 1, 4) X(3, 6, 4) X(4, 4, 8) X(5, 4, 1) X(6, 4, 4) X(7, 1, 2) X(8, 2, 1) X(9, 3, 1) X(10, 1, 8) \
   X(11, 8, 1) X(12, 8, 4) X(13, 4, 2) X(14, 2, 2) X(15, 3, 3) X(16, 8, 8) X(17, 2, 4) X(18, 3, 2) X(19, 6, 1) X(20, 1, 1) X(21, 2, 3) X(22, 4, 3) X(23, 3, 8) X(24, 2, 8)
 // id of a shape, -1 = not instantiated
-int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out);
+int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out, int flags, int act,
+                   int act2);
 int wr_pair_shape(int n_in, int n_out);
 // float count / offsets of a layer's weight block (shared by the planner and the kernel)
 struct WrLayerLayout
@@ -445,28 +457,30 @@ constexpr int wr_pad4(int n)
 }
 constexpr WrLayerLayout wr_layer_layout(int cond, int C, int B, bool gating, int K, int HO)
 {
+  // every matrix is stored TRANSPOSED, [in][pad4(out)]: one b128 read = the weights of four outputs for one input,
+  // i.e. two packed FMAs (v_pk_fma_f32: two outputs per instruction) with the input broadcast to both halves
   WrLayerLayout L{};
   const int zc = gating ? 2 * B : B;
   int o = 0;
-  L.conv = o;
-  o += zc * wr_pad4(K * C);
+  L.conv = o; // [K * C][pad4(zc)], row = tap * C + channel
+  o += K * C * wr_pad4(zc);
   L.conv_b = o;
   o += wr_pad4(zc);
-  L.mixin = o;
-  o += zc * wr_pad4(cond);
-  L.l1 = o;
-  o += C * wr_pad4(B);
+  L.mixin = o; // [cond][pad4(zc)]
+  o += cond * wr_pad4(zc);
+  L.l1 = o; // [B][pad4(C)]
+  o += B * wr_pad4(C);
   L.l1_b = o;
   o += wr_pad4(C);
-  L.h1 = o;
-  o += HO * wr_pad4(B);
+  L.h1 = o; // [B][pad4(HO)]
+  o += B * wr_pad4(HO);
   L.h1_b = o;
   o += wr_pad4(HO);
   const int dims[8] = {C, zc, cond, zc, zc, B, C, HO};
   for (int k = 0; k < 8; k++)
   {
-    L.film[k] = o; // [2 * D][pad4(cond)] then bias [pad4(2 * D)]
-    o += 2 * dims[k] * wr_pad4(cond) + wr_pad4(2 * dims[k]);
+    L.film[k] = o; // scale [cond][pad4(D)], shift [cond][pad4(D)], scale bias [pad4(D)], shift bias [pad4(D)]
+    o += 2 * cond * wr_pad4(dims[k]) + 2 * wr_pad4(dims[k]);
   }
   L.act = o;
   o += kWrActFloats;
