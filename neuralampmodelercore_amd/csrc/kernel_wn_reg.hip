@@ -20,6 +20,7 @@
 // FiLM slots and the shift are run-time flags (wavefront-uniform branches); activation types are run-time (one
 // dispatch per layer and activation, not per channel); grouped convs arrive expanded to dense from the planner.
 
+#include <cstddef>
 #include <type_traits>
 
 #include "device_common.h"
@@ -32,6 +33,19 @@ namespace
 using mf::f4;
 using mf::lds_ld4;
 using mf::lds_st4;
+
+// the fields of a WrOp the kernel reads, as scalars (a whole-struct copy would park the float and the padding in scratch)
+struct WrOpS
+{
+  int type, shape, w, hist, dil, flags, act, act2, n_out, scale_bits;
+  __device__ __forceinline__ float scale() const { return __builtin_bit_cast(float, scale_bits); }
+};
+__device__ __forceinline__ WrOpS wr_fetch(const WrOp* ops, int i)
+{
+  const int* p = reinterpret_cast<const int*>(ops + i);
+  static_assert(offsetof(WrOp, scale) == 44 && offsetof(WrOp, n_out) == 40 && offsetof(WrOp, act) == 28, "WrOp layout");
+  return WrOpS{p[0], p[1], p[2], p[3], p[5], p[6], p[7], p[8], p[10], p[11]};
+}
 
 struct WrRegs
 {
@@ -237,7 +251,7 @@ __device__ __forceinline__ void wr_act(int type, f2* v, const WrActP<N>& ap)
 // FM >= 0: FiLM mask / shift mask / blend / activation types are compile-time (one straight-line block); FM < 0: run-time
 // flags from the op
 template <int COND, int C, int B, bool G, int K, int HO, int FM, int SM, int BL, int A1, int A2>
-__device__ __forceinline__ void wr_layer(WrRegs& r, const WrOp& op, char* lds, int lane)
+__device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, int lane)
 {
   constexpr WrLayerLayout L = wr_layer_layout(COND, C, B, G, K, HO);
   constexpr int ZC = G ? 2 * B : B;
@@ -416,7 +430,7 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOp& op, char* lds, i
 // _LayerArray::process prologue, model.cpp:463-492: the head accumulator starts from the previous array's head output
 // (or zero), the rechannel 1x1 (no bias) maps the previous array's layer output (or the model input) to C channels
 template <int IN, int C>
-__device__ __forceinline__ void wr_array_begin(WrRegs& r, const WrOp& op, const char* lds)
+__device__ __forceinline__ void wr_array_begin(WrRegs& r, const WrOpS& op, const char* lds)
 {
   const bool first = (op.flags & 1) != 0;
 #pragma unroll
@@ -435,7 +449,7 @@ __device__ __forceinline__ void wr_array_begin(WrRegs& r, const WrOp& op, const 
 
 // head rechannel (kernel size 1), model.cpp:547-548: head output = W head accumulator (+ bias); W^T = [HI][pad4(HS)]
 template <int HI, int HS>
-__device__ __forceinline__ void wr_array_end(WrRegs& r, const WrOp& op, const char* lds)
+__device__ __forceinline__ void wr_array_end(WrRegs& r, const WrOpS& op, const char* lds)
 {
   WrMat<HS, HI> m;
   wr_ld(m, lds, (unsigned)op.w * 4u, true, (unsigned)op.w * 4u + (unsigned)(HI * wr_pad4(HS)) * 4u); // (a zero bias when none)
@@ -452,14 +466,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   char* const lds = lds_wr;
   const int lane = (int)threadIdx.x;
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
-  // weights -> LDS (the blob is a multiple of 4 floats)
-  for (int i = lane * 4; i < a.blob_floats; i += 256)
-    lds_st4(lds, (unsigned)i * 4u, *reinterpret_cast<const f4*>(a.blob + i));
-  // conv input histories <- state: row r = the last 64 frames of one channel of one layer's conv input
+  // weights -> LDS (the blob is a multiple of 4 floats) and conv input histories <- state (row r = the last 64 frames
+  // of one channel of one layer's conv input): eight requests in flight per round trip to memory
   float* const st = a.state + (long)stream * a.state_stride;
   const unsigned hist0 = (unsigned)a.hist_base * 4u;
-  for (int row = 0; row < a.n_rows; row++)
-    lds_st1(lds, hist0 + (unsigned)(row * kWrPitch + lane) * 4u, st[row * 64 + lane]);
+  for (int base = 0; base < a.blob_floats; base += 8 * 256)
+  {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+    {
+      const int i = base + u * 256 + lane * 4;
+      v[u] = i < a.blob_floats ? *reinterpret_cast<const f4*>(a.blob + i) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+    {
+      const int i = base + u * 256 + lane * 4;
+      if (i < a.blob_floats)
+        lds_st4(lds, (unsigned)i * 4u, v[u]);
+    }
+  }
+  for (int base = 0; base < a.n_rows; base += 8)
+  {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      v[u] = base + u < a.n_rows ? st[(base + u) * 64 + lane] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (base + u < a.n_rows)
+        lds_st1(lds, hist0 + (unsigned)((base + u) * kWrPitch + lane) * 4u, v[u]);
+  }
   const float* const in = a.in ? a.in + (long)stream * a.in_ch * a.io_stride : nullptr;
   float* const out = a.out ? a.out + (long)stream * a.out_ch * a.io_stride : nullptr;
 
@@ -474,10 +512,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       r.cond[c] = r.in[c]; // a net without condition_dsp (and the nested net itself) is conditioned on its input
       r.x[c] = r.hacc[c] = r.hout[c] = 0.0f;
     }
-    WrOp cur = a.ops[0];
+    WrOpS cur = wr_fetch(a.ops, 0);
     for (int oi = 0; oi < a.n_ops; oi++)
     {
-      const WrOp nxt = a.ops[min(oi + 1, a.n_ops - 1)]; // requested before this op runs
+      const WrOpS nxt = wr_fetch(a.ops, min(oi + 1, a.n_ops - 1)); // requested before this op runs
       switch (cur.type)
       {
         case WR_LAYER:
@@ -513,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         case WR_SET_COND:
 #pragma unroll
           for (int c = 0; c < kWrRegs; c++)
-            r.cond[c] = cur.scale * r.hout[c];
+            r.cond[c] = cur.scale() * r.hout[c];
           break;
         case WR_OUTPUT:
           if (out)
@@ -521,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int c = 0; c < kWrRegs; c++)
               if (c < cur.n_out && lane < n)
-                out[(long)c * a.io_stride + f0 + lane] = cur.scale * r.hout[c];
+                out[(long)c * a.io_stride + f0 + lane] = cur.scale() * r.hout[c];
           }
           break;
         default: __builtin_trap();
