@@ -1,6 +1,7 @@
 // kernel_lstm.hip — the LSTM kernels (lanes = streams; 16 streams per wavefront on the matrix cores) and the
 // per-stream state fill.
 #include "device_common.h"
+#include "il_common.h"
 
 namespace namhip
 {
@@ -468,6 +469,11 @@ __device__ __forceinline__ float tanh_like(float x)
 template <int NL, int NI, int NH, bool FAST>
 __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restrict__ blob, const LSTMArgs a)
 {
+  // The 64 steps of a block are unrolled (compile-time t): the input sample of step t is a DPP row broadcast out of
+  // the lane / register that loaded it (lane q of the row keeps frames q, q + 16, q + 32, q + 48), so neither an LDS
+  // read nor any address arithmetic sits in the step; the compiler folds the broadcasts (input, h of every unit) into
+  // the FMAs that consume them. The head is NOT computed in the step: the top layer's h goes to LDS (one store per
+  // step, immediate offset) and the 64 outputs are formed afterwards with lane = frame.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const int row = lane >> 4, q = lane & 15;
@@ -476,33 +482,29 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
   const bool live = s0 + row < a.n_streams;
   const int stream = live ? (a.stream_map ? a.stream_map[s0 + row] : s0 + row) : 0;
   constexpr int H = NH; // hidden units (compile time: no broadcast / FMA is spent on padding units)
-  const int in_ch = a.in_ch, out_ch = a.out_ch;
-  float* xin = lds; // [in_ch][4 rows][65]
-  float* yout = xin + in_ch * 4 * 65; // [out_ch][4 rows][65]
+  const int out_ch = a.out_ch;
   const bool unit = u < H;
+  float* const hs = lds; // [4 rows][NH][65]: the top layer's h of every step; then 64 + 64 floats nobody reads
+  // sigmoid(x) = 0.5 tanh(x / 2) + 0.5 for gates i, f, o; tanh for g: act(x) = A T(B x) + C. B (1 or 0.5: exact) is
+  // folded into the lane's weights.
+  const float cA = k == 2 ? 1.0f : 0.5f, cB = cA, cC = k == 2 ? 0.0f : 0.5f;
 
   // this lane's gate row of every layer: bias, input weights, recurrent weights (zero rows for the padding unit)
-  float wb[NL], wi[NL][NL == 1 ? NI : NH], wh[NL][NH];
+  constexpr int NW = NI > NH ? NI : NH;
+  float wb[NL], wi[NL][NW], wh[NL][NH];
 #pragma unroll
   for (int l = 0; l < NL; l++)
   {
     const int I = l == 0 ? NI : H;
     const float* __restrict__ W = blob + a.layer_w[l] + (size_t)(k * H + (unit ? u : 0)) * (I + H);
-    wb[l] = unit ? blob[a.layer_b[l] + k * H + u] : 0.0f;
+    wb[l] = unit ? cB * blob[a.layer_b[l] + k * H + u] : 0.0f;
 #pragma unroll
-    for (int e = 0; e < (NL == 1 ? NI : NH); e++)
-      wi[l][e] = (unit && e < I) ? W[e] : 0.0f;
+    for (int e = 0; e < NW; e++)
+      wi[l][e] = (unit && e < I) ? cB * W[e] : 0.0f;
 #pragma unroll
     for (int j = 0; j < NH; j++)
-      wh[l][j] = unit ? W[I + j] : 0.0f;
+      wh[l][j] = unit ? cB * W[I + j] : 0.0f;
   }
-  // head: lane q of the row computes output channel q
-  float hw[NH], hb = q < out_ch ? blob[a.head_b + q] : 0.0f;
-#pragma unroll
-  for (int j = 0; j < NH; j++)
-    hw[j] = q < out_ch ? blob[a.head_w + q * H + j] : 0.0f;
-  // sigmoid(x) = 0.5 tanh(x / 2) + 0.5 for gates i, f, o; tanh for g: act(x) = A T(B x) + C
-  const float cA = k == 2 ? 1.0f : 0.5f, cB = cA, cC = k == 2 ? 0.0f : 0.5f;
 
   float* st = a.state + (size_t)stream * a.state_stride;
   float h[NL], c[NL];
@@ -512,71 +514,58 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
     h[l] = (live && unit) ? st[(l * 2 + 0) * H + u] : 0.0f;
     c[l] = (live && unit) ? st[(l * 2 + 1) * H + u] : 0.0f;
   }
-  // h of every unit of every layer in every lane of the row (the recurrent operand of the next step)
-  float hbc[NL][NH];
-  auto bcast_units = [&](float (&dst)[NH], float v) {
-    dst[0] = lrow::row_bcast<0>(v);
-    if constexpr (NH > 1)
-      dst[1] = lrow::row_bcast<4>(v);
-    if constexpr (NH > 2)
-      dst[2] = lrow::row_bcast<8>(v);
-    if constexpr (NH > 3)
-      dst[3] = lrow::row_bcast<12>(v);
-  };
-#pragma unroll
-  for (int l = 0; l < NL; l++)
-    bcast_units(hbc[l], h[l]);
+  // where this lane's copy of the top h goes each step: gate lane 0 of a real unit -> its history row, else a dump slot
+  const unsigned hs_slot = (k == 0 && unit) ? (unsigned)((row * NH + u) * 65) : (unsigned)(4 * NH * 65 + lane);
 
   for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
   {
     const int nvalid = min(kBlock, a.n_frames - f0);
-    // coalesced input tile: row r = stream of position s0 + r, lane = frame
-    for (int ch = 0; ch < in_ch; ch++)
-      for (int r = 0; r < 4; r++)
-      {
-        const int s = __shfl(stream, r * 16);
-        float v = 0.0f;
-        if (a.in && s0 + r < a.n_streams && lane < nvalid)
-          v = a.in[((size_t)s * in_ch + ch) * a.io_stride + f0 + lane];
-        xin[(ch * 4 + r) * 65 + lane] = v;
-      }
-    // the row's input(s), read two steps ahead so that an LDS round trip is never on the recurrence
-    const int xrow = row * 65;
-    float xa[NI], xb[NI];
+    // lane q of the row: frames q, q + 16, q + 32, q + 48 of the row's stream (16 lanes = 64 contiguous bytes)
+    float xr[NI][4];
 #pragma unroll
     for (int e = 0; e < NI; e++)
-    {
-      xa[e] = xin[(min(e, in_ch - 1) * 4) * 65 + xrow];
-      xb[e] = xin[(min(e, in_ch - 1) * 4) * 65 + xrow + 1];
-    }
-    const int ybase = (min(q, out_ch - 1) * 4 + row) * 65;
-    for (int t = 0; t < nvalid; t++)
-    {
-      float xn[NI];
 #pragma unroll
-      for (int e = 0; e < NI; e++)
-        xn[e] = xin[(min(e, in_ch - 1) * 4) * 65 + xrow + min(t + 2, kBlock - 1)];
+      for (int j = 0; j < 4; j++)
+      {
+        const int t = q + 16 * j;
+        xr[e][j] = (a.in && live && t < nvalid) ? a.in[((size_t)stream * a.in_ch + e) * a.io_stride + f0 + t] : 0.0f;
+      }
+    auto step = [&](auto t_tag) {
+      constexpr int T = decltype(t_tag)::value;
+      if (T >= nvalid) // (wavefront-uniform)
+        return;
 #pragma unroll
       for (int l = 0; l < NL; l++)
       {
-        // gate pre-activation of this lane's row: b + Wi . in + Wh . h(t - 1)
+        // gate pre-activation of this lane's row (times B): b + Wi . in + Wh . h(t - 1)
         float pre = wb[l];
         if (l == 0)
         {
 #pragma unroll
           for (int e = 0; e < NI; e++)
-            pre = fmaf(wi[0][e], xa[e], pre);
+            pre = fmaf(wi[0][e], lrow::row_bcast<T % 16>(xr[e][T / 16]), pre);
         }
         else
         {
-#pragma unroll
-          for (int e = 0; e < NH; e++)
-            pre = fmaf(wi[l][e], hbc[l > 0 ? l - 1 : 0][e], pre); // the layer below's h(t), just broadcast
+          const float hb_ = h[l > 0 ? l - 1 : 0]; // the layer below's h(t)
+          pre = fmaf(wi[l][0], lrow::row_bcast<0>(hb_), pre);
+          if constexpr (NH > 1)
+            pre = fmaf(wi[l][1], lrow::row_bcast<4>(hb_), pre);
+          if constexpr (NH > 2)
+            pre = fmaf(wi[l][2], lrow::row_bcast<8>(hb_), pre);
+          if constexpr (NH > 3)
+            pre = fmaf(wi[l][3], lrow::row_bcast<12>(hb_), pre);
         }
-#pragma unroll
-        for (int j = 0; j < NH; j++)
-          pre = fmaf(wh[l][j], hbc[l][j], pre);
-        const float g = fmaf(cA, lrow::tanh_like<FAST>(cB * pre), cC);
+        // (two partial sums: the recurrent FMAs are the head of the step's dependency chain)
+        float rec = wh[l][0] * lrow::row_bcast<0>(h[l]);
+        if constexpr (NH > 1)
+          pre = fmaf(wh[l][1], lrow::row_bcast<4>(h[l]), pre);
+        if constexpr (NH > 2)
+          rec = fmaf(wh[l][2], lrow::row_bcast<8>(h[l]), rec);
+        if constexpr (NH > 3)
+          pre = fmaf(wh[l][3], lrow::row_bcast<12>(h[l]), pre);
+        pre += rec;
+        const float g = fmaf(cA, lrow::tanh_like<FAST>(pre), cC);
         // the unit's four gates meet in every lane of its quad
         const float gi = lrow::quad_bcast<0>(g), gf = lrow::quad_bcast<1>(g), gg = lrow::quad_bcast<2>(g),
                     go = lrow::quad_bcast<3>(g);
@@ -584,30 +573,31 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
         const float hn = go * lrow::tanh_like<FAST>(cn);
         c[l] = cn;
         h[l] = hn;
-        bcast_units(hbc[l], hn);
       }
-      // head: y = Wh . h_top(t) + bh (lane q = output channel q)
-      float y = hb;
-#pragma unroll
-      for (int j = 0; j < NH; j++)
-        y = fmaf(hw[j], hbc[NL - 1][j], y);
-      if (q < out_ch)
-        yout[ybase + t] = y;
-#pragma unroll
-      for (int e = 0; e < NI; e++)
-      {
-        xa[e] = xb[e];
-        xb[e] = xn[e];
-      }
-    }
+      hs[hs_slot + T] = h[NL - 1];
+    };
+    il::for_each_index(step, std::make_integer_sequence<int, kBlock>{});
+    // head: y[ch][t] = bh + Wh . h_top(t), lane = frame (coalesced stores)
     if (a.out)
-      for (int ch = 0; ch < out_ch; ch++)
-        for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++)
+      {
+        const int s = __shfl(stream, r * 16);
+        if (s0 + r >= a.n_streams)
+          break;
+        float hv[NH];
+#pragma unroll
+        for (int j = 0; j < NH; j++)
+          hv[j] = hs[(r * NH + j) * 65 + lane];
+        for (int ch = 0; ch < out_ch; ch++)
         {
-          const int s = __shfl(stream, r * 16);
-          if (s0 + r < a.n_streams && lane < nvalid)
-            a.out[((size_t)s * out_ch + ch) * a.io_stride + f0 + lane] = yout[(ch * 4 + r) * 65 + lane];
+          float y = blob[a.head_b + ch];
+#pragma unroll
+          for (int j = 0; j < NH; j++)
+            y = fmaf(blob[a.head_w + ch * H + j], hv[j], y);
+          if (lane < nvalid)
+            a.out[((size_t)s * out_ch + ch) * a.io_stride + f0 + lane] = y;
         }
+      }
   }
   if (live && unit && k == 0)
 #pragma unroll
@@ -708,7 +698,7 @@ hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream)
   if (!lstm_row_eligible(a))
     return hipErrorInvalidValue;
   const int n_blocks = (a.n_streams + 3) / 4;
-  const int lds_bytes = (a.in_ch + a.out_ch) * 4 * 65 * (int)sizeof(float);
+  const int lds_bytes = (4 * a.hidden * 65 + 128) * (int)sizeof(float); // h history of the block + the dump slots
 #define NAM_LSTM_ROW_H(NL, NI, NH) \
   if (a.fast) \
     hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, NH, true>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a); \
