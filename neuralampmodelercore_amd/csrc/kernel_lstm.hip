@@ -2,6 +2,7 @@
 // per-stream state fill.
 #include "device_common.h"
 #include "il_common.h"
+#include "persist_wave.h"
 
 namespace namhip
 {
@@ -506,6 +507,16 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
       wh[l][j] = unit ? cB * W[I + j] : 0.0f;
   }
 
+  // persistent session (persist_wave.h): blocks come from commands, not from a frame count
+  const bool pers = a.ps.ring != nullptr;
+  PersistWave pw;
+  unsigned cmd_off = 0;
+  if (pers && !pw.begin(a.ps, (int)blockIdx.x, cmd_off))
+  {
+    pw.leave(a.ps, (int)blockIdx.x); // nothing to do
+    return;
+  }
+
   float* st = a.state + (size_t)stream * a.state_stride;
   float h[NL], c[NL];
 #pragma unroll
@@ -517,9 +528,11 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
   // where this lane's copy of the top h goes each step: gate lane 0 of a real unit -> its history row, else a dump slot
   const unsigned hs_slot = (k == 0 && unit) ? (unsigned)((row * NH + u) * 65) : (unsigned)(4 * NH * 65 + lane);
 
-  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  for (int f0 = pers ? (int)cmd_off : 0;;)
   {
-    const int nvalid = min(kBlock, a.n_frames - f0);
+    const int nvalid = pers ? kBlock : min(kBlock, a.n_frames - f0);
+    if (pers)
+      pw.look_ahead(a.ps);
     // lane q of the row: frames q, q + 16, q + 32, q + 48 of the row's stream (16 lanes = 64 contiguous bytes)
     float xr[NI][4];
 #pragma unroll
@@ -528,7 +541,12 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
       for (int j = 0; j < 4; j++)
       {
         const int t = q + 16 * j;
-        xr[e][j] = (a.in && live && t < nvalid) ? a.in[((size_t)stream * a.in_ch + e) * a.io_stride + f0 + t] : 0.0f;
+        xr[e][j] = 0.0f;
+        if (a.in && live && t < nvalid)
+        {
+          const float* px = a.in + ((size_t)stream * a.in_ch + e) * a.io_stride + f0 + t;
+          xr[e][j] = pers ? persist_in(px) : *px;
+        }
       }
     auto step = [&](auto t_tag) {
       constexpr int T = decltype(t_tag)::value;
@@ -598,6 +616,18 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
             a.out[((size_t)s * out_ch + ch) * a.io_stride + f0 + lane] = y;
         }
       }
+    if (pers)
+    {
+      if (!pw.next(a.ps, (int)blockIdx.x, cmd_off))
+        break; // ring empty: leave
+      f0 = (int)cmd_off;
+    }
+    else
+    {
+      f0 += kBlock;
+      if (f0 >= a.n_frames)
+        break;
+    }
   }
   if (live && unit && k == 0)
 #pragma unroll
@@ -606,6 +636,8 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
       st[(l * 2 + 0) * H + u] = h[l];
       st[(l * 2 + 1) * H + u] = c[l];
     }
+  if (pers)
+    pw.leave(a.ps, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

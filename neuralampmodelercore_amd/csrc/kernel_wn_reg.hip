@@ -25,6 +25,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "persist_wave.h"
 
 namespace namhip
 {
@@ -466,6 +467,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   char* const lds = lds_wr;
   const int lane = (int)threadIdx.x;
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  // persistent session (persist_wave.h): blocks come from commands, not from a frame count
+  const bool pers = a.ps.ring != nullptr;
+  PersistWave pw;
+  unsigned cmd_off = 0;
+  if (pers && !pw.begin(a.ps, (int)blockIdx.x, cmd_off))
+  {
+    pw.leave(a.ps, (int)blockIdx.x); // nothing to do
+    return;
+  }
   // weights -> LDS (the blob is a multiple of 4 floats) and conv input histories <- state (row r = the last 64 frames
   // of one channel of one layer's conv input): eight requests in flight per round trip to memory
   float* const st = a.state + (long)stream * a.state_stride;
@@ -501,14 +511,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const float* const in = a.in ? a.in + (long)stream * a.in_ch * a.io_stride : nullptr;
   float* const out = a.out ? a.out + (long)stream * a.out_ch * a.io_stride : nullptr;
 
-  for (int f0 = 0; f0 < a.n_frames; f0 += kBlock)
+  for (int f0 = pers ? (int)cmd_off : 0;;)
   {
-    const int n = min(kBlock, a.n_frames - f0);
+    const int n = pers ? kBlock : min(kBlock, a.n_frames - f0);
+    if (pers)
+      pw.look_ahead(a.ps);
     WrRegs r;
 #pragma unroll
     for (int c = 0; c < kWrRegs; c++)
     {
-      r.in[c] = (in && c < a.in_ch && lane < n) ? in[(long)c * a.io_stride + f0 + lane] : 0.0f;
+      r.in[c] = 0.0f;
+      if (in && c < a.in_ch && lane < n)
+        r.in[c] = pers ? persist_in(in + (long)c * a.io_stride + f0 + lane) : in[(long)c * a.io_stride + f0 + lane];
       r.cond[c] = r.in[c]; // a net without condition_dsp (and the nested net itself) is conditioned on its input
       r.x[c] = r.hacc[c] = r.hout[c] = 0.0f;
     }
@@ -573,9 +587,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       const float v = lds_ld1(lds, rb + (unsigned)(lane + n) * 4u);
       lds_st1(lds, rb + (unsigned)lane * 4u, v);
     }
+    if (pers)
+    {
+      if (!pw.next(a.ps, (int)blockIdx.x, cmd_off))
+        break; // ring empty: leave
+      f0 = (int)cmd_off;
+    }
+    else
+    {
+      f0 += kBlock;
+      if (f0 >= a.n_frames)
+        break;
+    }
   }
   for (int row = 0; row < a.n_rows; row++)
     st[row * 64 + lane] = lds_ld1(lds, hist0 + (unsigned)(row * kWrPitch + lane) * 4u);
+  if (pers)
+    pw.leave(a.ps, (int)blockIdx.x);
 }
 
 hipError_t launch_wn_reg(const WrArgs& a, int n_streams, int lds_bytes, hipStream_t stream)

@@ -8,6 +8,19 @@
 namespace namhip
 {
 
+// Persistent session of a one-wavefront-per-workgroup kernel (persist_wave.h); ring == nullptr: an ordinary launch
+struct PersistArgs
+{
+  unsigned long long* ring = nullptr; // commands: (seq << 32) | frame offset
+  int ring_mask = 0; // ring size - 1
+  unsigned* cons = nullptr; // device memory: commands consumed per workgroup (where its next launch resumes)
+  unsigned* prog = nullptr; // host-mapped: progress (every 16 commands)
+  unsigned* done = nullptr; // host-mapped: consumed count | "left" bit, written when the workgroup leaves
+  long long seq0 = -1; // >= 0: every workgroup has consumed exactly this many commands (cons is not read) ...
+  unsigned long long cmd0 = 0; // ... and this is the next command (the ring is not read for it)
+  int grace = 0; // ticks (100 MHz) a fresh launch looks for its first command before it leaves again
+};
+
 // I/O convention for every kernel: planar float32 in HBM,
 //   in [stream][in_ch ][io_stride]   out [stream][out_ch][io_stride]
 // of which frames [0, n_frames) are processed by this launch (the caller may point `in`/`out` into
@@ -88,6 +101,7 @@ struct LSTMArgs
   int mf_off, mf_floats, mf_nt, mf_head_tiles, mf_head_bias, mf_lds_bytes;
   int mf_layer_tiles[16];
   int mf_layer_bias[16];
+  PersistArgs ps; // nam_lstm_row_kernel only
 };
 
 struct WrArgs // nam_wn_reg_kernel (plan.h: WrPlan)
@@ -106,6 +120,7 @@ struct WrArgs // nam_wn_reg_kernel (plan.h: WrPlan)
   int in_ch, out_ch;
   int hist_base; // LDS float offset of history row 0 (behind the weights)
   int n_rows; // history rows: the sum of the layers' channel counts
+  PersistArgs ps;
 };
 
 hipError_t launch_wn_reg(const WrArgs& a, int n_streams, int lds_bytes, hipStream_t stream);

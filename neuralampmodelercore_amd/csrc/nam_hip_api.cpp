@@ -140,7 +140,9 @@ struct PersistSession
   const float* in_base = nullptr;
   float* out_base = nullptr;
   long stride = 0;
-  int n_wg = 0;
+  int n_wg = 0; // workgroups of the session's launch
+  int kind = -1; // PersistKind
+  int done_off = 0; // h_words: [0, done_off) progress words, [done_off, 2 done_off) completion words
 };
 } // namespace
 
@@ -166,6 +168,7 @@ struct nam_hip_batch
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
   PersistSession ps;
   bool ps_launching = false; // launch_group is starting the session's resident launch
+  int n_cus = 0; // compute units of the device
 };
 
 namespace
@@ -292,13 +295,31 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 
 // Name of the __global__ function launch_group runs for this group (what rocprofv3 --kernel-trace reports, without
 // template arguments): lets callers attribute measurements to the right kernel.
-bool persist_eligible(const nam_hip_batch* b);
+enum PersistKind : int
+{
+  PERSIST_NONE = -1,
+  PERSIST_A1_P2 = 0, // nam_a1_p2_kernel: one workgroup (4 wavefronts, most of a CU's LDS) per stream
+  PERSIST_WN_REG = 1, // nam_wn_reg_kernel: one wavefront per stream
+  PERSIST_LSTM_ROW = 2 // nam_lstm_row_kernel: one wavefront per four streams
+};
+int persist_kind(const nam_hip_batch* b);
+int persist_family(const nam_hip_batch* b, const WidthGroup& g);
+inline bool persist_eligible(const nam_hip_batch* b)
+{
+  return persist_kind(b) != PERSIST_NONE;
+}
 
 const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
 {
   const Plan& p = *g.plan;
-  if (b->ps.enabled && persist_eligible(b))
-    return "nam_a1_p2_kernel"; // persistent block mode
+  if (b->ps.enabled)
+    switch (persist_kind(b)) // persistent block mode
+    {
+      case PERSIST_A1_P2: return "nam_a1_p2_kernel";
+      case PERSIST_WN_REG: return "nam_wn_reg_kernel";
+      case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
+      default: break;
+    }
   if (p.arch == ARCH_WAVENET)
   {
     switch (pick_kernel(b, g))
@@ -317,6 +338,23 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
   if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
     return (L.input_size <= 4 && L.n_layers <= 2 && L.mf_nt <= 6) ? "nam_lstm_mfma_reg_kernel" : "nam_lstm_mfma_kernel";
   return "nam_lstm_kernel";
+}
+
+// the session's side of a persistent launch of a one-wavefront-per-workgroup kernel (kernels.h: PersistArgs)
+PersistArgs persist_args(const nam_hip_batch* b)
+{
+  PersistArgs pa;
+  if (!b->ps_launching)
+    return pa;
+  pa.ring = b->ps.d_ring;
+  pa.ring_mask = (int)kPRing - 1;
+  pa.cons = b->ps.d_cons;
+  pa.prog = b->ps.d_words;
+  pa.done = b->ps.d_words + b->ps.done_off;
+  pa.seq0 = b->ps.seq0;
+  pa.cmd0 = b->ps.cmd0;
+  pa.grace = b->ps.grace;
+  return pa;
 }
 
 // Launch one group's kernel over `n` streams given by `d_map` (nullptr = streams 0..n-1).
@@ -355,6 +393,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.out_ch = p.out_channels;
       a.hist_base = (int)p.wr.blob.size();
       a.n_rows = p.wr.state_floats / kBlock;
+      a.ps = persist_args(b);
       NAM_HIP_CHECK(launch_wn_reg(a, n, p.wr.lds_bytes, s));
       return NAM_HIP_OK;
     }
@@ -410,7 +449,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_ring_mask = (int)kPRing - 1;
           a.p_cons = b->ps.d_cons;
           a.p_prog = b->ps.d_words;
-          a.p_done = b->ps.d_words + n;
+          a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
@@ -516,7 +555,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
     // AUTO: small cells (hidden <= 4) one gate row per lane, else the matrix-core kernel (16 streams per wavefront);
     // NAM_HIP_KERNEL_A1_MFMA forces the matrix-core kernel; NAM_HIP_KERNEL_GENERIC: lanes = streams
     if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && lstm_row_eligible(a))
+    {
+      a.ps = persist_args(b);
       NAM_HIP_CHECK(launch_lstm_row(a, s));
+    }
     else if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
       NAM_HIP_CHECK(launch_lstm_mfma(a, s));
     else
@@ -561,12 +603,38 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
 
 // ---- persistent block mode -------------------------------------------------------------------------------------
 constexpr int kGraceUs = 40; // how long a fresh launch looks for the doorbell it was started for
-bool persist_eligible(const nam_hip_batch* b)
+// the state layout the session's kernel keeps (WaveNets only)
+int persist_family(const nam_hip_batch* b, const WidthGroup& g)
+{
+  return persist_kind(b) == PERSIST_WN_REG ? 2 : state_family_of(*g.plan, NAM_HIP_KERNEL_A1_IL);
+}
+
+// Which kernel a persistent session of this batch would run (PERSIST_NONE: the mode does not apply). Every workgroup
+// of the session's launch must be on the chip at once — a workgroup that is waiting for a slot consumes nothing while
+// the resident ones keep the ring busy — hence the stream limits.
+int persist_kind(const nam_hip_batch* b)
 {
   const WidthGroup& g = b->groups[b->model->full_width];
-  return b->ps.enabled && !b->il_generic && g.plan->arch == ARCH_WAVENET && g.plan->a1.valid && g.plan->a1.il_ok
-         && g.plan->a1.p2_ok && (int)g.streams.size() == b->n_streams && g.d_map == nullptr
-         && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL);
+  if (!b->ps.enabled || (int)g.streams.size() != b->n_streams || g.d_map != nullptr)
+    return PERSIST_NONE;
+  const int cus = std::max(b->n_cus, 1);
+  if (g.plan->arch == ARCH_WAVENET)
+  {
+    if (!b->il_generic && g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= cus
+        && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL))
+      return PERSIST_A1_P2;
+    if (g.d_wr_ops && pick_kernel(b, g) == NAM_HIP_KERNEL_WN_REG && b->n_streams <= 4 * cus) // one wavefront per SIMD
+      return PERSIST_WN_REG;
+    return PERSIST_NONE;
+  }
+  if (g.plan->arch == ARCH_LSTM && b->kernel == NAM_HIP_KERNEL_AUTO)
+  {
+    const LSTMPlan& L = g.plan->lstm;
+    if (L.hidden >= 1 && L.hidden <= 4 && L.n_layers >= 1 && L.n_layers <= 2 && L.input_size >= 1 && L.input_size <= 2
+        && L.in_ch == L.input_size && L.out_ch >= 1 && L.out_ch <= 16 && (b->n_streams + 3) / 4 <= 8 * cus)
+      return PERSIST_LSTM_ROW;
+  }
+  return PERSIST_NONE;
 }
 
 // (Re)starts the session's launch: every workgroup resumes behind the commands it has consumed so far and runs until
@@ -590,12 +658,13 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   // the workgroups set the top bit of their completion word when they leave: cleared here, "all set" = no launch of
   // the session is running any more (cheaper for the host to look at than hipStreamQuery on a busy stream)
   for (int w = 0; w < ps.n_wg; w++)
-    __atomic_and_fetch(&ps.h_words[ps.n_wg + w], 0x7fffffffu, __ATOMIC_RELAXED);
+    __atomic_and_fetch(&ps.h_words[ps.done_off + w], 0x7fffffffu, __ATOMIC_RELAXED);
   ps.outstanding = true;
   const int keep = b->kernel;
-  b->kernel = NAM_HIP_KERNEL_A1_IL;
+  if (ps.kind == PERSIST_A1_P2)
+    b->kernel = NAM_HIP_KERNEL_A1_IL;
   b->ps_launching = true;
-  const int rc = launch_group(b, g, nullptr, ps.n_wg, ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream);
+  const int rc = launch_group(b, g, nullptr, b->n_streams, ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream);
   b->ps_launching = false;
   b->kernel = keep;
   return rc;
@@ -618,7 +687,7 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
     unsigned lo = ~0u, all_left = 0x80000000u;
     for (int w = 0; w < ps.n_wg; w++)
     {
-      const unsigned v = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_ACQUIRE);
+      const unsigned v = __atomic_load_n(&ps.h_words[ps.done_off + w], __ATOMIC_ACQUIRE);
       lo = std::min(lo, v & 0x7fffffffu);
       all_left &= v;
     }
@@ -690,10 +759,28 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
     ps.seq = 0; // (sequence numbers run on across sessions: no ring slot ever needs clearing)
   }
+  const int kind = persist_kind(b);
+  if (kind != ps.kind)
+  {
+    // another kernel, another workgroup count: every workgroup of the new shape starts behind the commands consumed
+    // so far (nothing of the old session is in flight: a session ends with a flush)
+    std::vector<unsigned> at((size_t)b->n_streams, ps.seq);
+    NAM_HIP_CHECK(hipMemcpy(ps.d_cons, at.data(), at.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    for (int w = 0; w < b->n_streams; w++)
+    {
+      ps.h_words[w] = ps.seq;
+      ps.h_words[b->n_streams + w] = ps.seq | 0x80000000u;
+    }
+    ps.kind = kind;
+    ps.flushed = ps.seq;
+    ps.flushed_valid = true;
+    ps.outstanding = false;
+  }
   ps.in_base = d_in;
   ps.out_base = d_out;
   ps.stride = stride;
-  ps.n_wg = n;
+  ps.done_off = b->n_streams;
+  ps.n_wg = kind == PERSIST_LSTM_ROW ? (n + 3) / 4 : n;
   ps.active = true;
   ps.need_order = true;
   return NAM_HIP_OK;
@@ -731,7 +818,7 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
       unsigned lo = ~0u, all_left = 0x80000000u;
       for (int w = 0; w < ps.n_wg; w++)
       {
-        const unsigned d = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_RELAXED);
+        const unsigned d = __atomic_load_n(&ps.h_words[ps.done_off + w], __ATOMIC_RELAXED);
         lo = std::min(lo, std::max(__atomic_load_n(&ps.h_words[w], __ATOMIC_RELAXED), d & 0x7fffffffu));
         all_left &= d;
       }
@@ -758,7 +845,7 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
     idle = uniform = true;
     for (int w = 0; w < ps.n_wg && idle; w++)
     {
-      const unsigned v = __atomic_load_n(&ps.h_words[ps.n_wg + w], __ATOMIC_ACQUIRE);
+      const unsigned v = __atomic_load_n(&ps.h_words[ps.done_off + w], __ATOMIC_ACQUIRE);
       idle = (v & 0x80000000u) != 0;
       uniform = uniform && v == left;
     }
@@ -800,7 +887,8 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   ps.flushed_valid = false;
   ps.last_caller = caller;
   WidthGroup& g = b->groups[b->model->full_width];
-  g.state_family = state_family_of(*g.plan, NAM_HIP_KERNEL_A1_IL);
+  if (g.plan->arch == ARCH_WAVENET)
+    g.state_family = persist_family(b, g);
   return NAM_HIP_OK;
 }
 
@@ -1034,6 +1122,7 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
     return fail(NAM_HIP_ERR_DEVICE, "nam_hip_batch_create: out of host memory");
   b->model = model;
   b->device = device;
+  (void)hipDeviceGetAttribute(&b->n_cus, hipDeviceAttributeMultiprocessorCount, device);
   {
     const char* e = std::getenv("NAM_HIP_IL_GENERIC");
     b->il_generic = e && e[0] == '1';
@@ -1199,10 +1288,10 @@ int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float*
     batch->last_ext_stream = s;
   if (batch->ps.enabled && persist_eligible(batch))
   {
-    // fresh state has the layout either kernel family writes; anything else must already be the A1 family's
+    // fresh state has the layout any kernel family writes; anything else must already be the session kernel's
     WidthGroup& g0 = batch->groups[batch->model->full_width];
-    if (g0.state_family >= 0 && g0.state_family != state_family_of(*g0.plan, NAM_HIP_KERNEL_A1_IL))
-      return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "persistent mode: the state was written by the generic kernel; reset first");
+    if (g0.plan->arch == ARCH_WAVENET && g0.state_family >= 0 && g0.state_family != persist_family(batch, g0))
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "persistent mode: the state was written in another kernel family's layout; reset first");
     const int rc = persist_submit(batch, d_in, d_out, n_frames, (long)frame_stride, s);
     if (rc <= 0)
       return rc; // submitted (0) or failed (< 0)

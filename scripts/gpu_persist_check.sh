@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 TAG=${1:-ps1}
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "persistent or interleaved" > gpurun_out/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_$TAG.log
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "persistent or interleaved or lstm or register_resident" > gpurun_out/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_$TAG.log
 for args in "--persistent 1 --steps 20 --warmup 5" "--persistent 1 --steps 2000 --warmup 200" "--persistent 0 --steps 2000 --warmup 200" "--persistent 1 --kernel a1_il --steps 2000 --warmup 200" "--persistent 0 --kernel a1_il --steps 2000 --warmup 200"; do
   timeout 300 python bench.py $args --no-cpu-baseline 2>gpurun_out/bench_ps_$TAG.err | python -c "
 import sys, json

@@ -863,11 +863,15 @@ def test_persistent_block_mode_matches_oracle(nam_lib, oracle):
     nam = nam_lib
     n_streams, block, nb = 7, 64, 12
     x = stream_bank(n_streams, block * nb + 40, seed=321)
-    for name in ("wavenet_a1_standard", "synth_a1_feather"):
+    # the three kernels that speak the session protocol: nam_a1_p2_kernel (a workgroup per stream), nam_wn_reg_kernel (a
+    # wavefront per stream), nam_lstm_row_kernel (a wavefront per four streams: 7 streams = a ragged last workgroup)
+    for name, kname in (("wavenet_a1_standard", "nam_a1_p2_kernel"), ("synth_a1_feather", "nam_a1_p2_kernel"),
+                        ("wavenet_a2_max", "nam_wn_reg_kernel"), ("lstm", "nam_lstm_row_kernel"),
+                        ("synth_lstm_h4x2", "nam_lstm_row_kernel")):
         model = nam.get_dsp(model_path(name), fast_tanh=True)
         refs = [_oracle_run(oracle, name, x[s], block, True) for s in range(n_streams)]
         b = model.batch(n_streams, block)
-        assert b.set_persistent(True) and b.kernel_name() == "nam_a1_p2_kernel"
+        assert b.set_persistent(True) and b.kernel_name() == kname
         b.Reset(prewarm=True)
         xd = torch.from_numpy(x[:, None, :]).cuda()
         yd = torch.zeros_like(xd)
