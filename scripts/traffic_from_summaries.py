@@ -1,0 +1,69 @@
+"""Build profiles/traffic.json from the round's committed rocprofv3 summaries (profiles/rNN/rocprofv3_summary_*.txt,
+written by scripts/gpu_profile_config.sh + scripts/summarize_prof.py). One entry per (kernel function, model, streams,
+block, launch); bench.py looks its run up by exactly that key.
+
+HBM bytes per launch = 2 x FETCH_SIZE (KB; gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md, HBM
+section) + WRITE_SIZE (KB), each from its own --pmc pass."""
+import json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNS = [  # (summary tag, kernel function, model, streams, launch)
+    ("r02", "c2_p2", "nam_a1_p2_kernel", "wavenet_a1_standard", 256, "block"),
+    ("r02", "c3_lstm_row", "nam_lstm_row_kernel", "lstm", 1024, "block"),
+    ("r02", "c4_wn_reg", "nam_wn_reg_kernel", "wavenet_a2_max", 512, "block"),
+    ("r02", "c4_generic", "nam_generic_kernel", "wavenet_a2_max", 512, "block"),
+    ("r02", "c2_valu", "nam_a1_kernel", "wavenet_a1_standard", 256, "block"),
+]
+
+
+def counters(path, kernel):
+    """{counter: per-dispatch average} of the kernel's block-launch instantiation (the one with the most dispatches)."""
+    best, out = 0, {}
+    for line in open(path):
+        if kernel not in line or "dispatches=" not in line:
+            continue
+        n = int(re.search(r"dispatches=(\d+)", line).group(1))
+        vals = {k: float(v) for k, v in re.findall(r"(\w+)=([0-9.e+]+)", line) if k != "dispatches"}
+        if n >= best:
+            if n > best:
+                out = {}
+            best = n
+            out.update(vals)
+    avg_ns = None
+    for line in open(path):
+        if kernel in line and "avg_ns=" in line:
+            c = int(re.search(r"calls=(\d+)", line).group(1))
+            if c >= best * 0.9:
+                avg_ns = float(re.search(r"avg_ns=([0-9.]+)", line).group(1))
+    return best, out, avg_ns
+
+
+entries = [json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"][0]]  # round 1: a1_mfma (kept)
+entries = [e for e in entries if e.get("kernel") == "a1_mfma"]
+for e in entries:
+    e["kernel"] = "nam_a1_mfma_kernel"
+    e.setdefault("model", "wavenet_a1_standard")
+for rnd, tag, kernel, model, streams, launch in RUNS:
+    path = os.path.join(ROOT, "profiles", rnd, f"rocprofv3_summary_{tag}.txt")
+    n, c, avg_ns = counters(path, kernel)
+    if not n:
+        print("no counters for", tag, file=sys.stderr)
+        continue
+    fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+    entries.append({
+        "kernel": kernel, "model": model, "streams": streams, "block": 64, "launch": launch,
+        "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
+        "kernel_cycles": c.get("GRBM_GUI_ACTIVE"),
+        "lds_idx_active_cycles": c.get("SQ_LDS_IDX_ACTIVE"),
+        "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
+        "insts_per_launch": {k: c.get("SQ_INSTS_" + k) for k in ("VALU", "SALU", "SMEM", "LDS", "VMEM_RD", "VMEM_WR")},
+        "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32"),
+        "rocprof_avg_launch_us": None if avg_ns is None else round(avg_ns / 1e3, 2),
+        "note": f"profiles/{rnd}/rocprofv3_summary_{tag}.txt ({n} dispatches, one launch per 64-frame step): FETCH_SIZE {fetch_kb:,.0f} KB x2 "
+                f"(gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE {write_kb:,.0f} KB, separate "
+                "--pmc passes; the persistent block mode runs the same kernel body per command",
+        "lds_note": "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE, per launch (kernel-trace only)",
+    })
+json.dump({"entries": entries}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+for e in entries:
+    print(e["kernel"], e["model"], e["streams"], e["hbm_bytes_per_launch"], e.get("rocprof_avg_launch_us"), e.get("insts_per_launch"))
