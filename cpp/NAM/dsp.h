@@ -69,6 +69,35 @@ struct BatchDeleter
 };
 } // namespace detail
 
+namespace detail
+{
+// the thread-local default newly constructed DSP objects copy (reference NAM/dsp.cpp:20)
+inline bool& prewarm_on_reset_default()
+{
+  static thread_local bool value = true;
+  return value;
+}
+} // namespace detail
+
+// Scoped change of that default (reference NAM/dsp.h:40-56): objects constructed on this thread while it lives take the
+// scoped value as their instance setting; existing objects are untouched.
+class ScopedPrewarmOnResetDefault
+{
+public:
+  explicit ScopedPrewarmOnResetDefault(const bool prewarmOnReset)
+  : mPreviousPrewarmOnReset(detail::prewarm_on_reset_default())
+  {
+    detail::prewarm_on_reset_default() = prewarmOnReset;
+  }
+  ~ScopedPrewarmOnResetDefault() { detail::prewarm_on_reset_default() = mPreviousPrewarmOnReset; }
+  ScopedPrewarmOnResetDefault(const ScopedPrewarmOnResetDefault&) = delete;
+  ScopedPrewarmOnResetDefault& operator=(const ScopedPrewarmOnResetDefault&) = delete;
+  bool PreviousPrewarmOnReset() const { return mPreviousPrewarmOnReset; }
+
+private:
+  bool mPreviousPrewarmOnReset;
+};
+
 class SlimmableModel // reference NAM/slimmable.h:13-29
 {
 public:
@@ -83,6 +112,7 @@ public:
   DSP(std::shared_ptr<nam_hip_model> model, int device = 0)
   : mModel(std::move(model))
   , mDevice(device)
+  , mPrewarmOnReset(detail::prewarm_on_reset_default())
   {
     detail::check(nam_hip_model_get_info(mModel.get(), &mInfo));
     mInputLevel = mInfo.input_level;
@@ -107,8 +137,8 @@ public:
     if (!mBatch)
       SetMaxBufferSize(num_frames > NAM_DEFAULT_MAX_BUFFER_SIZE ? num_frames : NAM_DEFAULT_MAX_BUFFER_SIZE);
     const int ic = NumInputChannels(), oc = NumOutputChannels();
-    mIn.resize((size_t)ic * num_frames);
-    mOut.resize((size_t)oc * num_frames);
+    if (num_frames > mMaxBufferSize) // (the staging buffers are sized in SetMaxBufferSize: no allocation on the audio path)
+      throw std::runtime_error("process: num_frames exceeds the max buffer size set by Reset()");
     for (int c = 0; c < ic; c++)
       for (int i = 0; i < num_frames; i++)
         mIn[(size_t)c * num_frames + i] = input[c][i];
@@ -181,6 +211,8 @@ protected:
     detail::check(nam_hip_batch_create(mModel.get(), mDevice, NumStreams(), maxBufferSize, &b));
     mBatch.reset(b);
     mMaxBufferSize = maxBufferSize;
+    mIn.assign((size_t)NumInputChannels() * NumStreams() * maxBufferSize, NAM_SAMPLE(0));
+    mOut.assign((size_t)NumOutputChannels() * NumStreams() * maxBufferSize, NAM_SAMPLE(0));
   }
   virtual int NumStreams() const { return 1; }
 
@@ -191,7 +223,7 @@ protected:
   int mMaxBufferSize = 0;
   bool mHaveExternalSampleRate = false;
   double mExternalSampleRate = -1.0;
-  std::atomic<bool> mPrewarmOnReset{true};
+  std::atomic<bool> mPrewarmOnReset;
   bool mHasLoudness = false, mHasInputLevel = false, mHasOutputLevel = false;
   double mLoudness = 0.0, mInputLevel = 0.0, mOutputLevel = 0.0;
   std::vector<NAM_SAMPLE> mIn, mOut;

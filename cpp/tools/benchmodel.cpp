@@ -1,7 +1,15 @@
 // benchmodel — same protocol and command line as the reference's tools/benchmodel.cpp:23-143
 // (2 s of audio in 64-frame buffers of zeros, fast tanh ON by default, prints milliseconds), running
-// through the C++ adapter -> C ABI -> HIP kernels. Extra: --streams N benchmarks the batched path.
+// through the C++ adapter -> C ABI -> HIP kernels. Extras: --streams N benchmarks the batched path; the per-buffer round
+// trip (host buffer in -> host buffer out) is printed as min / p50 / p99 / max; --count-allocs counts heap allocations
+// made during the timed loop, by the module that asked for them (the reference's real-time-safety check,
+// tools/test/allocation_tracking.cpp:21-90, asserts zero inside process(); here the adapter and libnam_hip.so must make
+// none — what the HIP runtime does inside a launch is reported separately).
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <dlfcn.h>
+#include <new>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -16,19 +24,76 @@ using std::chrono::milliseconds;
 
 #define AUDIO_BUFFER_SIZE 64
 
+// ---- allocation accounting (operator new of the whole process resolves here) ----------------------------------------
+namespace
+{
+std::atomic<bool> g_counting{false};
+std::atomic<long> g_ours{0}, g_cxx{0}, g_hip{0}, g_other{0};
+void note_allocation(void* caller)
+{
+  if (!g_counting.load(std::memory_order_relaxed))
+    return;
+  Dl_info info{};
+  const char* name = (dladdr(caller, &info) && info.dli_fname) ? info.dli_fname : "";
+  if (std::strstr(name, "libnam_hip") || std::strstr(name, "benchmodel"))
+    g_ours++;
+  else if (std::strstr(name, "libstdc++"))
+    g_cxx++; // (std::string / iostream internals: the caller behind them is not visible from here)
+  else if (std::strstr(name, "libamdhip") || std::strstr(name, "libhsa") || std::strstr(name, "librocprofiler") || std::strstr(name, "libamd_comgr"))
+    g_hip++;
+  else
+    g_other++;
+}
+} // namespace
+void* operator new(std::size_t n)
+{
+  note_allocation(__builtin_return_address(0));
+  if (void* p = std::malloc(n ? n : 1))
+    return p;
+  throw std::bad_alloc();
+}
+void* operator new[](std::size_t n)
+{
+  note_allocation(__builtin_return_address(0));
+  if (void* p = std::malloc(n ? n : 1))
+    return p;
+  throw std::bad_alloc();
+}
+void operator delete(void* p) noexcept { std::free(p); }
+void operator delete[](void* p) noexcept { std::free(p); }
+void operator delete(void* p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void* p, std::size_t) noexcept { std::free(p); }
+
+namespace
+{
+void report(std::vector<double>& us, bool count_allocs)
+{
+  std::sort(us.begin(), us.end());
+  auto pct = [&](double q) { return us[std::min(us.size() - 1, (size_t)(q * (us.size() - 1) + 0.5))]; };
+  std::cout << "round trip per buffer (us): min " << us.front() << "  p50 " << pct(0.5) << "  p99 " << pct(0.99) << "  max "
+            << us.back() << "\n";
+  if (count_allocs)
+    std::cout << "allocations in the timed loop: nam_hip+adapter " << g_ours.load() << "  libstdc++ " << g_cxx.load()
+              << "  hip-runtime " << g_hip.load() << "  other " << g_other.load() << "\n";
+}
+} // namespace
+
 int main(int argc, char* argv[])
 {
   if (argc < 2)
   {
-    std::cerr << "Usage: benchmodel <model_path> [--slim <0..1>] [--no-fast-tanh] [--streams N]\n";
+    std::cerr << "Usage: benchmodel <model_path> [--slim <0..1>] [--no-fast-tanh] [--streams N] [--count-allocs]\n";
     return 1;
   }
   const char* modelPath = argv[1];
   double slim = -1.0;
   bool fast_tanh = true;
   int streams = 1;
+  bool count_allocs = false;
   for (int i = 2; i < argc; i++)
   {
+    if (!std::strcmp(argv[i], "--count-allocs"))
+      count_allocs = true;
     if (!std::strcmp(argv[i], "--slim") && i + 1 < argc)
       slim = std::atof(argv[++i]);
     else if (!std::strcmp(argv[i], "--no-fast-tanh"))
@@ -58,12 +123,22 @@ int main(int argc, char* argv[])
       for (int c = 0; c < oc; c++)
         outp[c] = out[c].data();
       std::cout << "Running benchmark\n";
+      std::vector<double> us(numBuffers, 0.0);
+      for (int i = 0; i < 8; i++) // (first-launch costs stay outside, as the reference's prewarm does for its rings)
+        model->process(inp.data(), outp.data(), AUDIO_BUFFER_SIZE);
+      g_counting = count_allocs;
       auto t1 = high_resolution_clock::now();
       for (size_t i = 0; i < numBuffers; i++)
+      {
+        auto a = high_resolution_clock::now();
         model->process(inp.data(), outp.data(), AUDIO_BUFFER_SIZE);
+        us[i] = duration<double, std::micro>(high_resolution_clock::now() - a).count();
+      }
       auto t2 = high_resolution_clock::now();
+      g_counting = false;
       duration<double, std::milli> ms = t2 - t1;
       std::cout << duration_cast<milliseconds>(t2 - t1).count() << "ms\n" << ms.count() << "ms\n";
+      report(us, count_allocs);
     }
     else
     {
@@ -75,13 +150,23 @@ int main(int argc, char* argv[])
       std::vector<float> in((size_t)streams * batch.NumInputChannels() * AUDIO_BUFFER_SIZE, 0.0f),
         out((size_t)streams * batch.NumOutputChannels() * AUDIO_BUFFER_SIZE, 0.0f);
       std::cout << "Running benchmark (" << streams << " streams, host buffers)\n";
+      std::vector<double> us(numBuffers, 0.0);
+      for (int i = 0; i < 8; i++)
+        batch.process_batch(in.data(), out.data(), AUDIO_BUFFER_SIZE);
+      g_counting = count_allocs;
       auto t1 = high_resolution_clock::now();
       for (size_t i = 0; i < numBuffers; i++)
+      {
+        auto a = high_resolution_clock::now();
         batch.process_batch(in.data(), out.data(), AUDIO_BUFFER_SIZE);
+        us[i] = duration<double, std::micro>(high_resolution_clock::now() - a).count();
+      }
       auto t2 = high_resolution_clock::now();
+      g_counting = false;
       duration<double, std::milli> ms = t2 - t1;
       std::cout << ms.count() << "ms for 2 s x " << streams << " streams = " << 2000.0 * streams / ms.count()
                 << " x real time\n";
+      report(us, count_allocs);
     }
   }
   catch (const std::exception& e)

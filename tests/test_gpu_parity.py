@@ -334,6 +334,17 @@ def test_cpp_adapter_benchmodel_runs(nam_lib):
         assert "ms" in out.stdout
     bad = subprocess.run([exe, "/nonexistent.nam"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "does not exist" in bad.stderr
+    # real-time safety (tools/test/allocation_tracking.cpp:21-90 asserts zero allocations inside process()): neither the
+    # adapter nor libnam_hip.so asks for heap memory in the steady-state loop, one stream and many; the per-buffer round
+    # trip is printed
+    import re
+    for args in ([model_path("wavenet_a1_standard"), "--count-allocs"], [model_path("lstm"), "--count-allocs"],
+                 [model_path("wavenet_a2_max"), "--count-allocs", "--streams", "16"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "round trip per buffer (us): min" in out.stdout
+        m = re.search(r"nam_hip\+adapter (\d+)", out.stdout)
+        assert m and int(m.group(1)) == 0, out.stdout
 
 
 def _read_f32_wav(path):
