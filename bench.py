@@ -248,7 +248,8 @@ class HipEngine:
         self.dev = torch.device("cuda", local_rank)
         self.batch = model.batch(n_streams, block, device=local_rank)
         if kernel != "auto":
-            self.batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA, "a1_il": nam.KERNEL_A1_IL}[kernel])
+            self.batch.set_kernel({"generic": nam.KERNEL_GENERIC, "a1": nam.KERNEL_A1, "a1_mfma": nam.KERNEL_A1_MFMA, "a1_il": nam.KERNEL_A1_IL,
+                                   "wn_reg": nam.KERNEL_WN_REG}[kernel])
         self.batch.Reset(prewarm=True)
         if classes is not None:  # mixed widths: stream i of this rank runs at ratio SLIM_RATIOS[classes[i]]
             for c in sorted(set(classes)):
@@ -351,7 +352,7 @@ def main():
     ap.add_argument("--model", default=None, help="fixture name under tests/golden/models; default from --config")
     ap.add_argument("--fast-tanh", type=int, default=1, help="benchmodel default: fast tanh ON (tools/benchmodel.cpp:27)")
     ap.add_argument("--launch", choices=["block", "resident"], default="block")
-    ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma", "a1_il"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "generic", "a1", "a1_mfma", "a1_il", "wn_reg"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the latency pass and the fast_tanh-off / zeros-input runs")
     ap.add_argument("--slim-mix", action="store_true",

@@ -8,14 +8,19 @@
 // 64-frame block on, nearly all of it dispatch and LDS row traffic.
 //
 // Mapping (plan.h: WrPlan): one wavefront per stream, lane = frame of the 64-frame block. A WaveNet has no recurrence —
-// every frame of a block is independent given the conv inputs of the previous 64 frames — so a lane carries its frame
+// every frame of a block is independent given the conv inputs of the earlier frames — so a lane carries its frame
 // through the whole network: the layer input x[C], the condition, the head accumulator and head output live in
 // registers from the input sample to the output sample. A layer is ONE fully unrolled function, instantiated per
 // (condition size, channels, bottleneck, gating, kernel size, head1x1 size) shape; weights are read from an LDS copy of
 // the blob as broadcast b128 reads (every lane the same address: no bank conflicts, 4 weights per instruction). The only
-// per-frame LDS traffic is the conv input: each layer stores its C values and reads (K - 1) * C taps from the rows its
-// neighbours (and the previous block, kept 64 frames back) wrote. One wavefront per workgroup: LDS operations of a
-// wavefront execute in order, so no barrier anywhere.
+// per-frame LDS traffic is the conv input: each layer appends its C values to its LDS-resident ring (lookback + 64
+// frames: the reference's RingBuffer, NAM/ring_buffer.cpp:7-109, kept on the CU) and reads (K - 1) * C taps from it. One
+// wavefront per workgroup: LDS operations of a wavefront execute in order, so no barrier anywhere.
+//
+// A launch that runs more than one block (offline render, prewarm, a persistent session) brings the stream's whole ring
+// area from its state in HBM and takes it back at the end; a launch of ONE block fetches only the 64-frame windows its
+// taps reach (plan.h: the `pf` table) and stores only the frames it appended. One launch serves several width groups
+// (kernels.h: WrArgs): a slimmable batch with mixed widths is ONE launch, and one persistent session.
 //
 // FiLM slots and the shift are run-time flags (wavefront-uniform branches); activation types are run-time (one
 // dispatch per layer and activation, not per channel); grouped convs arrive expanded to dense from the planner.
@@ -38,14 +43,16 @@ using mf::lds_st4;
 // the fields of a WrOp the kernel reads, as scalars (a whole-struct copy would park the float and the padding in scratch)
 struct WrOpS
 {
-  int type, shape, w, hist, dil, flags, act, act2, n_out, scale_bits;
+  int type, shape, w, hist, ring, dil, flags, act, act2, n_out, scale_bits, slot;
   __device__ __forceinline__ float scale() const { return __builtin_bit_cast(float, scale_bits); }
 };
 __device__ __forceinline__ WrOpS wr_fetch(const WrOp* ops, int i)
 {
   const int* p = reinterpret_cast<const int*>(ops + i);
-  static_assert(offsetof(WrOp, scale) == 44 && offsetof(WrOp, n_out) == 40 && offsetof(WrOp, act) == 28, "WrOp layout");
-  return WrOpS{p[0], p[1], p[2], p[3], p[5], p[6], p[7], p[8], p[10], p[11]};
+  static_assert(offsetof(WrOp, scale) == 44 && offsetof(WrOp, n_out) == 40 && offsetof(WrOp, act) == 28
+                  && offsetof(WrOp, ring) == 16 && offsetof(WrOp, slot) == 48,
+                "WrOp layout");
+  return WrOpS{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[10], p[11], p[12]};
 }
 
 struct WrRegs
@@ -67,6 +74,66 @@ __device__ __forceinline__ void lds_st1(char* lds, unsigned byte_off, float v)
 }
 
 using f2 = __attribute__((ext_vector_type(2))) float;
+using i4 = __attribute__((ext_vector_type(4))) int;
+
+__device__ __forceinline__ int lds_ldi(const char* lds, unsigned byte_off)
+{
+  return *reinterpret_cast<const int*>(lds + byte_off);
+}
+__device__ __forceinline__ void lds_sti(char* lds, unsigned byte_off, int v)
+{
+  *reinterpret_cast<int*>(lds + byte_off) = v;
+}
+
+// A layer's conv-input ring (plan.h): [ceil(C / 4)][R][gs] floats, gs = 4 (the last group: C % 4) — a lane's frame of a
+// group is one b128 / b64 / b32 access (three b32 for gs = 3), and the lane stride gs is bank-conflict free for each.
+// `base_b`: byte offset of the area, `idx`: ring index of the lane's frame.
+template <int C>
+__device__ __forceinline__ void wr_ring_put(char* lds, unsigned base_b, int idx, int R, const float* v)
+{
+#pragma unroll
+  for (int q = 0; q * 4 < C; q++)
+  {
+    const int gs = C - 4 * q < 4 ? C - 4 * q : 4;
+    const unsigned a = base_b + (unsigned)(q * 4 * R + idx * gs) * 4u;
+    if (gs == 4)
+      lds_st4(lds, a, f4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+    else if (gs == 2)
+      *reinterpret_cast<f2*>(lds + a) = f2{v[4 * q], v[4 * q + 1]};
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < gs; i++)
+        lds_st1(lds, a + (unsigned)i * 4u, v[4 * q + i]);
+    }
+  }
+}
+template <int C>
+__device__ __forceinline__ void wr_ring_get(const char* lds, unsigned base_b, int idx, int R, float* v)
+{
+#pragma unroll
+  for (int q = 0; q * 4 < C; q++)
+  {
+    const int gs = C - 4 * q < 4 ? C - 4 * q : 4;
+    const unsigned a = base_b + (unsigned)(q * 4 * R + idx * gs) * 4u;
+    if (gs == 4)
+    {
+      const f4 t = lds_ld4(lds, a);
+      v[4 * q] = t[0], v[4 * q + 1] = t[1], v[4 * q + 2] = t[2], v[4 * q + 3] = t[3];
+    }
+    else if (gs == 2)
+    {
+      const f2 t = *reinterpret_cast<const f2*>(lds + a);
+      v[4 * q] = t[0], v[4 * q + 1] = t[1];
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < gs; i++)
+        v[4 * q + i] = lds_ld1(lds, a + (unsigned)i * 4u);
+    }
+  }
+}
 
 // Accumulators are PAIRS of outputs in adjacent registers (f2), so that one v_pk_fma_f32 advances two outputs; a
 // vector of N values occupies pad2(N) / 2 pairs (the odd tail is padding: zero weights, zero bias, never read).
@@ -252,7 +319,7 @@ __device__ __forceinline__ void wr_act(int type, f2* v, const WrActP<N>& ap)
 // FM >= 0: FiLM mask / shift mask / blend / activation types are compile-time (one straight-line block); FM < 0: run-time
 // flags from the op
 template <int COND, int C, int B, bool G, int K, int HO, int FM, int SM, int BL, int A1, int A2>
-__device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, int lane)
+__device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, int lane, unsigned pos_b)
 {
   constexpr WrLayerLayout L = wr_layer_layout(COND, C, B, G, K, HO);
   constexpr int ZC = G ? 2 * B : B;
@@ -299,18 +366,19 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
     for (int i = 0; i < C; i++)
       ci[i] = r.x[i];
   }
-  const unsigned hb = ((unsigned)op.hist + 64u + (unsigned)lane) * 4u; // this block's frames, behind the 64 before them
-#pragma unroll
-  for (int i = 0; i < C; i++)
-    lds_st1(lds, hb + (unsigned)i * (kWrPitch * 4u), ci[i]);
+  // the layer's ring: this lane's frame goes to index (position + lane) mod R, tap k is (K - 1 - k) * dilation behind it
+  const int R = op.ring;
+  int widx = lds_ldi(lds, pos_b + (unsigned)op.slot * 4u) + lane;
+  widx -= widx >= R ? R : 0;
+  const unsigned hb = (unsigned)op.hist * 4u;
+  wr_ring_put<C>(lds, hb, widx, R, ci);
   float taps[K * C]; // [k][i]: tap k looks (K - 1 - k) * dilation frames back (conv1d.cpp: the last tap is "now")
 #pragma unroll
   for (int k = 0; k + 1 < K; k++)
   {
-    const unsigned a = hb - (unsigned)((K - 1 - k) * op.dil) * 4u;
-#pragma unroll
-    for (int i = 0; i < C; i++)
-      taps[k * C + i] = lds_ld1(lds, a + (unsigned)i * (kWrPitch * 4u));
+    int idx = widx - (K - 1 - k) * op.dil;
+    idx += idx < 0 ? R : 0;
+    wr_ring_get<C>(lds, hb, idx, R, taps + k * C);
   }
 #pragma unroll
   for (int i = 0; i < C; i++)
@@ -466,7 +534,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   extern __shared__ __attribute__((aligned(16))) char lds_wr[];
   char* const lds = lds_wr;
   const int lane = (int)threadIdx.x;
-  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  // the width group of this workgroup (wavefront-uniform: everything below stays in scalar registers)
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < kWrMaxGroups; k++)
+    if (k < a.n_groups && (int)blockIdx.x >= a.g[k].first)
+      gi = k;
+  const WrGroup& G = a.g[gi];
+  const int member = (int)blockIdx.x - G.first;
+  const int stream = G.stream_map ? G.stream_map[member] : member;
   // persistent session (persist_wave.h): blocks come from commands, not from a frame count
   const bool pers = a.ps.ring != nullptr;
   PersistWave pw;
@@ -476,44 +552,104 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     pw.leave(a.ps, (int)blockIdx.x); // nothing to do
     return;
   }
-  // weights -> LDS (the blob is a multiple of 4 floats) and conv input histories <- state (row r = the last 64 frames
-  // of one channel of one layer's conv input): eight requests in flight per round trip to memory
-  float* const st = a.state + (long)stream * a.state_stride;
-  const unsigned hist0 = (unsigned)a.hist_base * 4u;
-  for (int base = 0; base < a.blob_floats; base += 8 * 256)
+  float* const st = G.state + (long)stream * G.state_stride;
+  int* const sti = reinterpret_cast<int*>(st);
+  float* const st_ring = st + kWrPosInts;
+  const int blob_floats = G.blob_floats, hist_floats = G.hist_floats;
+  const unsigned pos_b = (unsigned)blob_floats * 4u; // LDS: [blob][positions][rings]
+  const unsigned ring_b = pos_b + (unsigned)kWrPosInts * 4u;
+  const bool whole = pers || a.n_frames > kBlock; // more than one block: the whole ring area comes in (and goes back)
+
+  // Prologue. The write positions first (lane = slot): every ring address depends on them. A one-block launch then
+  // requests the windows its taps reach — table entries {float offset, R, slot | gs << 8, o} straight from memory
+  // (wavefront-uniform: scalar loads), lane j <-> ring index wrap(position - o + j) — before the weights, so that both
+  // travel together; everything lands in LDS afterwards: [blob (weights, tables)][positions][rings].
+  const int pos_in = sti[lane];
+  const i4* const tab_pf = reinterpret_cast<const i4*>(G.blob + G.tab_pf);
+  const int n_pf = whole ? 0 : G.n_pf;
+  constexpr int kWin = 32;
+  float win[kWin];
+  int win_off[kWin];
+  auto window = [&](int e, float& v, int& off) {
+    const i4 t = tab_pf[e];
+    const int p = __builtin_amdgcn_readlane(pos_in, t[2] & 255);
+    int idx = p - t[3] + lane;
+    idx += idx < 0 ? t[1] : 0;
+    idx -= idx >= t[1] ? t[1] : 0;
+    off = t[0] + idx * (t[2] >> 8);
+    v = st_ring[off];
+  };
+  if (n_pf > 0)
+  {
+#pragma unroll
+    for (int u = 0; u < kWin; u++)
+      window(min(u, n_pf - 1), win[u], win_off[u]);
+  }
+  for (int base = 0; base < blob_floats; base += 8 * 256)
   {
     f4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; u++)
     {
       const int i = base + u * 256 + lane * 4;
-      v[u] = i < a.blob_floats ? *reinterpret_cast<const f4*>(a.blob + i) : f4{0.f, 0.f, 0.f, 0.f};
+      v[u] = i < blob_floats ? *reinterpret_cast<const f4*>(G.blob + i) : f4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
     {
       const int i = base + u * 256 + lane * 4;
-      if (i < a.blob_floats)
+      if (i < blob_floats)
         lds_st4(lds, (unsigned)i * 4u, v[u]);
     }
   }
-  for (int base = 0; base < a.n_rows; base += 8)
+  lds_sti(lds, pos_b + (unsigned)lane * 4u, pos_in);
+  if (whole)
   {
-    float v[8];
+    for (int base = 0; base < hist_floats; base += 8 * 256)
+    {
+      f4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++)
-      v[u] = base + u < a.n_rows ? st[(base + u) * 64 + lane] : 0.0f;
+      for (int u = 0; u < 8; u++)
+      {
+        const int i = base + u * 256 + lane * 4;
+        v[u] = i < hist_floats ? *reinterpret_cast<const f4*>(st_ring + i) : f4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (base + u < a.n_rows)
-        lds_st1(lds, hist0 + (unsigned)((base + u) * kWrPitch + lane) * 4u, v[u]);
+      for (int u = 0; u < 8; u++)
+      {
+        const int i = base + u * 256 + lane * 4;
+        if (i < hist_floats)
+          lds_st4(lds, ring_b + (unsigned)i * 4u, v[u]);
+      }
+    }
+  }
+  else if (n_pf > 0)
+  {
+#pragma unroll
+    for (int u = 0; u < kWin; u++)
+      if (u < n_pf)
+        lds_st1(lds, ring_b + (unsigned)win_off[u] * 4u, win[u]);
+    for (int e0 = kWin; e0 < n_pf; e0 += 16)
+    {
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        window(min(e0 + u, n_pf - 1), win[u], win_off[u]);
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (e0 + u < n_pf)
+          lds_st1(lds, ring_b + (unsigned)win_off[u] * 4u, win[u]);
+    }
   }
   const float* const in = a.in ? a.in + (long)stream * a.in_ch * a.io_stride : nullptr;
   float* const out = a.out ? a.out + (long)stream * a.out_ch * a.io_stride : nullptr;
+  const WrOp* const ops = G.ops;
+  const int n_ops = G.n_ops, n_slots = G.n_slots;
+  const unsigned rtab_b = (unsigned)G.tab_ring * 4u;
 
+  int n = kBlock;
   for (int f0 = pers ? (int)cmd_off : 0;;)
   {
-    const int n = pers ? kBlock : min(kBlock, a.n_frames - f0);
+    n = pers ? kBlock : min(kBlock, a.n_frames - f0);
     if (pers)
       pw.look_ahead(a.ps);
     WrRegs r;
@@ -526,17 +662,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       r.cond[c] = r.in[c]; // a net without condition_dsp (and the nested net itself) is conditioned on its input
       r.x[c] = r.hacc[c] = r.hout[c] = 0.0f;
     }
-    WrOpS cur = wr_fetch(a.ops, 0);
-    for (int oi = 0; oi < a.n_ops; oi++)
+    WrOpS cur = wr_fetch(ops, 0);
+    for (int oi = 0; oi < n_ops; oi++)
     {
-      const WrOpS nxt = wr_fetch(a.ops, min(oi + 1, a.n_ops - 1)); // requested before this op runs
+      const WrOpS nxt = wr_fetch(ops, min(oi + 1, n_ops - 1)); // requested before this op runs
       switch (cur.type)
       {
         case WR_LAYER:
           switch (cur.shape)
           {
 #define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
-  case ID: wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane); break;
+  case ID: wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane, pos_b); break;
             WR_LAYER_SHAPES(X)
 #undef X
             default: __builtin_trap();
@@ -580,12 +716,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
       cur = nxt;
     }
-    // the block's n frames move into the history: row[j] <- row[j + n] (reads of a wavefront precede its later writes)
-    for (int row = 0; row < a.n_rows; row++)
+    // every ring moves on by the block's n frames (lane = slot)
+    if (lane < n_slots)
     {
-      const unsigned rb = hist0 + (unsigned)(row * kWrPitch) * 4u;
-      const float v = lds_ld1(lds, rb + (unsigned)(lane + n) * 4u);
-      lds_st1(lds, rb + (unsigned)lane * 4u, v);
+      const int R = lds_ldi(lds, rtab_b + (unsigned)lane * 4u);
+      int p = lds_ldi(lds, pos_b + (unsigned)lane * 4u) + n;
+      p -= p >= R ? R : 0;
+      lds_sti(lds, pos_b + (unsigned)lane * 4u, p);
     }
     if (pers)
     {
@@ -600,17 +737,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         break;
     }
   }
-  for (int row = 0; row < a.n_rows; row++)
-    st[row * 64 + lane] = lds_ld1(lds, hist0 + (unsigned)(row * kWrPitch + lane) * 4u);
+  // the state goes back: everything, or the frames this launch's single block appended
+  if (whole)
+  {
+    for (int base = 0; base < hist_floats; base += 4 * 256)
+    {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+        const int i = base + u * 256 + lane * 4;
+        if (i < hist_floats)
+          *reinterpret_cast<f4*>(st_ring + i) = lds_ld4(lds, ring_b + (unsigned)i * 4u);
+      }
+    }
+  }
+  else
+  {
+    // `rows` table: one entry per channel; the n frames of this launch's block sit at wrap(old position + lane)
+    const i4* const tab_rows = reinterpret_cast<const i4*>(G.blob + G.tab_rows);
+    const int n_rows = G.n_rows;
+    for (int e0 = 0; e0 < n_rows; e0 += 8)
+    {
+      float v[8];
+      int off[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+      {
+        const i4 t = tab_rows[min(e0 + u, n_rows - 1)];
+        int idx = __builtin_amdgcn_readlane(pos_in, t[2] & 255) + lane;
+        idx -= idx >= t[1] ? t[1] : 0;
+        off[u] = t[0] + idx * (t[2] >> 8);
+        v[u] = lds_ld1(lds, ring_b + (unsigned)off[u] * 4u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (e0 + u < n_rows && lane < n)
+          st_ring[off[u]] = v[u];
+    }
+  }
+  sti[lane] = lds_ldi(lds, pos_b + (unsigned)lane * 4u);
   if (pers)
     pw.leave(a.ps, (int)blockIdx.x);
 }
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_streams, int lds_bytes, hipStream_t stream)
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream)
 {
-  if (n_streams <= 0 || a.n_frames <= 0)
+  if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL(nam_wn_reg_kernel, dim3(n_streams), dim3(64), lds_bytes, stream, a);
+  hipLaunchKernelGGL(nam_wn_reg_kernel, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -104,26 +104,35 @@ struct LSTMArgs
   PersistArgs ps; // nam_lstm_row_kernel only
 };
 
-struct WrArgs // nam_wn_reg_kernel (plan.h: WrPlan)
+// nam_wn_reg_kernel (plan.h: WrPlan). One launch serves up to kWrMaxGroups WIDTH GROUPS — streams of a slimmable model
+// (or container) that currently run different sub-models: workgroups [first, next group's first) belong to group g, each
+// with its own op list, weights, LDS layout and state ("LDS repacking" per width); the audio windows are shared.
+struct WrGroup
 {
   const WrOp* ops;
-  int n_ops;
-  const float* blob; // weights as the kernel's LDS copy holds them (a multiple of 4 floats)
-  int blob_floats;
-  float* state;
+  const float* blob; // weights and tables as the kernel's LDS copy holds them (a multiple of 4 floats)
+  float* state; // [stream][state_stride]
+  const int* stream_map; // optional: position inside the group -> stream index; nullptr = identity
   long state_stride;
-  const int* stream_map;
+  int n_ops, blob_floats;
+  int hist_floats; // floats of ring area behind the positions
+  int n_slots; // layers (write positions)
+  int tab_rows, n_rows, tab_pf, n_pf, tab_ring; // blob float offsets / entry counts of the tables
+  int first; // first workgroup of the group
+};
+struct WrArgs
+{
+  WrGroup g[kWrMaxGroups];
+  int n_groups;
   const float* in; // nullptr = silence (prewarm)
   float* out; // nullptr = discard
   long io_stride;
   int n_frames;
   int in_ch, out_ch;
-  int hist_base; // LDS float offset of history row 0 (behind the weights)
-  int n_rows; // history rows: the sum of the layers' channel counts
   PersistArgs ps;
 };
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_streams, int lds_bytes, hipStream_t stream);
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream);
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);

@@ -283,8 +283,10 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
     case NAM_HIP_KERNEL_A1_MFMA: return mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback;
     case NAM_HIP_KERNEL_A1_IL: return il ? NAM_HIP_KERNEL_A1_IL : (mfma ? NAM_HIP_KERNEL_A1_MFMA : fallback);
     default: // AUTO
+      // narrow models (1 .. 8 channels in the instantiated layer shapes) keep their whole dilation history in LDS on
+      // nam_wn_reg_kernel; the VALU kernel fetches it from the HBM rings layer by layer
       if (!mfma)
-        return fallback;
+        return wr ? NAM_HIP_KERNEL_WN_REG : fallback;
       // The K-tap kernel (A2 shapes) spreads a stream over four wavefronts: 2.3x the VALU kernel while the chip has
       // idle SIMDs, level with it at ~1,000 streams per GPU, behind it beyond (it issues more instructions per tap).
       if (!g.plan->a1.ws_ok && g.streams.size() > kKtAutoMaxStreams)
@@ -357,6 +359,92 @@ PersistArgs persist_args(const nam_hip_batch* b)
   return pa;
 }
 
+// nam_wn_reg_kernel over up to kWrMaxGroups width groups in ONE launch (kernels.h: WrArgs): group k's `counts[k]` streams
+// (`maps[k]`: position -> stream index, nullptr = identity) become consecutive workgroups.
+int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* maps, const int* counts, int n_groups,
+              const float* d_in, float* d_out, int n_frames, long io_stride, hipStream_t s)
+{
+  WrArgs a;
+  std::memset(&a, 0, sizeof(a));
+  int total = 0, lds_bytes = 0;
+  for (int k = 0; k < n_groups; k++)
+  {
+    WidthGroup& g = *groups[k];
+    const WrPlan& w = g.plan->wr;
+    if (g.state_family >= 0 && g.state_family != 2)
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
+                  "kernel change crosses state layouts (the op program's rings, the A1 kernels' zero-padded rings and "
+                  "nam_wn_reg_kernel's LDS-image rings differ): call nam_hip_batch_reset before switching");
+    g.state_family = 2;
+    WrGroup& G = a.g[k];
+    G.ops = g.d_wr_ops;
+    G.blob = g.d_wr_blob;
+    G.state = g.d_state;
+    G.stream_map = maps[k];
+    G.state_stride = g.state_stride;
+    G.n_ops = (int)w.ops.size();
+    G.blob_floats = (int)w.blob.size();
+    G.hist_floats = w.hist_floats;
+    G.n_slots = w.n_layers;
+    G.tab_rows = w.tab_rows;
+    G.n_rows = w.n_rows;
+    G.tab_pf = w.tab_pf;
+    G.n_pf = w.n_pf;
+    G.tab_ring = w.tab_ring;
+    G.first = total;
+    total += counts[k];
+    lds_bytes = std::max(lds_bytes, w.lds_bytes);
+  }
+  a.n_groups = n_groups;
+  a.in = d_in;
+  a.out = d_out;
+  a.io_stride = io_stride;
+  a.n_frames = n_frames;
+  a.in_ch = groups[0]->plan->in_channels;
+  a.out_ch = groups[0]->plan->out_channels;
+  a.ps = persist_args(b);
+  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, s));
+  return NAM_HIP_OK;
+}
+
+// The non-empty groups of a batch when ALL of them run nam_wn_reg_kernel (then one launch serves the whole batch, and a
+// persistent session can too); n = 0 otherwise. (A fixed array: this runs inside process calls, which allocate nothing.)
+struct WrGroupList
+{
+  WidthGroup* g[kWrMaxGroups];
+  int n = 0;
+};
+WrGroupList wr_groups(nam_hip_batch* b)
+{
+  WrGroupList out;
+  const Plan& full = *b->groups[b->model->full_width].plan;
+  for (auto& g : b->groups)
+  {
+    if (g.streams.empty())
+      continue;
+    if (out.n == kWrMaxGroups || g.plan->arch != ARCH_WAVENET || !g.d_wr_ops || pick_kernel(b, g) != NAM_HIP_KERNEL_WN_REG
+        || g.plan->in_channels != full.in_channels || g.plan->out_channels != full.out_channels)
+    {
+      out.n = 0;
+      return out;
+    }
+    out.g[out.n++] = &g;
+  }
+  return out;
+}
+int launch_wr_all(nam_hip_batch* b, const WrGroupList& gs, const float* d_in, float* d_out, int n_frames, long io_stride,
+                  hipStream_t s)
+{
+  const int* maps[kWrMaxGroups];
+  int counts[kWrMaxGroups];
+  for (int k = 0; k < gs.n; k++)
+  {
+    maps[k] = gs.g[k]->d_map;
+    counts[k] = (int)gs.g[k]->streams.size();
+  }
+  return launch_wr(b, gs.g, maps, counts, gs.n, d_in, d_out, n_frames, io_stride, s);
+}
+
 // Launch one group's kernel over `n` streams given by `d_map` (nullptr = streams 0..n-1).
 int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const float* d_in, float* d_out,
                  int n_frames, long io_stride, hipStream_t s)
@@ -377,25 +465,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
     g.state_family = fam;
     if (kernel == NAM_HIP_KERNEL_WN_REG)
     {
-      WrArgs a;
-      a.ops = g.d_wr_ops;
-      a.n_ops = (int)p.wr.ops.size();
-      a.blob = g.d_wr_blob;
-      a.blob_floats = (int)p.wr.blob.size();
-      a.state = g.d_state;
-      a.state_stride = g.state_stride;
-      a.stream_map = d_map;
-      a.in = d_in;
-      a.out = d_out;
-      a.io_stride = io_stride;
-      a.n_frames = n_frames;
-      a.in_ch = p.in_channels;
-      a.out_ch = p.out_channels;
-      a.hist_base = (int)p.wr.blob.size();
-      a.n_rows = p.wr.state_floats / kBlock;
-      a.ps = persist_args(b);
-      NAM_HIP_CHECK(launch_wn_reg(a, n, p.wr.lds_bytes, s));
-      return NAM_HIP_OK;
+      WidthGroup* one[1] = {&g};
+      const int* maps[1] = {d_map};
+      const int counts[1] = {n};
+      return launch_wr(b, one, maps, counts, 1, d_in, d_out, n_frames, io_stride, s);
     }
     if (kernel != NAM_HIP_KERNEL_GENERIC)
     {
@@ -615,16 +688,29 @@ int persist_family(const nam_hip_batch* b, const WidthGroup& g)
 int persist_kind(const nam_hip_batch* b)
 {
   const WidthGroup& g = b->groups[b->model->full_width];
-  if (!b->ps.enabled || (int)g.streams.size() != b->n_streams || g.d_map != nullptr)
+  if (!b->ps.enabled)
     return PERSIST_NONE;
   const int cus = std::max(b->n_cus, 1);
+  {
+    // nam_wn_reg_kernel serves every width group with one launch: a mixed-width batch is one session. Its workgroups
+    // are one wavefront with (the largest group's) LDS image: at most four per CU, and no more than fit its 160 KB
+    const WrGroupList gs = wr_groups(const_cast<nam_hip_batch*>(b));
+    if (gs.n > 0)
+    {
+      int lds = 1;
+      for (int k = 0; k < gs.n; k++)
+        lds = std::max(lds, gs.g[k]->plan->wr.lds_bytes);
+      const int per_cu = std::min(4, (160 * 1024) / (lds + 512));
+      return b->n_streams <= per_cu * cus ? PERSIST_WN_REG : PERSIST_NONE;
+    }
+  }
+  if ((int)g.streams.size() != b->n_streams || g.d_map != nullptr)
+    return PERSIST_NONE;
   if (g.plan->arch == ARCH_WAVENET)
   {
     if (!b->il_generic && g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= cus
         && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL))
       return PERSIST_A1_P2;
-    if (g.d_wr_ops && pick_kernel(b, g) == NAM_HIP_KERNEL_WN_REG && b->n_streams <= 4 * cus) // one wavefront per SIMD
-      return PERSIST_WN_REG;
     return PERSIST_NONE;
   }
   if (g.plan->arch == ARCH_LSTM && b->kernel == NAM_HIP_KERNEL_AUTO)
@@ -664,7 +750,9 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   if (ps.kind == PERSIST_A1_P2)
     b->kernel = NAM_HIP_KERNEL_A1_IL;
   b->ps_launching = true;
-  const int rc = launch_group(b, g, nullptr, b->n_streams, ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream);
+  const int rc = ps.kind == PERSIST_WN_REG
+                   ? launch_wr_all(b, wr_groups(b), ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream)
+                   : launch_group(b, g, nullptr, b->n_streams, ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream);
   b->ps_launching = false;
   b->kernel = keep;
   return rc;
@@ -731,8 +819,7 @@ int persist_stop(nam_hip_batch* b)
 int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride)
 {
   PersistSession& ps = b->ps;
-  WidthGroup& g = b->groups[b->model->full_width];
-  const int n = (int)g.streams.size();
+  const int n = b->n_streams; // (a session holds every stream of the batch)
   if (!ps.d_ring)
   {
     ps.host_store_ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long),
@@ -886,9 +973,9 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   ps.seq++;
   ps.flushed_valid = false;
   ps.last_caller = caller;
-  WidthGroup& g = b->groups[b->model->full_width];
-  if (g.plan->arch == ARCH_WAVENET)
-    g.state_family = persist_family(b, g);
+  for (auto& g : b->groups)
+    if (!g.streams.empty() && g.plan->arch == ARCH_WAVENET)
+      g.state_family = persist_family(b, g);
   return NAM_HIP_OK;
 }
 
@@ -1289,9 +1376,10 @@ int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float*
   if (batch->ps.enabled && persist_eligible(batch))
   {
     // fresh state has the layout any kernel family writes; anything else must already be the session kernel's
-    WidthGroup& g0 = batch->groups[batch->model->full_width];
-    if (g0.plan->arch == ARCH_WAVENET && g0.state_family >= 0 && g0.state_family != persist_family(batch, g0))
-      return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "persistent mode: the state was written in another kernel family's layout; reset first");
+    for (auto& g0 : batch->groups)
+      if (!g0.streams.empty() && g0.plan->arch == ARCH_WAVENET && g0.state_family >= 0
+          && g0.state_family != persist_family(batch, g0))
+        return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "persistent mode: the state was written in another kernel family's layout; reset first");
     const int rc = persist_submit(batch, d_in, d_out, n_frames, (long)frame_stride, s);
     if (rc <= 0)
       return rc; // submitted (0) or failed (< 0)
@@ -1301,6 +1389,12 @@ int nam_hip_batch_process_device(nam_hip_batch* batch, const float* d_in, float*
     const int rc = persist_stop(batch);
     if (rc != NAM_HIP_OK)
       return rc;
+  }
+  {
+    // every group on nam_wn_reg_kernel: one launch for the whole (mixed-width) batch
+    const WrGroupList gs = wr_groups(batch);
+    if (gs.n > 1)
+      return n_frames > 0 ? launch_wr_all(batch, gs, d_in, d_out, n_frames, (long)frame_stride, s) : NAM_HIP_OK;
   }
   for (auto& g : batch->groups)
   {

@@ -1252,8 +1252,69 @@ namespace
 struct WrBuilder
 {
   WrPlan& wr;
-  int rows = 0; // history rows so far (one per conv-input channel of every layer)
+  int hist = 0; // floats of ring area laid out so far (a multiple of 4)
+  struct Entry // one 64-frame window of one channel (plan.h: tables)
+  {
+    int32_t off, ring, slot_gs, o;
+  };
+  std::vector<Entry> rows, pf;
+  std::vector<int32_t> ring_of_slot;
   explicit WrBuilder(WrPlan& w) : wr(w) {}
+
+  // A layer's conv-input ring: [ceil(C / 4)][R][gs] floats; table entries for its channels. Returns the float offset
+  // of the area (relative to the ring area's start).
+  int ring_area(int C, int K, int dil)
+  {
+    const long lookback = (long)(K - 1) * dil;
+    if (lookback + kBlock > (1 << 20))
+      throw Unsupported("a conv reaching more than 2^20 frames back");
+    const int R = (int)lookback + kBlock;
+    const int slot = (int)ring_of_slot.size();
+    if (slot >= kWrPosInts)
+      throw Unsupported("more than 64 layers");
+    ring_of_slot.push_back(R);
+    const int off = hist;
+    // the offsets (1 = the frame before the block) a block's taps can reach: tap L reads frames t - L, t = 0 .. 63
+    std::vector<char> need((size_t)lookback + 1, 0);
+    for (int k = 0; k + 1 < K; k++)
+    {
+      const long L = (long)(K - 1 - k) * dil;
+      for (long o = std::max(1l, L - (kBlock - 1)); o <= L; o++)
+        need[(size_t)o] = 1;
+    }
+    std::vector<int> windows; // o of lane 0; a window covers offsets o - 63 .. o (offsets < 1 land in the block being written)
+    for (long hi = lookback; hi >= 1;)
+    {
+      if (!need[(size_t)hi])
+      {
+        hi--;
+        continue;
+      }
+      const long o = std::max<long>(hi, kBlock);
+      windows.push_back((int)o);
+      hi = o - kBlock;
+    }
+    for (int q = 0; q * 4 < C; q++)
+    {
+      const int gs = std::min(4, C - 4 * q);
+      for (int i = 0; i < gs; i++)
+      {
+        const int32_t eo = off + q * 4 * R + i;
+        rows.push_back({eo, R, slot | (gs << 8), 0});
+        for (int o : windows)
+          pf.push_back({eo, R, slot | (gs << 8), o});
+      }
+    }
+    hist += wr_pad4(C * R);
+    return off;
+  }
+  int table(const std::vector<Entry>& t)
+  {
+    const int off = reserve((int)t.size() * 4);
+    if (!t.empty())
+      std::memcpy(&wr.blob[(size_t)off], t.data(), t.size() * sizeof(Entry));
+    return off;
+  }
 
   struct Unsupported : std::runtime_error
   {
@@ -1362,8 +1423,6 @@ struct WrBuilder
         const bool G = gm != GATING_NONE;
         const int zc = G ? 2 * B : B, K = A.kernel_sizes[l], dil = A.dilations[l];
         const int h1o = A.head1x1_active ? A.head1x1_out : 0;
-        if ((K - 1) * dil > kBlock)
-          throw Unsupported("a conv reaching more than 64 frames back");
         const ActSpec& a1 = A.activations[l];
         const ActSpec& a2 = A.secondary_activations[l];
         if (a1.type == ACT_LUT || (G && a2.type == ACT_LUT))
@@ -1425,13 +1484,13 @@ struct WrBuilder
         WrOp& op = push(WR_LAYER);
         op.shape = shape;
         op.w = off;
-        op.hist = rows * kWrPitch; // + the history area's base, added once the weights are complete
-        op.state = rows * kBlock;
+        op.slot = (int)ring_of_slot.size();
+        op.hist = ring_area(C, K, dil); // + the ring area's base, added once the weights and tables are complete
+        op.ring = (K - 1) * dil + kBlock;
         op.dil = dil;
         op.flags = flags;
         op.act = a1.type;
         op.act2 = G ? a2.type : ACT_IDENTITY;
-        rows += C;
         wr.n_layers++;
       }
       {
@@ -1493,15 +1552,23 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
   {
     WrBuilder b(wr);
     b.net(wn, false);
-    const int hist_base = (int)wr.blob.size(); // history rows behind the weights
+    static_assert(sizeof(WrBuilder::Entry) == 16, "table entries are int4");
+    wr.tab_rows = b.table(b.rows);
+    wr.n_rows = (int)b.rows.size();
+    wr.tab_pf = b.table(b.pf);
+    wr.n_pf = (int)b.pf.size();
+    wr.tab_ring = b.reserve((int)b.ring_of_slot.size());
+    if (!b.ring_of_slot.empty())
+      std::memcpy(&wr.blob[(size_t)wr.tab_ring], b.ring_of_slot.data(), b.ring_of_slot.size() * sizeof(int32_t));
+    const int hist_base = (int)wr.blob.size() + kWrPosInts; // LDS: weights and tables | write positions | rings
     for (auto& op : wr.ops)
       if (op.type == WR_LAYER)
         op.hist += hist_base;
-    wr.hist_floats = b.rows * kWrPitch;
-    wr.state_floats = b.rows * kBlock;
+    wr.hist_floats = b.hist;
+    wr.state_floats = (kWrPosInts + b.hist + 63) / 64 * 64;
     wr.lds_bytes = (hist_base + wr.hist_floats) * 4;
     if (wr.lds_bytes > 64 * 1024)
-      throw WrBuilder::Unsupported("more than 64 KB of weights and histories");
+      throw WrBuilder::Unsupported("more than 64 KB of weights and rings");
     wr.ok = true;
   }
   catch (const WrBuilder::Unsupported& e)

@@ -362,16 +362,27 @@ struct A1Plan
 };
 
 // ---- register-resident WaveNet (nam_wn_reg_kernel) ----------------------------------------------------------------
-// For WaveNets whose every conv reaches back at most 64 frames ((K - 1) * dilation <= 64) and whose layers are a few
-// channels wide (the FiLM-heavy A2 "max" feature set, nested condition_dsp included): one wavefront per stream, lane =
-// frame, EVERY activation in registers — a layer is one fully unrolled function instantiated per shape
-// (kernel_wn_reg.hip: WR_SHAPES), run from a list of macro-ops (an array's rechannel, a layer, an array's head
-// rechannel, "the nested net's output becomes the condition", "store the output"). The only LDS traffic is the
-// weights (broadcast b128 reads) and each layer's conv input, kept 64 frames back for the taps.
-//   weights: `blob` is copied to LDS once per launch; per matrix [out][pad4(in)] row-major, zero padded; grouped convs
+// For WaveNets whose layers are a few channels wide (the FiLM-heavy A2 "max" feature set, nested condition_dsp included;
+// the slimmable example's 1..3 channels with dilations up to 512): one wavefront per stream, lane = frame, EVERY
+// activation in registers — a layer is one fully unrolled function instantiated per shape (kernel_wn_reg.hip:
+// WR_SHAPES), run from a list of macro-ops (an array's rechannel, a layer, an array's head rechannel, "the nested net's
+// output becomes the condition", "store the output"). The only LDS traffic is the weights (broadcast b128 reads) and each
+// layer's conv input, which lives in an LDS-RESIDENT RING of exactly lookback + 64 frames (the reference's RingBuffer,
+// NAM/ring_buffer.cpp:7-109, without the rewind): the dilation history never leaves the CU while a launch runs.
+//   weights: `blob` is copied to LDS once per launch; per matrix [in][pad4(out)] (transposed), zero padded; grouped convs
 //            expanded to dense (block-diagonal); a layer's block has a fixed layout given its shape (inactive FiLMs
-//            keep their zeroed slot), see kernel_wn_reg.hip: LayerLayout
-//   state:   per layer [C][64] floats: the last 64 frames of the layer's conv input (kernel_wn_reg.hip)
+//            keep their zeroed slot), see wr_layer_layout; behind the weights three int tables (below)
+//   rings:   layer with C conv-input channels, kernel K, dilation d: R = (K - 1) d + 64 frames, stored as
+//            [ceil(C / 4)][R][gs] floats (gs = 4, the last group C % 4): frame-major inside a group of up to four channels,
+//            so a lane appends / fetches its frame's group with ONE ds_write / ds_read (b128 / b64 / b32: the lane stride
+//            of every shape is bank-conflict free). One write position per layer ("slot").
+//   state:   per stream [64 ints: the slots' write positions][the rings, exactly as in LDS]
+//   LDS:     [blob][64 ints: positions][rings]
+//   tables (int4 entries {float offset inside the ring area, R, slot | gs << 8, o}): entry = one 64-frame window of one
+//            channel: lane j <-> ring index wrap(position - o + j), float offset + index * gs.
+//            `rows`: one entry per channel with o = 0 (the block being written; the kernel substitutes o = frames
+//            just processed when it stores them back); `pf`: the windows of history a single 64-frame block's taps can
+//            reach (what a one-block launch fetches from the state instead of the whole ring); `ring`: R per slot.
 enum WrOpType : int32_t
 {
   WR_ARRAY_BEGIN = 0, // head accumulator = first array ? 0 : previous head output; x = rechannel(previous x | input)
@@ -386,8 +397,8 @@ struct WrOp // 16 x int32 = 64 bytes
   int32_t type;
   int32_t shape; // index into the kernel's instantiation table (WR_LAYER / WR_ARRAY_*: (in, out) pair)
   int32_t w; // float offset of this op's weights in the blob (and in the LDS copy)
-  int32_t hist; // WR_LAYER: LDS float offset of the layer's history rows [C][128]; state offset = layer index * C * 64
-  int32_t state; // WR_LAYER: float offset of the layer's [C][64] block in the per-stream state
+  int32_t hist; // WR_LAYER: LDS float offset of the layer's ring area
+  int32_t ring; // WR_LAYER: R, frames per ring = (K - 1) * dilation + 64
   int32_t dil; // WR_LAYER: dilation
   int32_t flags; // WR_LAYER: bit i = FiLM slot i active, bit 8 + i = it has a shift; bit 16 = blended (else gated) when the
                  // shape is a gating one; WR_ARRAY_BEGIN: bit 0 = first array (head accumulator starts at 0, x from the
@@ -395,24 +406,29 @@ struct WrOp // 16 x int32 = 64 bytes
   int32_t act, act2; // WR_LAYER: activation types (primary, secondary)
   int32_t n_in, n_out; // WR_ARRAY_BEGIN: input size, channels; WR_ARRAY_END: head input size, head size; SET_COND/OUTPUT: count
   float scale; // SET_COND / OUTPUT: head_scale
-  int32_t pad[4];
+  int32_t slot; // WR_LAYER: index of the layer's write position
+  int32_t pad[3];
 };
 static_assert(sizeof(WrOp) == 64, "WrOp must stay 64 bytes");
 
-constexpr int kWrPitch = 128; // floats per history row: 64 frames back + the block's 64
+constexpr int kWrPosInts = 64; // write positions per stream (one per layer): the header of the state, a table in LDS
 constexpr int kWrRegs = 8; // width of the register files (x, condition, head accumulator, head output)
 constexpr int kWrActFloats = 20; // per activation: p0..p3, then the PReLU slope of each of (up to) 16 rows
+constexpr int kWrMaxGroups = 8; // width groups one launch of nam_wn_reg_kernel can serve (kernels.h: WrArgs)
 
 struct WrPlan
 {
   bool ok = false;
   std::string why; // when !ok: the first unsupported thing
   std::vector<WrOp> ops;
-  std::vector<float> blob;
-  int n_layers = 0;
-  int state_floats = 0; // per stream
-  int hist_floats = 0; // LDS floats for the history rows
-  int lds_bytes = 0; // weights + history
+  std::vector<float> blob; // weights, then the tables (int bit patterns)
+  int n_layers = 0; // = slots
+  int state_floats = 0; // per stream: kWrPosInts + hist_floats, rounded up to a multiple of 64
+  int hist_floats = 0; // floats of the ring area (a multiple of 4)
+  int lds_bytes = 0; // blob + positions + rings
+  int tab_rows = 0, n_rows = 0; // blob float offset / entry count of the `rows` table
+  int tab_pf = 0, n_pf = 0; // ... of the one-block prefetch windows
+  int tab_ring = 0; // ... of R per slot (n_layers ints, padded to 4)
 };
 
 // The layer shapes kernel_wn_reg.hip instantiates — (id, condition size, channels, bottleneck, gating, kernel size,
@@ -427,6 +443,10 @@ struct WrPlan
   X(2, 1, 4, 2, true, 3, 4, 0xff, 0x00, 1, ACT_PRELU, ACT_LEAKYHARDTANH) \
   X(3, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_PRELU, ACT_RELU) \
   X(4, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_SOFTSIGN, ACT_SIGMOID) \
+  /* example_models/slimmable_wavenet.nam at its three widths (plain ReLU layers, dilations 1 .. 512) */ \
+  X(15, 1, 3, 3, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY) \
+  X(16, 1, 2, 2, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY) \
+  X(17, 1, 1, 1, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY) \
   /* run-time flags: the same shapes with other FiLM sets / activations, plain small stacks (no head1x1), */ \
   /* example_models/wavenet_condition_dsp.nam, multi-channel fixtures */ \
   X(5, 8, 4, 4, false, 4, 4, -1, 0, 0, -1, -1) \
@@ -438,7 +458,8 @@ struct WrPlan
   X(11, 1, 8, 8, false, 3, 0, -1, 0, 0, -1, -1) \
   X(12, 3, 3, 3, false, 3, 0, -1, 0, 0, -1, -1) \
   X(13, 3, 4, 4, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(14, 3, 2, 2, false, 3, 0, -1, 0, 0, -1, -1)
+  X(14, 3, 2, 2, false, 3, 0, -1, 0, 0, -1, -1) \
+  X(18, 1, 1, 1, false, 3, 0, -1, 0, 0, -1, -1)
 #define WR_PAIR_SHAPES(X) \
   X(0, 1, 3) X(1, 3, 4) X(2, 1, 4) X(3, 6, 4) X(4, 4, 8) X(5, 4, 1) X(6, 4, 4) X(7, 1, 2) X(8, 2, 1) X(9, 3, 1) X(10, 1, 8) \
   X(11, 8, 1) X(12, 8, 4) X(13, 4, 2) X(14, 2, 2) X(15, 3, 3) X(16, 8, 8) X(17, 2, 4) X(18, 3, 2) X(19, 6, 1) X(20, 1, 1) X(21, 2, 3) X(22, 4, 3) X(23, 3, 8) X(24, 2, 8)

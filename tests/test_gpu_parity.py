@@ -1000,3 +1000,88 @@ def test_register_resident_wavenet_kernel(nam_lib, oracle, name, in_ch):
         for s in range(n_streams):
             assert float(np.max(np.abs(yg[s] - y[s]))) <= 2 * tol * max(1.0, float(np.max(np.abs(yg[s]))))
         b.close()
+
+
+def test_lds_ring_kernel_mixed_width_batch_one_launch(nam_lib, oracle):
+    """Config 5 on nam_wn_reg_kernel: slimmable_wavenet (1..3 channels, dilations up to 512) keeps every layer's
+    dilation history in an LDS-resident ring, and the three width groups of a mixed batch share ONE launch (and one
+    persistent session). Long enough that the longest ring (1,088 frames) wraps twice. Covered: 64-frame calls (a launch
+    fetches only the windows its taps reach), odd partitions, one launch walking the whole signal, the persistent block
+    mode with mixed widths, a width change in the middle of a session — every stream against the oracle's slimmed model."""
+    torch = pytest.importorskip("torch")
+    nam = nam_lib
+    name, n_streams, block = "slimmable_wavenet", 11, 64
+    n = 64 * 40 + 23
+    x = stream_bank(n_streams, n, seed=505)
+    ratios = [0.0, 0.34, 0.67, 1.0]
+    ratio_of = [ratios[s % 4] for s in range(n_streams)]
+    for fast_tanh in (True, False):
+        model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
+        assert model.info.has_a1_kernel & 16
+        refs = [_oracle_run(oracle, name, x[s], block, fast_tanh, ratio=ratio_of[s]) for s in range(n_streams)]
+        tol = _tol(fast_tanh)
+
+        def check(y, upto, what):
+            for s in range(n_streams):
+                r = refs[s][..., :upto]
+                err = float(np.max(np.abs(r - np.asarray(y[s]).reshape(r.shape))))
+                assert err <= tol * max(1.0, float(np.max(np.abs(r)))), (what, fast_tanh, s, err)
+
+        b = model.batch(n_streams, block)
+        assert b.kernel_name() == "nam_wn_reg_kernel"  # what AUTO picks for the narrow widths
+
+        def set_widths():
+            for i, r in enumerate(ratios):
+                b.SetSlimmableSize(r, [s for s in range(n_streams) if s % 4 == i])
+
+        b.Reset(prewarm=True)
+        set_widths()
+        check(b.process_stream(x, block), n, "64-frame launches")
+        b.Reset(prewarm=True)
+        lens, rng = [], np.random.default_rng(8)
+        while sum(lens) < n:
+            lens.append(min(int(rng.integers(1, 65)), n - sum(lens)))
+        cuts = np.concatenate([[0], np.cumsum(lens)])
+        check(np.concatenate([b.process(x[:, a:z]) for a, z in zip(cuts[:-1], cuts[1:])], axis=-1), n, "odd partition")
+        b.Reset(prewarm=True)
+        check(b.render(list(x)), n, "one launch")
+        # persistent block mode, mixed widths: one session for the three groups
+        b.Reset(prewarm=True)
+        assert b.set_persistent(True) and b.kernel_name() == "nam_wn_reg_kernel"
+        xd = torch.from_numpy(x[:, None, :]).cuda()
+        yd = torch.zeros_like(xd)
+        T = xd.shape[2]
+        nb = n // block
+        torch.cuda.synchronize()
+        for k in range(nb):
+            b.process_device(xd.data_ptr() + k * block * 4, yd.data_ptr() + k * block * 4, block, T)
+            if k in (3, 20):
+                b.flush()  # the launch leaves, the next buffer starts it again: state through HBM and back
+        b.flush()
+        torch.cuda.synchronize()
+        check(yd.cpu().numpy()[:, 0, :nb * block], nb * block, "persistent")
+        b.close()
+
+    # a width change in the middle of a persistent session: the moved stream restarts from Reset + prewarm
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    b = model.batch(4, block)
+    assert b.set_persistent(True)
+    b.Reset(prewarm=True)
+    b.SetSlimmableSize(0.0, [1])
+    ref = oracle.get_dsp(model_path(name), fast_tanh=True)
+    ref.SetSlimmableSize(0.0)
+    ref.Reset(48000.0, block)
+    seg = block * 6
+    ys, want = [], []
+    for i, r in enumerate([0.0, 1.0, 0.5, 0.0]):
+        if i:
+            b.SetSlimmableSize(r, [1])
+            ref.SetSlimmableSize(r)
+        xs = x[:4, i * seg:(i + 1) * seg]
+        ys.append(b.process_stream(xs, block))
+        want.append(ref.process_stream(xs[1], block))
+    y = np.concatenate(ys, axis=-1)
+    assert float(np.max(np.abs(np.concatenate(want, axis=-1) - y[1]))) <= 5e-5
+    full = _oracle_run(oracle, name, x[0, :4 * seg], block, True)
+    assert float(np.max(np.abs(full - y[0]))) <= 5e-5
+    b.close()

@@ -44,7 +44,7 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
     ("wavenet_a1_standard", 15), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
     ("synth_a1_mixed", 7),  # kernel size 3 everywhere, several arrays: the wave-specialised + interleaved MFMA kernels
     ("synth_a1_lite", 15), ("synth_a1_feather", 15), ("synth_a1_c14", 7),  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
-    ("slimmable_wavenet", 1),  # 3 channels: VALU kernel only
+    ("slimmable_wavenet", 17),  # 3 channels: VALU kernel, and (dilations up to 512 in LDS-resident rings) nam_wn_reg_kernel
     # FiLMs / gating / nested condition_dsp / multi-channel: the register-resident kernel (bit 4) where every layer is
     # one of its instantiated shapes, else the op interpreter alone (a post-stack head)
     ("wavenet_a2_max", 16), ("wavenet_condition_dsp", 16), ("synth_multich", 16), ("synth_leakyhardtanh", 16),
