@@ -40,19 +40,27 @@ using mf::f4;
 using mf::lds_ld4;
 using mf::lds_st4;
 
+using i4 = __attribute__((ext_vector_type(4))) int;
+
 // the fields of a WrOp the kernel reads, as scalars (a whole-struct copy would park the float and the padding in scratch)
 struct WrOpS
 {
-  int type, shape, w, hist, ring, dil, flags, act, act2, n_out, scale_bits, slot;
+  int type, shape, w, hist, ring, dil, flags, act, act2, n_in, n_out, scale_bits, slot;
   __device__ __forceinline__ float scale() const { return __builtin_bit_cast(float, scale_bits); }
 };
-__device__ __forceinline__ WrOpS wr_fetch(const WrOp* ops, int i)
+// op i of the program, from the LDS copy of the blob (every lane reads the same words: broadcast reads; the values go
+// to scalar registers). From global memory an op cost a cache round trip (~0.5 us) that a small layer does not cover.
+__device__ __forceinline__ WrOpS wr_fetch(const char* lds, unsigned ops_b, int i)
 {
-  const int* p = reinterpret_cast<const int*>(ops + i);
   static_assert(offsetof(WrOp, scale) == 44 && offsetof(WrOp, n_out) == 40 && offsetof(WrOp, act) == 28
-                  && offsetof(WrOp, ring) == 16 && offsetof(WrOp, slot) == 48,
+                  && offsetof(WrOp, ring) == 16 && offsetof(WrOp, slot) == 48 && sizeof(WrOp) == 64,
                 "WrOp layout");
-  return WrOpS{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[10], p[11], p[12]};
+  const unsigned a = ops_b + (unsigned)i * 64u;
+  const i4 q0 = *reinterpret_cast<const i4*>(lds + a), q1 = *reinterpret_cast<const i4*>(lds + a + 16u),
+           q2 = *reinterpret_cast<const i4*>(lds + a + 32u);
+  const int q12 = *reinterpret_cast<const int*>(lds + a + 48u);
+  auto u = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  return WrOpS{u(q0[0]), u(q0[1]), u(q0[2]), u(q0[3]), u(q1[0]), u(q1[1]), u(q1[2]), u(q1[3]), u(q2[0]), u(q2[1]), u(q2[2]), u(q2[3]), u(q12)};
 }
 
 struct WrRegs
@@ -74,16 +82,7 @@ __device__ __forceinline__ void lds_st1(char* lds, unsigned byte_off, float v)
 }
 
 using f2 = __attribute__((ext_vector_type(2))) float;
-using i4 = __attribute__((ext_vector_type(4))) int;
 
-__device__ __forceinline__ int lds_ldi(const char* lds, unsigned byte_off)
-{
-  return *reinterpret_cast<const int*>(lds + byte_off);
-}
-__device__ __forceinline__ void lds_sti(char* lds, unsigned byte_off, int v)
-{
-  *reinterpret_cast<int*>(lds + byte_off) = v;
-}
 
 // A layer's conv-input ring (plan.h): [ceil(C / 4)][R][gs] floats, gs = 4 (the last group: C % 4) — a lane's frame of a
 // group is one b128 / b64 / b32 access (three b32 for gs = 3), and the lane stride gs is bank-conflict free for each.
@@ -319,7 +318,7 @@ __device__ __forceinline__ void wr_act(int type, f2* v, const WrActP<N>& ap)
 // FM >= 0: FiLM mask / shift mask / blend / activation types are compile-time (one straight-line block); FM < 0: run-time
 // flags from the op
 template <int COND, int C, int B, bool G, int K, int HO, int FM, int SM, int BL, int A1, int A2>
-__device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, int lane, unsigned pos_b)
+__device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, int lane, int posv)
 {
   constexpr WrLayerLayout L = wr_layer_layout(COND, C, B, G, K, HO);
   constexpr int ZC = G ? 2 * B : B;
@@ -368,7 +367,7 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
   }
   // the layer's ring: this lane's frame goes to index (position + lane) mod R, tap k is (K - 1 - k) * dilation behind it
   const int R = op.ring;
-  int widx = lds_ldi(lds, pos_b + (unsigned)op.slot * 4u) + lane;
+  int widx = __builtin_amdgcn_readlane(posv, op.slot) + lane; // (write positions: lane = slot)
   widx -= widx >= R ? R : 0;
   const unsigned hb = (unsigned)op.hist * 4u;
   wr_ring_put<C>(lds, hb, widx, R, ci);
@@ -496,6 +495,96 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
     r.x[i] += pget(l1, i);
 }
 
+// WR_RUN: consecutive PLAIN layers (model.cpp:183-393 with no FiLM, no gating, no head1x1, condition size 1, kernel size
+// 3, C = bottleneck <= 4, so every matrix row is one b128). One dispatch for the whole run; layer l + 1's weights and
+// ring record are requested before layer l computes, so a layer costs one exposed LDS round trip (its taps) instead of
+// four. Same weight block layout and the same summation order as wr_layer.
+template <int C>
+struct WrPlainW
+{
+  f4 conv[3 * C], conv_b, mix, l1[C], l1_b;
+  i4 rec; // {-, ring area float offset, R, dilation | slot << 24}
+};
+template <int C>
+__device__ __forceinline__ void wr_plain_ld(WrPlainW<C>& w, const char* lds, unsigned wb, unsigned rec_b)
+{
+  constexpr WrLayerLayout L = wr_layer_layout(1, C, C, false, 3, 0);
+  w.rec = *reinterpret_cast<const i4*>(lds + rec_b);
+#pragma unroll
+  for (int i = 0; i < 3 * C; i++)
+    w.conv[i] = lds_ld4(lds, wb + (unsigned)(L.conv + 4 * i) * 4u);
+  w.conv_b = lds_ld4(lds, wb + (unsigned)L.conv_b * 4u);
+  w.mix = lds_ld4(lds, wb + (unsigned)L.mixin * 4u);
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    w.l1[i] = lds_ld4(lds, wb + (unsigned)(L.l1 + 4 * i) * 4u);
+  w.l1_b = lds_ld4(lds, wb + (unsigned)L.l1_b * 4u);
+}
+// One plain layer with the weights in `w`; the next layer's weights / record (LDS byte addresses nxt_wb / nxt_rec) are
+// requested BEHIND this layer's taps: LDS returns in order, so the arithmetic waits for the taps only (a counted
+// lgkmcnt) while the 16 weight reads stream in under it.
+template <int C, int ACT>
+__device__ __forceinline__ void wr_plain_layer(WrRegs& r, const WrPlainW<C>& w, WrPlainW<C>& nxt, unsigned nxt_wb,
+                                               unsigned nxt_rec, char* lds, int lane, int posv)
+{
+  const int R = w.rec[2], dil = w.rec[3] & 0xffffff;
+  int widx = __builtin_amdgcn_readlane(posv, __builtin_amdgcn_readfirstlane(w.rec[3] >> 24)) + lane;
+  widx -= widx >= R ? R : 0;
+  const unsigned hb = (unsigned)w.rec[1] * 4u;
+  wr_ring_put<C>(lds, hb, widx, R, r.x);
+  float t0[C], t1[C]; // taps 2 and 1 dilations back
+  int i0 = widx - 2 * dil, i1 = widx - dil;
+  i0 += i0 < 0 ? R : 0;
+  i1 += i1 < 0 ? R : 0;
+  wr_ring_get<C>(lds, hb, i0, R, t0);
+  wr_ring_get<C>(lds, hb, i1, R, t1);
+  wr_fence();
+  wr_plain_ld(nxt, lds, nxt_wb, nxt_rec);
+  wr_fence();
+  const f4 m = w.mix * r.cond[0]; // input mixin (no bias): 0 + W cond
+  f4 z = w.conv_b;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    z = __builtin_elementwise_fma(w.conv[i], f4{t0[i], t0[i], t0[i], t0[i]}, z);
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    z = __builtin_elementwise_fma(w.conv[C + i], f4{t1[i], t1[i], t1[i], t1[i]}, z);
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    z = __builtin_elementwise_fma(w.conv[2 * C + i], f4{r.x[i], r.x[i], r.x[i], r.x[i]}, z);
+  z += m;
+  float a[C];
+#pragma unroll
+  for (int c = 0; c < C; c++)
+  {
+    a[c] = d_act<ACT>(z[c], 0.f, 0.f, 0.f, 0.f, 0.f);
+    r.hacc[c] += a[c];
+  }
+  f4 y = w.l1_b;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    y = __builtin_elementwise_fma(w.l1[i], f4{a[i], a[i], a[i], a[i]}, y);
+#pragma unroll
+  for (int c = 0; c < C; c++)
+    r.x[c] += y[c];
+}
+template <int C, int ACT>
+__device__ __forceinline__ void wr_run(WrRegs& r, const WrOpS& op, char* lds, int lane, int posv, int n_layers, int w_stride)
+{
+  WrPlainW<C> wa, wb;
+  const unsigned w0 = (unsigned)op.w * 4u, ws = (unsigned)w_stride * 4u, rec0 = (unsigned)op.hist * 4u;
+  wr_plain_ld(wa, lds, w0, rec0);
+  // two layers per trip (register sets a / b swap roles); every load is unconditional (the last ones re-read the final
+  // layer) so that the LDS counters stay exact
+  for (int l = 0; l < n_layers; l += 2)
+  {
+    const unsigned l1 = (unsigned)min(l + 1, n_layers - 1), l2 = (unsigned)min(l + 2, n_layers - 1);
+    wr_plain_layer<C, ACT>(r, wa, wb, w0 + l1 * ws, rec0 + l1 * 16u, lds, lane, posv);
+    if (l + 1 < n_layers)
+      wr_plain_layer<C, ACT>(r, wb, wa, w0 + l2 * ws, rec0 + l2 * 16u, lds, lane, posv);
+  }
+}
+
 // _LayerArray::process prologue, model.cpp:463-492: the head accumulator starts from the previous array's head output
 // (or zero), the rechannel 1x1 (no bias) maps the previous array's layer output (or the model input) to C channels
 template <int IN, int C>
@@ -529,6 +618,9 @@ __device__ __forceinline__ void wr_array_end(WrRegs& r, const WrOpS& op, const c
 
 } // namespace
 
+// SET: which layer code the instantiation carries — 0: WR_LAYER shapes only (FiLM / gating / nested-condition models),
+// 1: WR_RUN shapes only (plain stacks: a third of the registers, no spills, a short dispatch), 2: both.
+template <int SET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_kernel(const WrArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char lds_wr[];
@@ -556,15 +648,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   int* const sti = reinterpret_cast<int*>(st);
   float* const st_ring = st + kWrPosInts;
   const int blob_floats = G.blob_floats, hist_floats = G.hist_floats;
-  const unsigned pos_b = (unsigned)blob_floats * 4u; // LDS: [blob][positions][rings]
-  const unsigned ring_b = pos_b + (unsigned)kWrPosInts * 4u;
+  const unsigned ring_b = (unsigned)blob_floats * 4u; // LDS: [blob][rings]
   const bool whole = pers || a.n_frames > kBlock; // more than one block: the whole ring area comes in (and goes back)
 
   // Prologue. The write positions first (lane = slot): every ring address depends on them. A one-block launch then
   // requests the windows its taps reach — table entries {float offset, R, slot | gs << 8, o} straight from memory
   // (wavefront-uniform: scalar loads), lane j <-> ring index wrap(position - o + j) — before the weights, so that both
-  // travel together; everything lands in LDS afterwards: [blob (weights, tables)][positions][rings].
+  // travel together; everything lands in LDS afterwards: [blob (weights, tables, program)][rings].
   const int pos_in = sti[lane];
+  const int ring_len = lane < G.n_slots ? reinterpret_cast<const int*>(G.blob + G.tab_ring)[lane] : 0; // R of slot `lane`
   const i4* const tab_pf = reinterpret_cast<const i4*>(G.blob + G.tab_pf);
   const int n_pf = whole ? 0 : G.n_pf;
   constexpr int kWin = 32;
@@ -602,7 +694,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         lds_st4(lds, (unsigned)i * 4u, v[u]);
     }
   }
-  lds_sti(lds, pos_b + (unsigned)lane * 4u, pos_in);
   if (whole)
   {
     for (int base = 0; base < hist_floats; base += 8 * 256)
@@ -642,41 +733,101 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   const float* const in = a.in ? a.in + (long)stream * a.in_ch * a.io_stride : nullptr;
   float* const out = a.out ? a.out + (long)stream * a.out_ch * a.io_stride : nullptr;
-  const WrOp* const ops = G.ops;
-  const int n_ops = G.n_ops, n_slots = G.n_slots;
-  const unsigned rtab_b = (unsigned)G.tab_ring * 4u;
+  const unsigned ops_b = (unsigned)G.tab_ops * 4u;
+  const int n_ops = G.n_ops;
+  int posv = pos_in; // the rings' write positions, lane = slot
 
   int n = kBlock;
+  // The next block's input samples are requested half a block ahead (a memory round trip per block otherwise sits in
+  // front of the first layer): the next window of a multi-block launch, or — persistent session — the window of the
+  // next command when the early look at the ring already shows it.
+  float in_pf[kWrRegs];
+  int pf_off = -1; // the frame offset in_pf belongs to; -1 = none
+  auto load_in = [&](float* dst, int off, int count) {
+#pragma unroll
+    for (int c = 0; c < kWrRegs; c++)
+    {
+      dst[c] = 0.0f;
+      if (in && c < a.in_ch && lane < count)
+        dst[c] = pers ? persist_in(in + (long)c * a.io_stride + off + lane) : in[(long)c * a.io_stride + off + lane];
+    }
+  };
+  const int pf_at = n_ops >> 1;
   for (int f0 = pers ? (int)cmd_off : 0;;)
   {
     n = pers ? kBlock : min(kBlock, a.n_frames - f0);
     if (pers)
       pw.look_ahead(a.ps);
     WrRegs r;
+    if (pf_off == f0)
+    {
+#pragma unroll
+      for (int c = 0; c < kWrRegs; c++)
+        r.in[c] = in_pf[c];
+    }
+    else
+      load_in(r.in, f0, n);
+    pf_off = -1;
 #pragma unroll
     for (int c = 0; c < kWrRegs; c++)
     {
-      r.in[c] = 0.0f;
-      if (in && c < a.in_ch && lane < n)
-        r.in[c] = pers ? persist_in(in + (long)c * a.io_stride + f0 + lane) : in[(long)c * a.io_stride + f0 + lane];
       r.cond[c] = r.in[c]; // a net without condition_dsp (and the nested net itself) is conditioned on its input
       r.x[c] = r.hacc[c] = r.hout[c] = 0.0f;
     }
-    WrOpS cur = wr_fetch(ops, 0);
+    WrOpS cur = wr_fetch(lds, ops_b, 0);
     for (int oi = 0; oi < n_ops; oi++)
     {
-      const WrOpS nxt = wr_fetch(ops, min(oi + 1, n_ops - 1)); // requested before this op runs
+      const WrOpS nxt = wr_fetch(lds, ops_b, min(oi + 1, n_ops - 1)); // requested before this op runs
+      if (oi == pf_at)
+      {
+        int nf = -1, nn = kBlock;
+        if (pers)
+        {
+          if ((unsigned)(pw.spec >> 32) == pw.seq + 2u)
+            nf = (int)(unsigned)pw.spec;
+        }
+        else if (f0 + kBlock < a.n_frames)
+        {
+          nf = f0 + kBlock;
+          nn = min(kBlock, a.n_frames - nf);
+        }
+        if (nf >= 0)
+        {
+          load_in(in_pf, nf, nn);
+          pf_off = nf;
+        }
+      }
       switch (cur.type)
       {
         case WR_LAYER:
-          switch (cur.shape)
+          if constexpr (SET != 1)
           {
+            switch (cur.shape)
+            {
 #define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
-  case ID: wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane, pos_b); break;
-            WR_LAYER_SHAPES(X)
+  case ID: wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane, posv); break;
+              WR_LAYER_SHAPES(X)
 #undef X
-            default: __builtin_trap();
+              default: __builtin_trap();
+            }
           }
+          else
+            __builtin_trap();
+          break;
+        case WR_RUN:
+          if constexpr (SET != 0)
+          {
+            switch (cur.shape)
+            {
+#define X(ID, C, A) \
+  case ID: wr_run<C, A>(r, cur, lds, lane, posv, cur.n_in, cur.n_out); break;
+              WR_RUN_SHAPES(X)
+#undef X
+              default: __builtin_trap();
+            }
+          }
+          else
+            __builtin_trap();
           break;
         case WR_ARRAY_BEGIN:
           switch (cur.shape)
@@ -716,14 +867,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
       cur = nxt;
     }
-    // every ring moves on by the block's n frames (lane = slot)
-    if (lane < n_slots)
-    {
-      const int R = lds_ldi(lds, rtab_b + (unsigned)lane * 4u);
-      int p = lds_ldi(lds, pos_b + (unsigned)lane * 4u) + n;
-      p -= p >= R ? R : 0;
-      lds_sti(lds, pos_b + (unsigned)lane * 4u, p);
-    }
+    // every ring moves on by the block's n frames (lane = slot; lanes without a slot stay at 0)
+    posv += ring_len > 0 ? n : 0;
+    posv -= posv >= ring_len ? ring_len : 0;
     if (pers)
     {
       if (!pw.next(a.ps, (int)blockIdx.x, cmd_off))
@@ -775,16 +921,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           st_ring[off[u]] = v[u];
     }
   }
-  sti[lane] = lds_ldi(lds, pos_b + (unsigned)lane * 4u);
+  sti[lane] = posv;
   if (pers)
     pw.leave(a.ps, (int)blockIdx.x);
 }
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream)
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, hipStream_t stream)
 {
   if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL(nam_wn_reg_kernel, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
+  if (layers && runs)
+    hipLaunchKernelGGL(nam_wn_reg_kernel<2>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
+  else if (runs)
+    hipLaunchKernelGGL(nam_wn_reg_kernel<1>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL(nam_wn_reg_kernel<0>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -109,15 +109,14 @@ struct LSTMArgs
 // with its own op list, weights, LDS layout and state ("LDS repacking" per width); the audio windows are shared.
 struct WrGroup
 {
-  const WrOp* ops;
-  const float* blob; // weights and tables as the kernel's LDS copy holds them (a multiple of 4 floats)
+  const float* blob; // weights, tables and the op list as the kernel's LDS copy holds them (a multiple of 4 floats)
   float* state; // [stream][state_stride]
   const int* stream_map; // optional: position inside the group -> stream index; nullptr = identity
   long state_stride;
   int n_ops, blob_floats;
   int hist_floats; // floats of ring area behind the positions
   int n_slots; // layers (write positions)
-  int tab_rows, n_rows, tab_pf, n_pf, tab_ring; // blob float offsets / entry counts of the tables
+  int tab_rows, n_rows, tab_pf, n_pf, tab_ring, tab_ops; // blob float offsets / entry counts of the tables
   int first; // first workgroup of the group
 };
 struct WrArgs
@@ -132,7 +131,7 @@ struct WrArgs
   PersistArgs ps;
 };
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream);
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, hipStream_t stream);
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);

@@ -94,8 +94,7 @@ struct WidthGroup
   float* d_blob = nullptr;
   NamOp* d_ops = nullptr;
   A1Plan* d_a1 = nullptr;
-  WrOp* d_wr_ops = nullptr; // nam_wn_reg_kernel's macro-ops and weights (plan.h: WrPlan)
-  float* d_wr_blob = nullptr;
+  float* d_wr_blob = nullptr; // nam_wn_reg_kernel's weights, tables and macro-ops (plan.h: WrPlan)
   float* d_state = nullptr; // [n_streams][state_stride] (allocated when the first stream joins)
   float* d_init = nullptr; // LSTM initial state
   long state_stride = 0;
@@ -191,8 +190,6 @@ int upload_group(nam_hip_batch* b, WidthGroup& g)
     }
     if (p.wr.ok)
     {
-      NAM_HIP_CHECK(hipMalloc(&g.d_wr_ops, p.wr.ops.size() * sizeof(WrOp)));
-      NAM_HIP_CHECK(hipMemcpy(g.d_wr_ops, p.wr.ops.data(), p.wr.ops.size() * sizeof(WrOp), hipMemcpyHostToDevice));
       NAM_HIP_CHECK(hipMalloc(&g.d_wr_blob, p.wr.blob.size() * sizeof(float)));
       NAM_HIP_CHECK(hipMemcpy(g.d_wr_blob, p.wr.blob.data(), p.wr.blob.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -271,7 +268,7 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
   const bool a1 = g.plan->a1.valid && g.d_a1;
   const bool mfma = a1 && (g.plan->a1.ws_ok || g.plan->a1.kt_ok);
   const bool il = a1 && g.plan->a1.il_ok;
-  const bool wr = g.plan->wr.ok && g.d_wr_ops;
+  const bool wr = g.plan->wr.ok && g.d_wr_blob;
   // a model no A1 kernel takes (FiLMs, gating, a nested condition_dsp ...) runs with its activations in registers when
   // its layers are among the instantiated shapes, else through the op interpreter
   const int fallback = a1 ? NAM_HIP_KERNEL_A1 : (wr ? NAM_HIP_KERNEL_WN_REG : NAM_HIP_KERNEL_GENERIC);
@@ -367,17 +364,19 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   WrArgs a;
   std::memset(&a, 0, sizeof(a));
   int total = 0, lds_bytes = 0;
+  bool layers = false, runs = false;
   for (int k = 0; k < n_groups; k++)
   {
     WidthGroup& g = *groups[k];
     const WrPlan& w = g.plan->wr;
+    layers = layers || w.has_layers;
+    runs = runs || w.has_runs;
     if (g.state_family >= 0 && g.state_family != 2)
       return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
                   "kernel change crosses state layouts (the op program's rings, the A1 kernels' zero-padded rings and "
                   "nam_wn_reg_kernel's LDS-image rings differ): call nam_hip_batch_reset before switching");
     g.state_family = 2;
     WrGroup& G = a.g[k];
-    G.ops = g.d_wr_ops;
     G.blob = g.d_wr_blob;
     G.state = g.d_state;
     G.stream_map = maps[k];
@@ -391,6 +390,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
     G.tab_pf = w.tab_pf;
     G.n_pf = w.n_pf;
     G.tab_ring = w.tab_ring;
+    G.tab_ops = w.tab_ops;
     G.first = total;
     total += counts[k];
     lds_bytes = std::max(lds_bytes, w.lds_bytes);
@@ -403,7 +403,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   a.in_ch = groups[0]->plan->in_channels;
   a.out_ch = groups[0]->plan->out_channels;
   a.ps = persist_args(b);
-  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, s));
+  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, layers, runs, s));
   return NAM_HIP_OK;
 }
 
@@ -422,7 +422,7 @@ WrGroupList wr_groups(nam_hip_batch* b)
   {
     if (g.streams.empty())
       continue;
-    if (out.n == kWrMaxGroups || g.plan->arch != ARCH_WAVENET || !g.d_wr_ops || pick_kernel(b, g) != NAM_HIP_KERNEL_WN_REG
+    if (out.n == kWrMaxGroups || g.plan->arch != ARCH_WAVENET || !g.d_wr_blob || pick_kernel(b, g) != NAM_HIP_KERNEL_WN_REG
         || g.plan->in_channels != full.in_channels || g.plan->out_channels != full.out_channels)
     {
       out.n = 0;
@@ -1001,8 +1001,6 @@ void free_group(WidthGroup& g)
     (void)hipFree(g.d_blob);
   if (g.d_ops)
     (void)hipFree(g.d_ops);
-  if (g.d_wr_ops)
-    (void)hipFree(g.d_wr_ops);
   if (g.d_wr_blob)
     (void)hipFree(g.d_wr_blob);
   if (g.d_a1)

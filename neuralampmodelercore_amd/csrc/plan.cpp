@@ -1485,6 +1485,8 @@ struct WrBuilder
         op.shape = shape;
         op.w = off;
         op.slot = (int)ring_of_slot.size();
+        if (cond_dim == 1 && B == C && !G && K == 3 && h1o == 0 && flags == 0)
+          op.run = wr_run_shape(C, a1.type) + 1;
         op.hist = ring_area(C, K, dil); // + the ring area's base, added once the weights and tables are complete
         op.ring = (K - 1) * dil + kBlock;
         op.dil = dil;
@@ -1535,6 +1537,16 @@ int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kern
   return -1;
 }
 
+int wr_run_shape(int channels, int act)
+{
+#define X(ID, C, A) \
+  if (channels == C && act == A) \
+    return ID;
+  WR_RUN_SHAPES(X)
+#undef X
+  return -1;
+}
+
 int wr_pair_shape(int n_in, int n_out)
 {
 #define X(ID, IN, OUT) \
@@ -1553,6 +1565,52 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
     WrBuilder b(wr);
     b.net(wn, false);
     static_assert(sizeof(WrBuilder::Entry) == 16, "table entries are int4");
+    // consecutive plain layers of one shape (weight blocks at the layout's stride) become one WR_RUN
+    struct Run
+    {
+      size_t op; // index of the WR_RUN op
+      int table; // blob float offset of its records
+      std::vector<WrOp> layers;
+    };
+    std::vector<Run> runs;
+    {
+      std::vector<WrOp> fused;
+      for (size_t i = 0; i < wr.ops.size();)
+      {
+        const WrOp& o = wr.ops[i];
+        if (o.type != WR_LAYER || o.run <= 0)
+        {
+          fused.push_back(o);
+          i++;
+          continue;
+        }
+        size_t j = i + 1;
+        while (j < wr.ops.size() && wr.ops[j].type == WR_LAYER && wr.ops[j].run == o.run
+               && wr.ops[j].w - wr.ops[j - 1].w == wr.ops[i + 1].w - o.w)
+          j++;
+        WrOp r;
+        std::memset(&r, 0, sizeof(r));
+        r.type = WR_RUN;
+        r.shape = o.run - 1;
+        r.w = o.w;
+        r.n_in = (int)(j - i);
+        r.n_out = j - i > 1 ? wr.ops[i + 1].w - o.w : 0; // weight stride (floats)
+        r.act = o.act;
+        Run run;
+        run.op = fused.size();
+        run.table = b.reserve((int)(j - i) * 4);
+        run.layers.assign(wr.ops.begin() + (long)i, wr.ops.begin() + (long)j);
+        runs.push_back(std::move(run));
+        fused.push_back(r);
+        i = j;
+      }
+      wr.ops = std::move(fused);
+      for (const auto& o : wr.ops)
+      {
+        wr.has_layers = wr.has_layers || o.type == WR_LAYER;
+        wr.has_runs = wr.has_runs || o.type == WR_RUN;
+      }
+    }
     wr.tab_rows = b.table(b.rows);
     wr.n_rows = (int)b.rows.size();
     wr.tab_pf = b.table(b.pf);
@@ -1560,10 +1618,22 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
     wr.tab_ring = b.reserve((int)b.ring_of_slot.size());
     if (!b.ring_of_slot.empty())
       std::memcpy(&wr.blob[(size_t)wr.tab_ring], b.ring_of_slot.data(), b.ring_of_slot.size() * sizeof(int32_t));
-    const int hist_base = (int)wr.blob.size() + kWrPosInts; // LDS: weights and tables | write positions | rings
+    wr.tab_ops = b.reserve((int)wr.ops.size() * 16); // the macro-ops themselves: fetched from LDS, one op ahead
+    const int hist_base = (int)wr.blob.size(); // LDS: weights, tables, program | rings
     for (auto& op : wr.ops)
       if (op.type == WR_LAYER)
         op.hist += hist_base;
+    for (const auto& run : runs)
+    {
+      wr.ops[run.op].hist = run.table;
+      for (size_t l = 0; l < run.layers.size(); l++)
+      {
+        const WrOp& o = run.layers[l];
+        const int32_t rec[4] = {o.w, o.hist + hist_base, o.ring, o.dil | (o.slot << 24)};
+        std::memcpy(&wr.blob[(size_t)run.table + 4 * l], rec, sizeof(rec));
+      }
+    }
+    std::memcpy(&wr.blob[(size_t)wr.tab_ops], wr.ops.data(), wr.ops.size() * sizeof(WrOp));
     wr.hist_floats = b.hist;
     wr.state_floats = (kWrPosInts + b.hist + 63) / 64 * 64;
     wr.lds_bytes = (hist_base + wr.hist_floats) * 4;

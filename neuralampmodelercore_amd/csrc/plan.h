@@ -369,6 +369,8 @@ struct A1Plan
 // output becomes the condition", "store the output"). The only LDS traffic is the weights (broadcast b128 reads) and each
 // layer's conv input, which lives in an LDS-RESIDENT RING of exactly lookback + 64 frames (the reference's RingBuffer,
 // NAM/ring_buffer.cpp:7-109, without the rewind): the dilation history never leaves the CU while a launch runs.
+//   program: the macro-ops sit in the blob too (`tab_ops`): a global-memory fetch per op costs a cache round trip that
+//            a small layer does not cover; from LDS the next op arrives while the current one runs
 //   weights: `blob` is copied to LDS once per launch; per matrix [in][pad4(out)] (transposed), zero padded; grouped convs
 //            expanded to dense (block-diagonal); a layer's block has a fixed layout given its shape (inactive FiLMs
 //            keep their zeroed slot), see wr_layer_layout; behind the weights three int tables (below)
@@ -377,7 +379,7 @@ struct A1Plan
 //            so a lane appends / fetches its frame's group with ONE ds_write / ds_read (b128 / b64 / b32: the lane stride
 //            of every shape is bank-conflict free). One write position per layer ("slot").
 //   state:   per stream [64 ints: the slots' write positions][the rings, exactly as in LDS]
-//   LDS:     [blob][64 ints: positions][rings]
+//   LDS:     [blob][rings]; the write positions live in a register (lane = slot)
 //   tables (int4 entries {float offset inside the ring area, R, slot | gs << 8, o}): entry = one 64-frame window of one
 //            channel: lane j <-> ring index wrap(position - o + j), float offset + index * gs.
 //            `rows`: one entry per channel with o = 0 (the block being written; the kernel substitutes o = frames
@@ -389,7 +391,12 @@ enum WrOpType : int32_t
   WR_LAYER = 1,
   WR_ARRAY_END = 2, // head output = head_rechannel(head accumulator) (+ bias)
   WR_SET_COND = 3, // condition registers = scale * head output (the nested condition_dsp's result)
-  WR_OUTPUT = 4 // out[ch] = scale * head output[ch]
+  WR_OUTPUT = 4, // out[ch] = scale * head output[ch]
+  // a run of consecutive PLAIN layers of one shape (condition size 1, bottleneck = channels <= 4, kernel size 3, no
+  // gating / FiLM / head1x1, a parameterless activation): one dispatch for the run, the next layer's weights requested
+  // while the current layer computes. `n_in` = layers, `w` = the first layer's weight block (the others follow at the
+  // layout's stride), `hist` = LDS float offset of the per-layer records {unused, ring area offset, R, dilation | slot << 24}
+  WR_RUN = 5
 };
 
 struct WrOp // 16 x int32 = 64 bytes
@@ -407,7 +414,8 @@ struct WrOp // 16 x int32 = 64 bytes
   int32_t n_in, n_out; // WR_ARRAY_BEGIN: input size, channels; WR_ARRAY_END: head input size, head size; SET_COND/OUTPUT: count
   float scale; // SET_COND / OUTPUT: head_scale
   int32_t slot; // WR_LAYER: index of the layer's write position
-  int32_t pad[3];
+  int32_t run; // WR_LAYER (planner only): run shape id + 1 when the layer can join a WR_RUN, else 0
+  int32_t pad[2];
 };
 static_assert(sizeof(WrOp) == 64, "WrOp must stay 64 bytes");
 
@@ -423,12 +431,14 @@ struct WrPlan
   std::vector<WrOp> ops;
   std::vector<float> blob; // weights, then the tables (int bit patterns)
   int n_layers = 0; // = slots
+  bool has_layers = false, has_runs = false; // op types in the program (which kernel instantiation can run it)
   int state_floats = 0; // per stream: kWrPosInts + hist_floats, rounded up to a multiple of 64
   int hist_floats = 0; // floats of the ring area (a multiple of 4)
   int lds_bytes = 0; // blob + positions + rings
   int tab_rows = 0, n_rows = 0; // blob float offset / entry count of the `rows` table
   int tab_pf = 0, n_pf = 0; // ... of the one-block prefetch windows
   int tab_ring = 0; // ... of R per slot (n_layers ints, padded to 4)
+  int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
 };
 
 // The layer shapes kernel_wn_reg.hip instantiates — (id, condition size, channels, bottleneck, gating, kernel size,
@@ -460,6 +470,11 @@ struct WrPlan
   X(13, 3, 4, 4, false, 3, 0, -1, 0, 0, -1, -1) \
   X(14, 3, 2, 2, false, 3, 0, -1, 0, 0, -1, -1) \
   X(18, 1, 1, 1, false, 3, 0, -1, 0, 0, -1, -1)
+// plain-layer runs (WR_RUN): (id, channels, activation)
+#define WR_RUN_SHAPES(X) \
+  X(0, 1, ACT_RELU) X(1, 2, ACT_RELU) X(2, 3, ACT_RELU) X(3, 4, ACT_RELU) \
+  X(4, 1, ACT_TANH) X(5, 2, ACT_TANH) X(6, 3, ACT_TANH) X(7, 4, ACT_TANH) \
+  X(8, 1, ACT_FASTTANH) X(9, 2, ACT_FASTTANH) X(10, 3, ACT_FASTTANH) X(11, 4, ACT_FASTTANH)
 #define WR_PAIR_SHAPES(X) \
   X(0, 1, 3) X(1, 3, 4) X(2, 1, 4) X(3, 6, 4) X(4, 4, 8) X(5, 4, 1) X(6, 4, 4) X(7, 1, 2) X(8, 2, 1) X(9, 3, 1) X(10, 1, 8) \
   X(11, 8, 1) X(12, 8, 4) X(13, 4, 2) X(14, 2, 2) X(15, 3, 3) X(16, 8, 8) X(17, 2, 4) X(18, 3, 2) X(19, 6, 1) X(20, 1, 1) X(21, 2, 3) X(22, 4, 3) X(23, 3, 8) X(24, 2, 8)
@@ -467,6 +482,7 @@ struct WrPlan
 int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out, int flags, int act,
                    int act2);
 int wr_pair_shape(int n_in, int n_out);
+int wr_run_shape(int channels, int act);
 // float count / offsets of a layer's weight block (shared by the planner and the kernel)
 struct WrLayerLayout
 {
