@@ -364,6 +364,9 @@ def main():
     ap.add_argument("--persistent", type=int, default=1,
                     help="--launch block: use the persistent block mode when the batch is eligible (one resident launch, one "
                          "doorbell per step); 0 = one kernel launch per step")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the distributed branch (RCCL process group, model broadcast, scatter / gather, barriers, all_reduce) even "
+                         "with WORLD_SIZE=1: the only way to execute it on a one-GPU box (tests/test_gpu_parity.py)")
     ap.add_argument("--dry-run", action="store_true", help="CPU tensors + gloo + a stub instead of the kernels (plumbing test)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -380,7 +383,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
     if distributed and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not distributed and args.gpus != 1:

@@ -618,8 +618,9 @@ __device__ __forceinline__ void wr_array_end(WrRegs& r, const WrOpS& op, const c
 
 } // namespace
 
-// SET: which layer code the instantiation carries — 0: WR_LAYER shapes only (FiLM / gating / nested-condition models),
-// 1: WR_RUN shapes only (plain stacks: a third of the registers, no spills, a short dispatch), 2: both.
+// SET: which layer code the instantiation carries — 0: the fully described WR_LAYER shapes only (wavenet_a2_max: 344
+// registers, no spills), 1: WR_RUN shapes only (plain stacks: 278 registers, a short dispatch), 2: everything (the
+// run-time-flag layer shapes spill).
 template <int SET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_kernel(const WrArgs a)
 {
@@ -805,7 +806,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             switch (cur.shape)
             {
 #define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
-  case ID: wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane, posv); break;
+  case ID: \
+    if constexpr (SET == 2 || FM >= 0) \
+      wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane, posv); \
+    else \
+      __builtin_trap(); \
+    break;
               WR_LAYER_SHAPES(X)
 #undef X
               default: __builtin_trap();
@@ -926,11 +932,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     pw.leave(a.ps, (int)blockIdx.x);
 }
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, hipStream_t stream)
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers,
+                         hipStream_t stream)
 {
   if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
-  if (layers && runs)
+  if ((layers && runs) || rt_layers)
     hipLaunchKernelGGL(nam_wn_reg_kernel<2>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
   else if (runs)
     hipLaunchKernelGGL(nam_wn_reg_kernel<1>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);

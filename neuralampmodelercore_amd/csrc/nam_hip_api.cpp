@@ -364,13 +364,14 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   WrArgs a;
   std::memset(&a, 0, sizeof(a));
   int total = 0, lds_bytes = 0;
-  bool layers = false, runs = false;
+  bool layers = false, runs = false, rt_layers = false;
   for (int k = 0; k < n_groups; k++)
   {
     WidthGroup& g = *groups[k];
     const WrPlan& w = g.plan->wr;
     layers = layers || w.has_layers;
     runs = runs || w.has_runs;
+    rt_layers = rt_layers || w.has_rt_layers;
     if (g.state_family >= 0 && g.state_family != 2)
       return fail(NAM_HIP_ERR_INVALID_ARGUMENT,
                   "kernel change crosses state layouts (the op program's rings, the A1 kernels' zero-padded rings and "
@@ -403,7 +404,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   a.in_ch = groups[0]->plan->in_channels;
   a.out_ch = groups[0]->plan->out_channels;
   a.ps = persist_args(b);
-  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, layers, runs, s));
+  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, layers, runs, rt_layers, s));
   return NAM_HIP_OK;
 }
 

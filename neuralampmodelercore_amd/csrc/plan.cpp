@@ -1537,6 +1537,16 @@ int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kern
   return -1;
 }
 
+bool wr_layer_shape_is_exact(int id)
+{
+#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
+  if (id == ID) \
+    return FM >= 0;
+  WR_LAYER_SHAPES(X)
+#undef X
+  return false;
+}
+
 int wr_run_shape(int channels, int act)
 {
 #define X(ID, C, A) \
@@ -1609,6 +1619,7 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
       {
         wr.has_layers = wr.has_layers || o.type == WR_LAYER;
         wr.has_runs = wr.has_runs || o.type == WR_RUN;
+        wr.has_rt_layers = wr.has_rt_layers || (o.type == WR_LAYER && !wr_layer_shape_is_exact(o.shape));
       }
     }
     wr.tab_rows = b.table(b.rows);

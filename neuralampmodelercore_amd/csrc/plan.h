@@ -432,6 +432,7 @@ struct WrPlan
   std::vector<float> blob; // weights, then the tables (int bit patterns)
   int n_layers = 0; // = slots
   bool has_layers = false, has_runs = false; // op types in the program (which kernel instantiation can run it)
+  bool has_rt_layers = false; // a WR_LAYER whose shape leaves FiLM set / activations to run-time flags
   int state_floats = 0; // per stream: kWrPosInts + hist_floats, rounded up to a multiple of 64
   int hist_floats = 0; // floats of the ring area (a multiple of 4)
   int lds_bytes = 0; // blob + positions + rings
@@ -482,6 +483,7 @@ struct WrPlan
 int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out, int flags, int act,
                    int act2);
 int wr_pair_shape(int n_in, int n_out);
+bool wr_layer_shape_is_exact(int id); // FiLM set, blend and activations compiled in
 int wr_run_shape(int channels, int act);
 // float count / offsets of a layer's weight block (shared by the planner and the kernel)
 struct WrLayerLayout

@@ -59,3 +59,27 @@ def test_bench_distributed_branch_world2_gloo(config, streams):
     assert line["repetitions"]["n"] == 3 and len(line["repetitions"]["ms_per_step_all"]) == 3
     assert line["value"] > 0 and line["config"]["streams_per_gpu"] == streams
     assert line["data"].startswith("dry-run")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("config,streams", [(2, 64), (5, 96)])
+def test_bench_distributed_branch_on_rccl_one_rank(config, streams):
+    """The same distributed branch on the GPU with the REAL backend: launched the way the driver launches N > 1
+    (python -m torch.distributed.run, one rank per GPU) but with one rank — RCCL process group bound to the device,
+    model-text broadcast, scatter / gather of device tensors, barriers and all_reduce(MAX) around the timed regions,
+    model.batch(device=LOCAL_RANK), persistent sessions per rank — and the kernels instead of the stub. A one-GPU box
+    cannot do more; N = 2, 4, 8 are the driver's."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-distributed", "--steps", "20",
+         "--warmup", "5", "--reps", "3", "--config", str(config), "--streams", str(streams), "--no-cpu-baseline",
+         "--no-side-runs", "--spinup-ms", "0"],
+        env=env, capture_output=True, text=True, timeout=550, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["finite"] is True
+    assert line["max_abs_err_vs_oracle"] <= 5e-5 and line["value"] > 0
+    assert line["config"]["streams_per_gpu"] == streams
