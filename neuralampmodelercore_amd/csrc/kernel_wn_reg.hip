@@ -271,6 +271,20 @@ __device__ __forceinline__ void wr_ld(WrActP<N>& a, const char* lds, unsigned ab
   for (int q = 0; q < wr_pad4(N) / 4; q++)
     a.slope[q] = lds_ld4(lds, ab + 16u + (unsigned)q * 16u);
 }
+// One activation value. The transcendental / dividing types take the hardware exp2 / rcp forms (device_common.h: mf::act_hw,
+// abs error ~1e-7, a handful of instructions) instead of libm expf / tanhf and IEEE division (a dozen instructions each:
+// a fifth of a wavenet_a2_max block); the piecewise-linear types are exact either way.
+template <int T>
+__device__ __forceinline__ float wr_act1(float x, float p0, float p1, float p2, float p3, float slope)
+{
+  if constexpr (T == ACT_TANH || T == ACT_FASTTANH || T == ACT_SIGMOID || T == ACT_SILU || T == ACT_SOFTSIGN || T == ACT_HARDSWISH)
+    return mf::act_hw(T, x, p0);
+  else if constexpr (T == ACT_FASTSIGMOID)
+    return mf::fast_sigmoid_hw(x);
+  else
+    return d_act<T>(x, p0, p1, p2, p3, slope);
+}
+
 // v[c] = act(v[c]) for rows [R0, R0 + N) of the pair vector: compile-time type (ACT >= 0) or one dispatch on the
 // wavefront-uniform run-time type, then straight-line code
 template <int N, int R0, int ACT>
@@ -285,7 +299,7 @@ __device__ __forceinline__ void wr_act(int type, f2* v, const WrActP<N>& ap)
     constexpr int T = decltype(tag)::value;
 #pragma unroll
     for (int c = 0; c < N; c++)
-      v[(R0 + c) >> 1][(R0 + c) & 1] = d_act<T>(pget(v, R0 + c), p[0], p[1], p[2], p[3], ap.slope[c >> 2][c & 3]);
+      v[(R0 + c) >> 1][(R0 + c) & 1] = wr_act1<T>(pget(v, R0 + c), p[0], p[1], p[2], p[3], ap.slope[c >> 2][c & 3]);
   };
   if constexpr (ACT >= 0)
     run(std::integral_constant<int, ACT>{});
@@ -557,7 +571,7 @@ __device__ __forceinline__ void wr_plain_layer(WrRegs& r, const WrPlainW<C>& w, 
 #pragma unroll
   for (int c = 0; c < C; c++)
   {
-    a[c] = d_act<ACT>(z[c], 0.f, 0.f, 0.f, 0.f, 0.f);
+    a[c] = wr_act1<ACT>(z[c], 0.f, 0.f, 0.f, 0.f, 0.f);
     r.hacc[c] += a[c];
   }
   f4 y = w.l1_b;
