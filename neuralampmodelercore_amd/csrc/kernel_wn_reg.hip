@@ -512,7 +512,7 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
 // WR_RUN: consecutive PLAIN layers (model.cpp:183-393 with no FiLM, no gating, no head1x1, condition size 1, kernel size
 // 3, C = bottleneck <= 4, so every matrix row is one b128). One dispatch for the whole run; layer l + 1's weights and
 // ring record are requested before layer l computes, so a layer costs one exposed LDS round trip (its taps) instead of
-// four. Same weight block layout and the same summation order as wr_layer.
+// four. Compact weight block (plan.h: wr_plain_layout), the same summation order as wr_layer.
 template <int C>
 struct WrPlainW
 {
@@ -522,7 +522,7 @@ struct WrPlainW
 template <int C>
 __device__ __forceinline__ void wr_plain_ld(WrPlainW<C>& w, const char* lds, unsigned wb, unsigned rec_b)
 {
-  constexpr WrLayerLayout L = wr_layer_layout(1, C, C, false, 3, 0);
+  constexpr WrPlainLayout L = wr_plain_layout(C); // the compact block of a plain layer: 4 C + 3 rows of four floats
   w.rec = *reinterpret_cast<const i4*>(lds + rec_b);
 #pragma unroll
   for (int i = 0; i < 3 * C; i++)
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const int ring_len = lane < G.n_slots ? reinterpret_cast<const int*>(G.blob + G.tab_ring)[lane] : 0; // R of slot `lane`
   const i4* const tab_pf = reinterpret_cast<const i4*>(G.blob + G.tab_pf);
   const int n_pf = whole ? 0 : G.n_pf;
-  constexpr int kWin = 32;
+  constexpr int kWin = 64;
   float win[kWin];
   int win_off[kWin];
   auto window = [&](int e, float& v, int& off) {
@@ -735,13 +735,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int u = 0; u < kWin; u++)
       if (u < n_pf)
         lds_st1(lds, ring_b + (unsigned)win_off[u] * 4u, win[u]);
-    for (int e0 = kWin; e0 < n_pf; e0 += 16)
+    // further windows: their table entries come from the LDS copy of the blob (no extra memory round trip)
+    const unsigned tab_b = (unsigned)G.tab_pf * 4u;
+    for (int e0 = kWin; e0 < n_pf; e0 += kWin)
     {
 #pragma unroll
-      for (int u = 0; u < 16; u++)
-        window(min(e0 + u, n_pf - 1), win[u], win_off[u]);
+      for (int u = 0; u < kWin; u++)
+      {
+        const i4 t = *reinterpret_cast<const i4*>(lds + tab_b + (unsigned)min(e0 + u, n_pf - 1) * 16u);
+        const int p = __builtin_amdgcn_readlane(pos_in, __builtin_amdgcn_readfirstlane(t[2] & 255));
+        int idx = p - t[3] + lane;
+        idx += idx < 0 ? t[1] : 0;
+        idx -= idx >= t[1] ? t[1] : 0;
+        win_off[u] = t[0] + idx * (t[2] >> 8);
+        win[u] = st_ring[win_off[u]];
+      }
 #pragma unroll
-      for (int u = 0; u < 16; u++)
+      for (int u = 0; u < kWin; u++)
         if (e0 + u < n_pf)
           lds_st1(lds, ring_b + (unsigned)win_off[u] * 4u, win[u]);
     }
@@ -919,24 +929,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   else
   {
-    // `rows` table: one entry per channel; the n frames of this launch's block sit at wrap(old position + lane)
-    const i4* const tab_rows = reinterpret_cast<const i4*>(G.blob + G.tab_rows);
+    // `rows` table (from the LDS copy of the blob): one entry per channel; the n frames of this launch's block sit at
+    // wrap(old position + lane)
+    const unsigned tab_b = (unsigned)G.tab_rows * 4u;
     const int n_rows = G.n_rows;
-    for (int e0 = 0; e0 < n_rows; e0 += 8)
+    for (int e0 = 0; e0 < n_rows; e0 += 16)
     {
-      float v[8];
-      int off[8];
+      float v[16];
+      int off[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 16; u++)
       {
-        const i4 t = tab_rows[min(e0 + u, n_rows - 1)];
-        int idx = __builtin_amdgcn_readlane(pos_in, t[2] & 255) + lane;
+        const i4 t = *reinterpret_cast<const i4*>(lds + tab_b + (unsigned)min(e0 + u, n_rows - 1) * 16u);
+        int idx = __builtin_amdgcn_readlane(pos_in, __builtin_amdgcn_readfirstlane(t[2] & 255)) + lane;
         idx -= idx >= t[1] ? t[1] : 0;
         off[u] = t[0] + idx * (t[2] >> 8);
         v[u] = lds_ld1(lds, ring_b + (unsigned)off[u] * 4u);
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 16; u++)
         if (e0 + u < n_rows && lane < n)
           st_ring[off[u]] = v[u];
     }
@@ -951,13 +962,26 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
 {
   if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
+  // more than the default 64 KB of dynamic LDS per workgroup (long dilations at 4+ channels: the official nano size
+  // keeps 68 KB of rings): raised once per instantiation
+  static bool raised[3] = {false, false, false};
+  auto launch = [&](auto kernel, int set) -> hipError_t {
+    if (lds_bytes > 64 * 1024 && !raised[set])
+    {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               kWrMaxLdsBytes);
+      if (e != hipSuccess)
+        return e;
+      raised[set] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
+    return hipGetLastError();
+  };
   if ((layers && runs) || rt_layers)
-    hipLaunchKernelGGL(nam_wn_reg_kernel<2>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
-  else if (runs)
-    hipLaunchKernelGGL(nam_wn_reg_kernel<1>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
-  else
-    hipLaunchKernelGGL(nam_wn_reg_kernel<0>, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
-  return hipGetLastError();
+    return launch(nam_wn_reg_kernel<2>, 2);
+  if (runs)
+    return launch(nam_wn_reg_kernel<1>, 1);
+  return launch(nam_wn_reg_kernel<0>, 0);
 }
 
 } // namespace namhip

@@ -1437,56 +1437,75 @@ struct WrBuilder
         for (int k = 0; k < FILM_COUNT; k++)
           if (A.film[k].active && !(k == FILM_HEAD1X1_POST && !A.head1x1_active))
             flags |= (1 << k) | (A.film[k].shift ? 1 << (8 + k) : 0);
+        // a PLAIN layer (no gating, FiLM or head1x1; condition size 1, kernel size 3, at most four channels, a
+        // parameterless activation) joins a WR_RUN and takes the compact weight block
+        const int run_shape = (cond_dim == 1 && B == C && !G && K == 3 && h1o == 0 && flags == 0) ? wr_run_shape(C, a1.type) : -1;
         const int shape = wr_layer_shape(cond_dim, C, B, G, K, h1o, flags, a1.type, G ? a2.type : (int)ACT_IDENTITY);
-        if (shape < 0)
+        if (shape < 0 && run_shape < 0)
           throw Unsupported("layer shape cond=" + std::to_string(cond_dim) + " C=" + std::to_string(C) + " B=" + std::to_string(B)
                             + (G ? " gating" : "") + " K=" + std::to_string(K) + " head1x1=" + std::to_string(h1o));
-        const WrLayerLayout L = wr_layer_layout(cond_dim, C, B, G, K, h1o);
-        const int off = reserve(L.total);
-        float* d = &wr.blob[(size_t)off];
-        // the flat stream order is conv, mixin, layer1x1, head1x1, then the 8 FiLMs (model.cpp:152-181)
-        dense(d + L.conv, w, C, zc, K, A.groups_input);
-        for (int i = 0; i < zc; i++)
-          d[L.conv_b + i] = *(w++);
-        dense(d + L.mixin, w, cond_dim, zc, 1, A.groups_input_mixin);
-        dense(d + L.l1, w, B, C, 1, A.layer1x1_groups);
-        for (int i = 0; i < C; i++)
-          d[L.l1_b + i] = *(w++);
-        if (A.head1x1_active)
+        int off = 0;
+        if (run_shape >= 0)
         {
-          dense(d + L.h1, w, B, h1o, 1, A.head1x1_groups);
-          for (int i = 0; i < h1o; i++)
-            d[L.h1_b + i] = *(w++);
+          const WrPlainLayout P = wr_plain_layout(C);
+          off = reserve(P.total);
+          float* d = &wr.blob[(size_t)off];
+          dense(d + P.conv, w, C, C, 3, A.groups_input);
+          for (int i = 0; i < C; i++)
+            d[P.conv_b + i] = *(w++);
+          dense(d + P.mixin, w, 1, C, 1, A.groups_input_mixin);
+          dense(d + P.l1, w, C, C, 1, A.layer1x1_groups);
+          for (int i = 0; i < C; i++)
+            d[P.l1_b + i] = *(w++);
         }
-        const int dims[FILM_COUNT] = {C, zc, cond_dim, zc, zc, B, C, h1o};
-        for (int k = 0; k < FILM_COUNT; k++)
+        else
         {
-          bool on = A.film[k].active;
-          if (k == FILM_HEAD1X1_POST && !A.head1x1_active)
-            on = false;
-          if (!on)
-            continue;
-          const int D = dims[k], outc = (A.film[k].shift ? 2 : 1) * D, D4 = wr_pad4(D);
-          // Conv1x1(cond -> outc, groups) + bias; outputs [0, D) scale, [D, 2D) shift: two matrices, two bias vectors
-          dense(d + L.film[k], w, cond_dim, outc, 1, A.film[k].groups, 0, D, !A.film[k].shift);
-          if (A.film[k].shift)
-            dense(d + L.film[k] + cond_dim * D4, w, cond_dim, outc, 1, A.film[k].groups, D, D);
-          float* bias = d + L.film[k] + 2 * cond_dim * D4;
-          for (int i = 0; i < D; i++)
-            bias[i] = *(w++);
-          if (A.film[k].shift)
+          const WrLayerLayout L = wr_layer_layout(cond_dim, C, B, G, K, h1o);
+          off = reserve(L.total);
+          float* d = &wr.blob[(size_t)off];
+          // the flat stream order is conv, mixin, layer1x1, head1x1, then the 8 FiLMs (model.cpp:152-181)
+          dense(d + L.conv, w, C, zc, K, A.groups_input);
+          for (int i = 0; i < zc; i++)
+            d[L.conv_b + i] = *(w++);
+          dense(d + L.mixin, w, cond_dim, zc, 1, A.groups_input_mixin);
+          dense(d + L.l1, w, B, C, 1, A.layer1x1_groups);
+          for (int i = 0; i < C; i++)
+            d[L.l1_b + i] = *(w++);
+          if (A.head1x1_active)
+          {
+            dense(d + L.h1, w, B, h1o, 1, A.head1x1_groups);
+            for (int i = 0; i < h1o; i++)
+              d[L.h1_b + i] = *(w++);
+          }
+          const int dims[FILM_COUNT] = {C, zc, cond_dim, zc, zc, B, C, h1o};
+          for (int k = 0; k < FILM_COUNT; k++)
+          {
+            bool on = A.film[k].active;
+            if (k == FILM_HEAD1X1_POST && !A.head1x1_active)
+              on = false;
+            if (!on)
+              continue;
+            const int D = dims[k], outc = (A.film[k].shift ? 2 : 1) * D, D4 = wr_pad4(D);
+            // Conv1x1(cond -> outc, groups) + bias; outputs [0, D) scale, [D, 2D) shift: two matrices, two bias vectors
+            dense(d + L.film[k], w, cond_dim, outc, 1, A.film[k].groups, 0, D, !A.film[k].shift);
+            if (A.film[k].shift)
+              dense(d + L.film[k] + cond_dim * D4, w, cond_dim, outc, 1, A.film[k].groups, D, D);
+            float* bias = d + L.film[k] + 2 * cond_dim * D4;
             for (int i = 0; i < D; i++)
-              bias[D4 + i] = *(w++);
+              bias[i] = *(w++);
+            if (A.film[k].shift)
+              for (int i = 0; i < D; i++)
+                bias[D4 + i] = *(w++);
+          }
+          act_block(d + L.act, a1, zc);
+          if (G)
+            act_block(d + L.act2, a2, B);
         }
-        act_block(d + L.act, a1, zc);
-        if (G)
-          act_block(d + L.act2, a2, B);
         WrOp& op = push(WR_LAYER);
         op.shape = shape;
         op.w = off;
         op.slot = (int)ring_of_slot.size();
-        if (cond_dim == 1 && B == C && !G && K == 3 && h1o == 0 && flags == 0)
-          op.run = wr_run_shape(C, a1.type) + 1;
+        op.run = run_shape + 1;
         op.hist = ring_area(C, K, dil); // + the ring area's base, added once the weights and tables are complete
         op.ring = (K - 1) * dil + kBlock;
         op.dil = dil;
@@ -1648,8 +1667,8 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
     wr.hist_floats = b.hist;
     wr.state_floats = (kWrPosInts + b.hist + 63) / 64 * 64;
     wr.lds_bytes = (hist_base + wr.hist_floats) * 4;
-    if (wr.lds_bytes > 64 * 1024)
-      throw WrBuilder::Unsupported("more than 64 KB of weights and rings");
+    if (wr.lds_bytes > kWrMaxLdsBytes)
+      throw WrBuilder::Unsupported("more than 156 KB of weights and rings");
     wr.ok = true;
   }
   catch (const WrBuilder::Unsupported& e)

@@ -422,6 +422,7 @@ static_assert(sizeof(WrOp) == 64, "WrOp must stay 64 bytes");
 constexpr int kWrPosInts = 64; // write positions per stream (one per layer): the header of the state, a table in LDS
 constexpr int kWrRegs = 8; // width of the register files (x, condition, head accumulator, head output)
 constexpr int kWrActFloats = 20; // per activation: p0..p3, then the PReLU slope of each of (up to) 16 rows
+constexpr int kWrMaxLdsBytes = 156 * 1024; // a workgroup of nam_wn_reg_kernel may take (nearly) a whole CU's 160 KB of LDS
 constexpr int kWrMaxGroups = 8; // width groups one launch of nam_wn_reg_kernel can serve (kernels.h: WrArgs)
 
 struct WrPlan
@@ -527,6 +528,17 @@ constexpr WrLayerLayout wr_layer_layout(int cond, int C, int B, bool gating, int
   o += kWrActFloats;
   L.total = o;
   return L;
+}
+
+// a PLAIN layer's weight block (WR_RUN): kernel size 3, C = bottleneck <= 4, condition size 1, nothing else — every
+// matrix transposed to rows of four floats: conv [3 C] (row = tap * C + input), conv bias, mixin, layer1x1 [C], its bias
+struct WrPlainLayout
+{
+  int conv, conv_b, mixin, l1, l1_b, total;
+};
+constexpr WrPlainLayout wr_plain_layout(int C)
+{
+  return WrPlainLayout{0, 12 * C, 12 * C + 4, 12 * C + 8, 16 * C + 8, 16 * C + 12};
 }
 
 // ---- LSTM ------------------------------------------------------------------------------------

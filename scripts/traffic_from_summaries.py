@@ -11,6 +11,7 @@ RUNS = [  # (summary tag, kernel function, model, streams, launch)
     ("r02", "c2_p2", "nam_a1_p2_kernel", "wavenet_a1_standard", 256, "block"),
     ("r02", "c3_lstm_row", "nam_lstm_row_kernel", "lstm", 1024, "block"),
     ("r02", "c4_wn_reg", "nam_wn_reg_kernel", "wavenet_a2_max", 512, "block"),
+    ("r02", "c5_wn_reg", "nam_wn_reg_kernel", "slimmable_wavenet", 768, "block"),
     ("r02", "c4_generic", "nam_generic_kernel", "wavenet_a2_max", 512, "block"),
     ("r02", "c2_valu", "nam_a1_kernel", "wavenet_a1_standard", 256, "block"),
 ]

@@ -22,6 +22,7 @@ from signals import two_tone  # noqa: E402
 
 MODELS = ["wavenet", "wavenet_a1_standard", "lstm", "wavenet_a2_max", "slimmable_wavenet", "wavenet_condition_dsp",
           "synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed",  # synth_*: make_synthetic_models.py
+          "synth_a1_nano",  # 4 -> 2 channels: the register-resident kernel's plain-layer runs
           "synth_a1_lite", "synth_a1_c14", "synth_a1_feather",  # channel counts that are not multiples of 4 (zero-padded for the MFMA kernel)
           "A2", "slimmable_container",  # SlimmableContainer files: the default (last) submodel
           "synth_lstm_h4x2",  # a small LSTM cell (gate-row kernel)

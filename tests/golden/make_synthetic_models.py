@@ -33,6 +33,10 @@ SPECS = {
     # the third instantiation of the compile-time-topology kernel (nam_a1_p2_kernel<8, 4>)
     "synth_a1_feather": dict(arrays=[(8, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
                                      (4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=17),
+    # the official "nano" shape: 4 -> 2 channels, ten layers each. Too narrow for the matrix-core kernels (2 channels):
+    # nam_wn_reg_kernel's plain-layer runs, 68 KB of LDS-resident rings per stream
+    "synth_a1_nano": dict(arrays=[(4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
+                                  (2, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=18),
     # 14 -> 10 channels (padded to 16 -> 12), Sigmoid: the padded channels carry f(0) = 0.5 against zero weights
     "synth_a1_c14": dict(arrays=[(14, [1, 2, 4, 8, 16, 32], "Sigmoid", True), (10, [64, 128, 256, 512, 1, 2], "Sigmoid", True)], seed=16),
     "synth_a1_mixed": dict(arrays=[(16, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 1, 2], "ReLU", True),

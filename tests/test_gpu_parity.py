@@ -12,7 +12,7 @@ from signals import stream_bank, two_tone
 
 pytestmark = pytest.mark.gpu
 
-WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet"]
+WAVENETS = ["wavenet", "wavenet_a1_standard", "wavenet_a2_max", "wavenet_condition_dsp", "slimmable_wavenet", "synth_a1_nano"]
 # synthetic A1-family fixtures (tests/golden/make_synthetic_models.py) that reach the MFMA kernel's variants
 SYNTH_A1 = ["synth_a1_13", "synth_a1_c12", "synth_a1_c8", "synth_a1_mixed", "synth_a1_lite", "synth_a1_c14", "synth_a1_feather"]
 # single-array fixtures with per-layer kernel sizes 1..16 and a head rechannel with taps: the K-tap MFMA kernel

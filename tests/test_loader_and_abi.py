@@ -43,7 +43,9 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
 @pytest.mark.parametrize("name,bits", [
     ("wavenet_a1_standard", 15), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
     ("synth_a1_mixed", 7),  # kernel size 3 everywhere, several arrays: the wave-specialised + interleaved MFMA kernels
-    ("synth_a1_lite", 15), ("synth_a1_feather", 15), ("synth_a1_c14", 7),  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
+    ("synth_a1_nano", 17),  # 4 -> 2 channels: VALU kernel, and nam_wn_reg_kernel's plain-layer runs (68 KB of LDS rings)
+    ("synth_a1_lite", 15), ("synth_a1_c14", 7),
+    ("synth_a1_feather", 31),  # (8 -> 4 channels also fit nam_wn_reg_kernel: 129 KB of LDS rings; AUTO keeps the matrix cores)  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
     ("slimmable_wavenet", 17),  # 3 channels: VALU kernel, and (dilations up to 512 in LDS-resident rings) nam_wn_reg_kernel
     # FiLMs / gating / nested condition_dsp / multi-channel: the register-resident kernel (bit 4) where every layer is
     # one of its instantiated shapes, else the op interpreter alone (a post-stack head)

@@ -21,14 +21,19 @@ with tempfile.TemporaryDirectory() as tmp:
         T = block * K
         x = torch.from_numpy(stream_bank(n, T, seed=1)[:, None, :]).to(dev)
         y = torch.zeros_like(x)
-        b = m.batch(n, block)
-        b.Reset(prewarm=True)
-        st = torch.cuda.Stream(dev); sh = st.cuda_stream
-        def run():
-            for s in range(K):
-                b.process_device(x.data_ptr() + s * block * 4, y.data_ptr() + s * block * 4, block, T, sh)
-        run(); torch.cuda.synchronize()
-        t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-        kname = {1: "generic", 2: "a1_valu", 3: "a1_mfma"}[b.get_kernel()]
-        print(f"{name:9s} {c0:2d}->{c1:d}  kernel {kname:8s} {n} streams: {dt*1e6:7.2f} us per 64-frame block = {n*block/48000/dt:9.0f} xRT", flush=True)
-        b.close()
+        for pers in (False, True):
+            b = m.batch(n, block)
+            b.Reset(prewarm=True)
+            if pers and not b.set_persistent(True):
+                b.close()
+                continue
+            st = torch.cuda.Stream(dev); sh = st.cuda_stream
+            def run():
+                for s in range(K):
+                    b.process_device(x.data_ptr() + s * block * 4, y.data_ptr() + s * block * 4, block, T, sh)
+                b.flush(sh)
+            run(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+            print(f"{name:9s} {c0:2d}->{c1:d}  {b.kernel_name():20s} {'persistent block mode' if pers else 'one launch per block '} {n} streams: "
+                  f"{dt*1e6:7.2f} us per 64-frame block = {n*block/48000/dt:9.0f} xRT", flush=True)
+            b.close()
