@@ -181,17 +181,19 @@ NAM_HIP_API int nam_hip_batch_process_device(nam_hip_batch* batch, const float* 
 NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float* const* out,
                                          const int64_t* n_frames);
 
-/* Persistent block mode (opt-in; the official WaveNet topology on nam_a1_p2_kernel, uniform batches): instead of one
- * kernel launch per nam_hip_batch_process_device call, ONE launch stays resident and every call of exactly 64 frames
- * becomes a command — a 64-bit doorbell written by hipStreamWriteValue64 on the call's stream, so it is ordered behind
- * whatever produced the input there — that the resident workgroups consume back to back. What a launch per buffer pays
- * on top of the computation (dispatch, cold prologue, write-through drain: ~4-7 us of a 14-17 us launch at 256 streams)
- * is paid once per session. Consecutive calls must address the same resident window (d_in / d_out of the first call
- * plus a common frame offset, same frame_stride); anything else — another shape, Reset, SetSlimmableSize, set_kernel,
- * destroy — ends the session first (the resident launch writes the streams' state back), transparently.
+/* Persistent block mode (opt-in; nam_a1_p2_kernel, nam_wn_reg_kernel — mixed slimmable widths included — and the small-cell
+ * LSTM kernel): instead of one kernel launch per nam_hip_batch_process_device call, a SESSION launch consumes every call of
+ * exactly 64 frames as a command — a 64-bit word in a device-memory ring, stored by the host itself when the call's stream
+ * is idle, else by hipStreamWriteValue64 on that stream, so it is ordered behind whatever produced the input there — for
+ * as long as the next command is already there when a buffer is finished, and leaves as soon as the ring is empty (a
+ * device-wide synchronize never waits for a session; the next call starts the launch again). What a launch per buffer
+ * pays on top of the computation (dispatch, cold prologue, state in and out: 4-12 us) is paid once per burst.
+ * Consecutive calls must address the same resident window (d_in / d_out of the first call plus a common frame offset,
+ * same frame_stride); anything else — another shape, Reset, SetSlimmableSize, set_kernel, destroy — ends the session
+ * first (the launch writes the streams' state back), transparently.
  * Outputs are NOT ordered on the caller's stream: call nam_hip_batch_flush (or nam_hip_batch_synchronize, or use the
- * blocking *_f32 / *_f64 entry points, which do it) before consuming them. A session that is not fed for ~2 s ends by
- * itself. Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual). */
+ * blocking *_f32 / *_f64 entry points, which do it) before consuming them.
+ * Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual). */
 NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);
 /* Blocks until every buffer submitted so far has been rendered and is visible (hip_stream: the stream the process
  * calls were issued on; NULL = the batch's own). No-op outside persistent mode. */
