@@ -641,6 +641,200 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wide LSTM cells (5 .. 32 hidden units, 1 - 2 layers: the sizes real NAM LSTM captures use), ONE WAVEFRONT PER STREAM,
+// TWO GATE ROWS PER LANE: lane 2u holds rows (i, f) of hidden unit u, lane 2u + 1 rows (g, o) — every weight of the
+// model lives in registers as pairs, so a time step is one v_pk_fma_f32 per input and lane (both rows at once, the input
+// as a scalar operand). A layer's new h is broadcast ONCE per step with v_readlane into scalar registers: it feeds the
+// layer above in this step and the layer's own recurrence in the next. The pair of lanes of a unit swaps its two
+// activations through one quad_perm DPP move each; c and h are kept in both. sigmoid(x) = 0.5 tanh(x / 2) + 0.5 as in the
+// gate-row kernel (the 0.5 folded into the weights: exact). The top layer's h goes to LDS every step and the block's 64
+// outputs are formed afterwards with lane = frame. 1,024 streams = 1,024 wavefronts (the 16-streams-per-wavefront MFMA
+// kernel keeps 64 busy and issues ~3 k cycles of matrix work per step for a 2 x 18 model).
+// Reference: NAM/lstm.cpp:31-68 (cell), :103-168 (process), gate order i, f, g, o; fast forms :48-58. State layout
+// [layer][h | c][H] shared with the other LSTM kernels.
+// ------------------------------------------------------------------------------------------------
+namespace lwide
+{
+using f2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ float pair_swap(float v) // the other lane of the (2u, 2u + 1) pair
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) // lane `src` (compile-time or scalar) -> a scalar register
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+} // namespace lwide
+
+template <int NL, int NI, int NH, bool FAST>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void nam_lstm_wide_kernel(
+  const float* __restrict__ blob, const LSTMArgs a)
+{
+  using lwide::f2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HP = NH + 4; // history row pitch: conflict-free b128 reads with lane = frame
+  const int lane = threadIdx.x;
+  const int u = lane >> 1;
+  const bool odd = (lane & 1) != 0;
+  const int H = a.hidden; // <= NH (NH: the next multiple of 4; padding units have zero rows and stay at h = c = 0)
+  const bool unit = u < H;
+  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  const int out_ch = a.out_ch;
+  float* const hist = lds; // [64 steps][HP]: the top layer's h
+  float* const hw = lds + kBlock * HP; // head weights [out_ch][NH] (zero padded), then the head bias [out_ch]
+
+  // this lane's two gate rows of every layer (row 0: i or g, row 1: f or o), as pairs: input weights, recurrent
+  // weights, bias. Rows that feed a sigmoid carry the 0.5 of sigmoid(x) = 0.5 tanh(x / 2) + 0.5.
+  const int g0 = odd ? 2 : 0, g1 = odd ? 3 : 1;
+  const float s0 = odd ? 1.0f : 0.5f; // row 0: g -> tanh, i -> sigmoid; row 1 (f, o) is always a sigmoid
+  constexpr int NIN = NI > NH ? NI : NH;
+  f2 wi[NL][NIN], wh[NL][NH], wb[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    const int I = l == 0 ? NI : H;
+    const float* __restrict__ W0 = blob + a.layer_w[l] + (size_t)(g0 * H + (unit ? u : 0)) * (I + H);
+    const float* __restrict__ W1 = blob + a.layer_w[l] + (size_t)(g1 * H + (unit ? u : 0)) * (I + H);
+    wb[l] = unit ? f2{s0 * blob[a.layer_b[l] + g0 * H + u], 0.5f * blob[a.layer_b[l] + g1 * H + u]} : f2{0.0f, 0.0f};
+#pragma unroll
+    for (int e = 0; e < NIN; e++)
+      wi[l][e] = (unit && e < I) ? f2{s0 * W0[e], 0.5f * W1[e]} : f2{0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+      wh[l][j] = (unit && j < H) ? f2{s0 * W0[I + j], 0.5f * W1[I + j]} : f2{0.0f, 0.0f};
+  }
+  const float a0 = odd ? 1.0f : 0.5f, b0 = odd ? 0.0f : 0.5f; // row 0's activation = a0 T(z) + b0
+  for (int i = lane; i < out_ch * NH; i += kBlock)
+    hw[i] = (i % NH) < H ? blob[a.head_w + (i / NH) * H + (i % NH)] : 0.0f;
+  if (lane < out_ch)
+    hw[out_ch * NH + lane] = blob[a.head_b + lane];
+
+  // persistent session (persist_wave.h): blocks come from commands, not from a frame count
+  const bool pers = a.ps.ring != nullptr;
+  PersistWave pw;
+  unsigned cmd_off = 0;
+  if (pers && !pw.begin(a.ps, (int)blockIdx.x, cmd_off))
+  {
+    pw.leave(a.ps, (int)blockIdx.x); // nothing to do
+    return;
+  }
+
+  float* const st = a.state + (size_t)stream * a.state_stride;
+  float h[NL], c[NL];
+  float hb[NL][NH]; // every unit's h of every layer, wavefront-uniform (scalar registers)
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+  {
+    h[l] = unit ? st[(l * 2 + 0) * H + u] : 0.0f;
+    c[l] = unit ? st[(l * 2 + 1) * H + u] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+      hb[l][j] = lwide::lane_bcast(h[l], 2 * j);
+  }
+  const float* const in = a.in ? a.in + (size_t)stream * a.in_ch * a.io_stride : nullptr;
+  float* const out = a.out ? a.out + (size_t)stream * out_ch * a.io_stride : nullptr;
+
+  for (int f0 = pers ? (int)cmd_off : 0;;)
+  {
+    const int nvalid = pers ? kBlock : min(kBlock, a.n_frames - f0);
+    if (pers)
+      pw.look_ahead(a.ps);
+    float xv[NI]; // lane = frame
+#pragma unroll
+    for (int e = 0; e < NI; e++)
+    {
+      xv[e] = 0.0f;
+      if (in && lane < nvalid)
+        xv[e] = pers ? persist_in(in + (size_t)e * a.io_stride + f0 + lane) : in[(size_t)e * a.io_stride + f0 + lane];
+    }
+#pragma unroll 1 // (64 unrolled steps of ~200 instructions would not fit the instruction cache)
+    for (int t = 0; t < nvalid; t++)
+    {
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+      {
+        // both rows' pre-activations (times their 1 or 0.5): W_in . in + W_h . h(t - 1) + b, in the reference's order
+        f2 z = f2{0.0f, 0.0f};
+        if (l == 0)
+        {
+#pragma unroll
+          for (int e = 0; e < NI; e++)
+          {
+            const float x = lwide::lane_bcast(xv[e], t);
+            z = __builtin_elementwise_fma(wi[0][e], f2{x, x}, z);
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < NH; j++)
+            z = __builtin_elementwise_fma(wi[l][j], f2{hb[l - 1][j], hb[l - 1][j]}, z);
+        }
+#pragma unroll
+        for (int j = 0; j < NH; j++)
+          z = __builtin_elementwise_fma(wh[l][j], f2{hb[l][j], hb[l][j]}, z);
+        z += wb[l];
+        const float r0 = fmaf(a0, lrow::tanh_like<FAST>(z[0]), b0), r1 = fmaf(0.5f, lrow::tanh_like<FAST>(z[1]), 0.5f);
+        const float p0 = lwide::pair_swap(r0), p1 = lwide::pair_swap(r1);
+        // even lane: (i, f) own, (g, o) from the partner; odd lane the other way round
+        const float gi = odd ? p0 : r0, gf = odd ? p1 : r1, gg = odd ? r0 : p0, go = odd ? r1 : p1;
+        const float cn = fmaf(gf, c[l], gi * gg);
+        const float hn = go * lrow::tanh_like<FAST>(cn);
+        c[l] = cn;
+        h[l] = hn;
+#pragma unroll
+        for (int j = 0; j < NH; j++)
+          hb[l][j] = lwide::lane_bcast(hn, 2 * j);
+      }
+      if (!odd && u < NH)
+        hist[t * HP + u] = h[NL - 1];
+    }
+    // head: y[ch][t] = Wh . h_top(t) + bh, lane = frame (coalesced stores)
+    if (out)
+    {
+      float hv[NH];
+#pragma unroll
+      for (int q = 0; q < NH / 4; q++)
+      {
+        const mf::f4 v = *reinterpret_cast<const mf::f4*>(hist + lane * HP + 4 * q);
+        hv[4 * q] = v[0], hv[4 * q + 1] = v[1], hv[4 * q + 2] = v[2], hv[4 * q + 3] = v[3];
+      }
+      for (int ch = 0; ch < out_ch; ch++)
+      {
+        float y = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NH; j++)
+          y = fmaf(hw[ch * NH + j], hv[j], y);
+        y += hw[out_ch * NH + ch];
+        if (lane < nvalid)
+          out[(size_t)ch * a.io_stride + f0 + lane] = y;
+      }
+    }
+    if (pers)
+    {
+      if (!pw.next(a.ps, (int)blockIdx.x, cmd_off))
+        break; // ring empty: leave
+      f0 = (int)cmd_off;
+    }
+    else
+    {
+      f0 += kBlock;
+      if (f0 >= a.n_frames)
+        break;
+    }
+  }
+  if (unit && !odd)
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      st[(l * 2 + 0) * H + u] = h[l];
+      st[(l * 2 + 1) * H + u] = c[l];
+    }
+  if (pers)
+    pw.leave(a.ps, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // State initialisation
 // ------------------------------------------------------------------------------------------------
 __global__ void nam_fill_state_kernel(float* state, long state_stride, const int* stream_map, int n_streams,
@@ -753,6 +947,46 @@ hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream)
   }
 #undef NAM_LSTM_ROW
 #undef NAM_LSTM_ROW_H
+  return hipGetLastError();
+}
+
+bool lstm_wide_eligible(const LSTMArgs& a)
+{
+  return a.hidden >= 5 && a.hidden <= 32 && a.n_layers >= 1 && a.n_layers <= 2 && a.input_size >= 1 && a.input_size <= 2
+         && a.in_ch == a.input_size && a.out_ch >= 1 && a.out_ch <= 16;
+}
+
+hipError_t launch_lstm_wide(const LSTMArgs& a, hipStream_t stream)
+{
+  if (!lstm_wide_eligible(a))
+    return hipErrorInvalidValue;
+  const int nh = (a.hidden + 3) & ~3;
+  const int lds_bytes = (kBlock * (nh + 4) + a.out_ch * nh + a.out_ch) * (int)sizeof(float);
+#define NAM_LSTM_WIDE_H(NL, NI, NH) \
+  if (a.fast) \
+    hipLaunchKernelGGL((nam_lstm_wide_kernel<NL, NI, NH, true>), dim3(a.n_streams), dim3(64), lds_bytes, stream, a.blob, a); \
+  else \
+    hipLaunchKernelGGL((nam_lstm_wide_kernel<NL, NI, NH, false>), dim3(a.n_streams), dim3(64), lds_bytes, stream, a.blob, a)
+#define NAM_LSTM_WIDE(NL, NI) \
+  switch (nh) \
+  { \
+    case 8: NAM_LSTM_WIDE_H(NL, NI, 8); break; \
+    case 12: NAM_LSTM_WIDE_H(NL, NI, 12); break; \
+    case 16: NAM_LSTM_WIDE_H(NL, NI, 16); break; \
+    case 20: NAM_LSTM_WIDE_H(NL, NI, 20); break; \
+    case 24: NAM_LSTM_WIDE_H(NL, NI, 24); break; \
+    case 28: NAM_LSTM_WIDE_H(NL, NI, 28); break; \
+    default: NAM_LSTM_WIDE_H(NL, NI, 32); break; \
+  }
+  switch (a.n_layers * 10 + a.input_size)
+  {
+    case 11: NAM_LSTM_WIDE(1, 1); break;
+    case 12: NAM_LSTM_WIDE(1, 2); break;
+    case 21: NAM_LSTM_WIDE(2, 1); break;
+    default: NAM_LSTM_WIDE(2, 2); break;
+  }
+#undef NAM_LSTM_WIDE
+#undef NAM_LSTM_WIDE_H
   return hipGetLastError();
 }
 

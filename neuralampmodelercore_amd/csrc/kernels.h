@@ -101,7 +101,7 @@ struct LSTMArgs
   int mf_off, mf_floats, mf_nt, mf_head_tiles, mf_head_bias, mf_lds_bytes;
   int mf_layer_tiles[16];
   int mf_layer_bias[16];
-  PersistArgs ps; // nam_lstm_row_kernel only
+  PersistArgs ps; // nam_lstm_row_kernel / nam_lstm_wide_kernel
 };
 
 // nam_wn_reg_kernel (plan.h: WrPlan). One launch serves up to kWrMaxGroups WIDTH GROUPS — streams of a slimmable model
@@ -144,6 +144,8 @@ hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);
 hipError_t launch_lstm_mfma(const LSTMArgs& a, hipStream_t stream);
 hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream); // hidden <= 4: one gate row per lane
 bool lstm_row_eligible(const LSTMArgs& a);
+hipError_t launch_lstm_wide(const LSTMArgs& a, hipStream_t stream); // 5 .. 32 hidden units: two gate rows per lane
+bool lstm_wide_eligible(const LSTMArgs& a);
 int lstm_lds_bytes(const LSTMArgs& a);
 hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,
                              int n_init, int state_floats, hipStream_t stream);

@@ -299,7 +299,8 @@ enum PersistKind : int
   PERSIST_NONE = -1,
   PERSIST_A1_P2 = 0, // nam_a1_p2_kernel: one workgroup (4 wavefronts, most of a CU's LDS) per stream
   PERSIST_WN_REG = 1, // nam_wn_reg_kernel: one wavefront per stream
-  PERSIST_LSTM_ROW = 2 // nam_lstm_row_kernel: one wavefront per four streams
+  PERSIST_LSTM_ROW = 2, // nam_lstm_row_kernel: one wavefront per four streams
+  PERSIST_LSTM_WIDE = 3 // nam_lstm_wide_kernel: one wavefront per stream
 };
 int persist_kind(const nam_hip_batch* b);
 int persist_family(const nam_hip_batch* b, const WidthGroup& g);
@@ -317,6 +318,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
       case PERSIST_A1_P2: return "nam_a1_p2_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
+      case PERSIST_LSTM_WIDE: return "nam_lstm_wide_kernel";
       default: break;
     }
   if (p.arch == ARCH_WAVENET)
@@ -334,6 +336,9 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
   if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && L.hidden >= 1 && L.hidden <= 4
       && L.n_layers <= 2 && L.input_size >= 1 && L.input_size <= 2 && L.in_ch == L.input_size && L.out_ch <= 16)
     return "nam_lstm_row_kernel";
+  if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && L.hidden >= 5 && L.hidden <= 32
+      && L.n_layers <= 2 && L.input_size >= 1 && L.input_size <= 2 && L.in_ch == L.input_size && L.out_ch <= 16)
+    return "nam_lstm_wide_kernel";
   if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
     return (L.input_size <= 4 && L.n_layers <= 2 && L.mf_nt <= 6) ? "nam_lstm_mfma_reg_kernel" : "nam_lstm_mfma_kernel";
   return "nam_lstm_kernel";
@@ -626,12 +631,18 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.mf_layer_tiles[i] = L.mf_layer_tiles[i];
       a.mf_layer_bias[i] = L.mf_layer_bias[i];
     }
-    // AUTO: small cells (hidden <= 4) one gate row per lane, else the matrix-core kernel (16 streams per wavefront);
+    // AUTO: small cells (hidden <= 4) one gate row per lane and four streams per wavefront, cells of 5 .. 32 units two
+    // gate rows per lane and one stream per wavefront, else the matrix-core kernel (16 streams per wavefront);
     // NAM_HIP_KERNEL_A1_MFMA forces the matrix-core kernel; NAM_HIP_KERNEL_GENERIC: lanes = streams
     if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && lstm_row_eligible(a))
     {
       a.ps = persist_args(b);
       NAM_HIP_CHECK(launch_lstm_row(a, s));
+    }
+    else if (b->kernel != NAM_HIP_KERNEL_GENERIC && b->kernel != NAM_HIP_KERNEL_A1_MFMA && lstm_wide_eligible(a))
+    {
+      a.ps = persist_args(b);
+      NAM_HIP_CHECK(launch_lstm_wide(a, s));
     }
     else if (L.mf_ok && b->kernel != NAM_HIP_KERNEL_GENERIC)
       NAM_HIP_CHECK(launch_lstm_mfma(a, s));
@@ -720,6 +731,9 @@ int persist_kind(const nam_hip_batch* b)
     if (L.hidden >= 1 && L.hidden <= 4 && L.n_layers >= 1 && L.n_layers <= 2 && L.input_size >= 1 && L.input_size <= 2
         && L.in_ch == L.input_size && L.out_ch >= 1 && L.out_ch <= 16 && (b->n_streams + 3) / 4 <= 8 * cus)
       return PERSIST_LSTM_ROW;
+    if (L.hidden >= 5 && L.hidden <= 32 && L.n_layers >= 1 && L.n_layers <= 2 && L.input_size >= 1 && L.input_size <= 2
+        && L.in_ch == L.input_size && L.out_ch >= 1 && L.out_ch <= 16 && b->n_streams <= 4 * cus) // one wavefront per SIMD
+      return PERSIST_LSTM_WIDE;
   }
   return PERSIST_NONE;
 }

@@ -525,8 +525,9 @@ def test_post_stack_head_and_multichannel_io(nam_lib, oracle, name, in_ch, fast_
                                         ("synth_lstm_h4x2", 1), ("synth_lstm_h2io", 2)])
 @pytest.mark.parametrize("kernel", ["auto", "mfma", "lanes"])
 def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
-    """The LSTM kernels — gate row per lane (hidden <= 4: AUTO for lstm.nam and the two small fixtures), matrix-core
-    (16 streams per wavefront: AUTO otherwise, or forced), lanes-are-streams (GENERIC) — against the oracle: partial
+    """The LSTM kernels — gate row per lane (hidden <= 4: AUTO for lstm.nam and the two small fixtures), two gate rows per
+    lane and one stream per wavefront (5 .. 32 units: AUTO for the 8-, 10- and 18-unit fixtures; 10 and 18 are padded to
+    12 / 20), matrix-core (16 streams per wavefront: forced), lanes-are-streams (GENERIC) — against the oracle: partial
     wavefronts / rows, padding units, several unit tiles with a ragged last one, two layers, 2-in / 3-out."""
     nam = nam_lib
     n_streams, n = 37, 64 * 3 + 11
@@ -540,7 +541,7 @@ def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
         elif kernel == "mfma":
             b.set_kernel(nam.KERNEL_A1_MFMA)
         small = name in ("lstm", "synth_lstm_h4x2", "synth_lstm_h2io")
-        want = {"lanes": "nam_lstm_kernel", "mfma": "nam_lstm_mfma", "auto": "nam_lstm_row_kernel" if small else "nam_lstm_mfma"}[kernel]
+        want = {"lanes": "nam_lstm_kernel", "mfma": "nam_lstm_mfma", "auto": "nam_lstm_row_kernel" if small else "nam_lstm_wide_kernel"}[kernel]
         assert b.kernel_name().startswith(want), (b.kernel_name(), want)
         b.Reset(prewarm=True)
         y = b.process_stream(x, 64)
@@ -874,11 +875,12 @@ def test_persistent_block_mode_matches_oracle(nam_lib, oracle):
     nam = nam_lib
     n_streams, block, nb = 7, 64, 12
     x = stream_bank(n_streams, block * nb + 40, seed=321)
-    # the three kernels that speak the session protocol: nam_a1_p2_kernel (a workgroup per stream), nam_wn_reg_kernel (a
-    # wavefront per stream), nam_lstm_row_kernel (a wavefront per four streams: 7 streams = a ragged last workgroup)
+    # the kernels that speak the session protocol: nam_a1_p2_kernel (a workgroup per stream), nam_wn_reg_kernel (a
+    # wavefront per stream), nam_lstm_row_kernel (a wavefront per four streams: 7 streams = a ragged last workgroup),
+    # nam_lstm_wide_kernel (a wavefront per stream)
     for name, kname in (("wavenet_a1_standard", "nam_a1_p2_kernel"), ("synth_a1_feather", "nam_a1_p2_kernel"),
                         ("wavenet_a2_max", "nam_wn_reg_kernel"), ("lstm", "nam_lstm_row_kernel"),
-                        ("synth_lstm_h4x2", "nam_lstm_row_kernel")):
+                        ("synth_lstm_h4x2", "nam_lstm_row_kernel"), ("synth_lstm_h18x2", "nam_lstm_wide_kernel")):
         model = nam.get_dsp(model_path(name), fast_tanh=True)
         refs = [_oracle_run(oracle, name, x[s], block, True) for s in range(n_streams)]
         b = model.batch(n_streams, block)
