@@ -664,6 +664,28 @@ __device__ __forceinline__ float lane_bcast(float v, int src) // lane `src` (com
 {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
+// tanh (or the reference's fast_tanh rational, activations.h:29-41) of both rows at once: packed arithmetic, two rcp
+template <bool FAST>
+__device__ __forceinline__ f2 tanh2(const f2 x)
+{
+  if constexpr (FAST)
+  {
+    const f2 ax = __builtin_elementwise_abs(x);
+    const f2 x2 = x * x;
+    const f2 k0 = f2{2.45550750702956f, 2.45550750702956f}, k1 = f2{0.893229853513558f, 0.893229853513558f},
+             k2 = f2{0.821226666969744f, 0.821226666969744f}, k3 = f2{2.44506634652299f, 2.44506634652299f},
+             k4 = f2{0.814642734961073f, 0.814642734961073f};
+    const f2 num = x * (__builtin_elementwise_fma(k0, ax, k0) + __builtin_elementwise_fma(k2, ax, k1) * x2);
+    const f2 den = __builtin_elementwise_fma(k3 + x2, __builtin_elementwise_abs(__builtin_elementwise_fma(k4 * x, ax, x)), k3);
+    return f2{num[0] * mf::rcp(den[0]), num[1] * mf::rcp(den[1])};
+  }
+  else
+  {
+    const f2 y = x * f2{2.885390081777927f, 2.885390081777927f}; // exp(2x) = 2^(2x log2 e)
+    const f2 e = f2{__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])} + f2{1.0f, 1.0f};
+    return __builtin_elementwise_fma(f2{-2.0f, -2.0f}, f2{mf::rcp(e[0]), mf::rcp(e[1])}, f2{1.0f, 1.0f});
+  }
+}
 } // namespace lwide
 
 template <int NL, int NI, int NH, bool FAST>
@@ -753,8 +775,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
       for (int l = 0; l < NL; l++)
       {
-        // both rows' pre-activations (times their 1 or 0.5): W_in . in + W_h . h(t - 1) + b, in the reference's order
-        f2 z = f2{0.0f, 0.0f};
+        // both rows' pre-activations (times their 1 or 0.5): W_in . in + W_h . h(t - 1) + b. Two partial sums: a
+        // v_pk_fma_f32 that depends on the one right before it costs a wait state (and an s_nop) each time
+        f2 z = f2{0.0f, 0.0f}, zb = f2{0.0f, 0.0f};
         if (l == 0)
         {
 #pragma unroll
@@ -767,14 +790,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         else
         {
 #pragma unroll
-          for (int j = 0; j < NH; j++)
+          for (int j = 0; j < NH; j += 2)
+          {
             z = __builtin_elementwise_fma(wi[l][j], f2{hb[l - 1][j], hb[l - 1][j]}, z);
+            zb = __builtin_elementwise_fma(wi[l][j + 1], f2{hb[l - 1][j + 1], hb[l - 1][j + 1]}, zb);
+          }
         }
 #pragma unroll
-        for (int j = 0; j < NH; j++)
-          z = __builtin_elementwise_fma(wh[l][j], f2{hb[l][j], hb[l][j]}, z);
+        for (int j = 0; j < NH; j += 2)
+        {
+          zb = __builtin_elementwise_fma(wh[l][j], f2{hb[l][j], hb[l][j]}, zb);
+          z = __builtin_elementwise_fma(wh[l][j + 1], f2{hb[l][j + 1], hb[l][j + 1]}, z);
+        }
+        z += zb;
         z += wb[l];
-        const float r0 = fmaf(a0, lrow::tanh_like<FAST>(z[0]), b0), r1 = fmaf(0.5f, lrow::tanh_like<FAST>(z[1]), 0.5f);
+        const f2 r = __builtin_elementwise_fma(f2{a0, 0.5f}, lwide::tanh2<FAST>(z), f2{b0, 0.5f});
+        const float r0 = r[0], r1 = r[1];
         const float p0 = lwide::pair_swap(r0), p1 = lwide::pair_swap(r1);
         // even lane: (i, f) own, (g, o) from the partner; odd lane the other way round
         const float gi = odd ? p0 : r0, gf = odd ? p1 : r1, gg = odd ? r0 : p0, go = odd ? r1 : p1;
