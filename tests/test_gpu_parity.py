@@ -128,13 +128,13 @@ def test_ktap_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh):
 
 
 def test_fuzzed_models_all_kernels(nam_lib, oracle):
-    """tools/fuzz_models.py: 18 seeded random A1-family models (random kernel sizes 1..16, dilations up to 512, head
-    taps, channel counts, activations, array counts) through every kernel that accepts them, block launches and one
-    multi-block launch, against the oracle."""
+    """tools/fuzz_models.py: 24 seeded random A1-family models (random kernel sizes 1..16, dilations up to 700, head
+    taps, channel counts 1 .. 16, activations, array counts) through every kernel that accepts them — the register-resident
+    kernel's LDS rings included —, block launches and one multi-block launch, against the oracle."""
     import subprocess
     import sys
     from conftest import ROOT
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "18", "23"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "24", "23"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "FUZZ OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 

@@ -1,6 +1,7 @@
 """Developer tool: random A1-family models (seeded) through every kernel that can run them, against the oracle.
 Single-array models with random per-layer kernel sizes / dilations / head taps reach the K-tap MFMA kernel;
-multi-array kernel-size-3 models reach the wave-specialised one. Usage: python tools/fuzz_models.py [n] [seed]"""
+multi-array kernel-size-3 models reach the wave-specialised one; narrow ones (1 .. 4 channels, odd dilations up to 700)
+the register-resident kernel's LDS rings, plain-layer runs and run-time-flag layers. Usage: python tools/fuzz_models.py [n] [seed]"""
 import json, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,13 +49,31 @@ def random_multi(rng, tmp, idx):
     return os.path.join(tmp, "models", name + ".nam"), dict(arrays=arrays)
 
 
+def random_narrow(rng, tmp, idx):
+    """1 .. 4 channels per array: nam_wn_reg_kernel (Tanh / ReLU layers fuse into runs, Sigmoid ones stay single layers)."""
+    n_arr = int(rng.integers(1, 4))
+    arrays = []
+    for a in range(n_arr):
+        C = int(rng.choice([1, 2, 3, 4]))
+        n_layers = int(rng.integers(1, 7))
+        dl = [int(rng.choice([1, 2, 3, 5, 7, 16, 31, 32, 33, 63, 64, 65, 100, 127, 128, 300, 512, 700])) for _ in range(n_layers)]
+        arrays.append((C, dl, ["Tanh", "ReLU", "Sigmoid"][int(rng.integers(3))], bool(rng.integers(2))))
+    name = f"fuzz_nw_{idx}"
+    old = msm.HERE
+    msm.HERE = tmp
+    os.makedirs(os.path.join(tmp, "models"), exist_ok=True)
+    msm.build(name, arrays, int(rng.integers(1 << 30)))
+    msm.HERE = old
+    return os.path.join(tmp, "models", name + ".nam"), dict(arrays=arrays)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(n):
-            path, spec = (random_ktap if i % 3 else random_multi)(rng, tmp, i)
+            path, spec = (random_multi, random_ktap, random_narrow)[i % 3](rng, tmp, i)
             ft = bool(rng.integers(2))
             model = nam.get_dsp(path, fast_tanh=ft)
             bits = model.info.has_a1_kernel
@@ -65,7 +84,7 @@ def main():
             ref.Reset(48000.0, block)
             r = ref.process_stream(x[1], block)
             errs = {}
-            kernels = [("generic", nam.KERNEL_GENERIC)] + ([("valu", nam.KERNEL_A1)] if bits & 1 else []) + ([("mfma", nam.KERNEL_A1_MFMA)] if bits & 2 else [])
+            kernels = [("generic", nam.KERNEL_GENERIC)] + ([("valu", nam.KERNEL_A1)] if bits & 1 else []) + ([("mfma", nam.KERNEL_A1_MFMA)] if bits & 2 else []) + ([("wn_reg", nam.KERNEL_WN_REG)] if bits & 16 else [])
             for kname, k in kernels:
                 for mode, mf in (("blocks", block), ("one", 512)):
                     b = model.batch(n_streams, mf)
