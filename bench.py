@@ -566,7 +566,8 @@ def main():
         if slim_mix:
             ref.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[0]]])
         ref.Reset(SR, block)
-        r = ref.process_stream(bank[mine[0], :n_chk], block)[0]
+        sig = bank[mine[0], :n_chk]
+        r = ref.process_stream(np.repeat(sig[None, :], ic, axis=0) if ic > 1 else sig, block)[0]  # (every input channel carries the signal)
         parity = float(np.max(np.abs(r - got_dev.cpu().numpy())))
     elif rank == 0 and args.dry_run:
         parity = float(torch.max(torch.abs(got_dev - 0.5 * x[0, 0, :n_chk])))

@@ -177,6 +177,10 @@ LSTMS = {
     # and one layer of 2 with 2 inputs / 3 outputs (padding units, one output channel per lane)
     "synth_lstm_h4x2": dict(num_layers=2, input_size=1, hidden=4, out_channels=1, seed=34),
     "synth_lstm_h2io": dict(num_layers=1, input_size=2, hidden=2, out_channels=3, seed=35),
+    # the two-rows-per-lane kernel at its limits: 32 units (every lane holds rows, 64 broadcasts per step) and two
+    # layers of 24 with 2 inputs / 2 outputs
+    "synth_lstm_h32": dict(num_layers=1, input_size=1, hidden=32, out_channels=1, seed=36),
+    "synth_lstm_h24x2io": dict(num_layers=2, input_size=2, hidden=24, out_channels=2, seed=37),
 }
 
 

@@ -522,7 +522,8 @@ def test_post_stack_head_and_multichannel_io(nam_lib, oracle, name, in_ch, fast_
 
 
 @pytest.mark.parametrize("name,in_ch", [("lstm", 1), ("synth_lstm_h18x2", 1), ("synth_lstm_io", 2), ("synth_lstm_h10x2", 1),
-                                        ("synth_lstm_h4x2", 1), ("synth_lstm_h2io", 2)])
+                                        ("synth_lstm_h4x2", 1), ("synth_lstm_h2io", 2), ("synth_lstm_h32", 1),
+                                        ("synth_lstm_h24x2io", 2)])
 @pytest.mark.parametrize("kernel", ["auto", "mfma", "lanes"])
 def test_lstm_kernels_match_oracle(nam_lib, oracle, name, in_ch, kernel):
     """The LSTM kernels — gate row per lane (hidden <= 4: AUTO for lstm.nam and the two small fixtures), two gate rows per
