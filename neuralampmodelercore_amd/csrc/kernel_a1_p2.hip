@@ -210,11 +210,15 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     lds_st4(lds, (unsigned)p2::kXtB + (unsigned)tid * 16u, x0v);
   lds_barrier();
 
+  // History jobs (dilation >= 64: both shifted taps are pure history, requested a block ago) get their two tap products
+  // from the job BEFORE them: those eight MFMAs run in the matrix pipe while that job's activation occupies the vector
+  // pipe, and the history job's own critical path shrinks to the current-frame chain (plan.h: p2::kind).
+  auto early = [](int ji) { return ji > 0 && ji < NJ && p2::kind(ji) == IL_HIST; };
   auto load_ops = [&](Ops& o, auto j_tag) {
     constexpr int JN = decltype(j_tag)::value; // the job whose operands are read
     constexpr unsigned consts_b = p2::kConstsB + JN * 256, tiles_b = p2::kTilesB + JN * 4096;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = (early(JN) ? 2 : 0); q < 4; q++) // (a history job's tap tiles were read by its predecessor)
       o.t[q] = lds_ld4(lds, v_lane16 + tiles_b + 1024u * q);
     o.bv = lds_ld4(lds, v_g16 + consts_b);
     o.mv = lds_ld4(lds, v_g16 + consts_b + 64u);
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
   // behind its ring append, its requests and its tap shuffles.
   Ops O;
 
+  f4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f}; // the next history job's tap products (see `early`)
   unsigned long long spec_cmd = 0; // persistent: this wave's early look at the next command
   bool spec_ok = false;
   unsigned spec_off = 0;
@@ -253,11 +258,21 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     unsigned gl16 = v_g16;
     asm volatile("" : "+v"(tl), "+v"(gl16));
     load_ops(O, j_tag);
+    constexpr bool kNextEarly = early(JI + 1), kThisEarly = early(JI);
+    f4 nt0 = {0.f, 0.f, 0.f, 0.f}, nt1 = {0.f, 0.f, 0.f, 0.f}; // tap tiles of the history job behind this one
+    if constexpr (kNextEarly)
+    {
+      constexpr unsigned ntiles_b = p2::kTilesB + (JI + 1) * 4096;
+      nt0 = lds_ld4(lds, v_lane16 + ntiles_b);
+      nt1 = lds_ld4(lds, v_lane16 + ntiles_b + 1024u);
+    }
     f4 xt = {0.f, 0.f, 0.f, 0.f}, ev = {0.f, 0.f, 0.f, 0.f};
     if constexpr ((flags & (CD_X0 | CD_PRE_HEAD | CD_POST_RECH | CD_POST_OUT)) != 0)
       load_extra(xt, ev, j_tag);
     const f4 Sa = sa[JI], Sb = sb[JI];
-    if constexpr (J.kind == IL_EXCH)
+    if constexpr (kThisEarly)
+      ; // (consumed by the previous job)
+    else if constexpr (J.kind == IL_EXCH)
       asm volatile("" ::"v"(Sa));
     else
       asm volatile("" ::"v"(Sa), "v"(Sb)); // one wait for the whole slot (the oldest requests in flight)
@@ -346,11 +361,36 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
 #pragma unroll
     for (int s = 0; s < NK; s++)
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[2][s], x[s], acc2, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < NK; s++)
+    if constexpr (kThisEarly)
     {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
+      acc0 += e0; // computed by the previous job
+      acc1 = e1;
+    }
+    else
+    {
+#pragma unroll
+      for (int s = 0; s < NK; s++)
+      {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[0][s], bt0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(O.t[1][s], bt1[s], acc1, 0, 0, 0);
+      }
+    }
+    if constexpr (kNextEarly)
+    {
+      // the history job behind this one: its two shifted taps (slot JI + 1, requested a block ago) times its tap tiles
+      constexpr int NKN = (p2::desc(C0, C1, 0, JI + 1 < NJ ? JI + 1 : JI).flags & CD_HALF) ? 2 : 4;
+      const f4 Na = sa[JI + 1 < NJ ? JI + 1 : JI], Nb = sb[JI + 1 < NJ ? JI + 1 : JI];
+      asm volatile("" ::"v"(Na), "v"(Nb));
+      auto nslice = [&](const f4& r) { return NKN == 4 ? r : (hi_pair ? f4{r[2], r[3], 0.f, 0.f} : f4{r[0], r[1], 0.f, 0.f}); };
+      const f4 n0 = nslice(Na), n1 = nslice(Nb);
+      e0 = f4{0.f, 0.f, 0.f, 0.f};
+      e1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKN; s++)
+      {
+        e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(nt0[s], n0[s], e0, 0, 0, 0);
+        e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(nt1[s], n1[s], e1, 0, 0, 0);
+      }
     }
     const f4 pre = (acc0 + acc1) + acc2;
     const f4 z = act4<ACT_T>(act, NK == 2 ? f4{pre[0], pre[1], pre[0], pre[1]} : pre, act_p0);
