@@ -330,17 +330,25 @@ __global__ __launch_bounds__(256) void nam_a1_p2_kernel(const float* __restrict_
     }
     else
     {
-      // exchange: jobs 0, 1, 10, 11 -> windows 0, 1, 0, 1 of every block
+      // exchange: jobs 0, 1, 10, 11 -> windows 0, 1, 0, 1 of every block.
+      // Window rows are NOT in frame order: frame F (0 .. 63 previous block, 64 .. 127 this block) sits in row
+      // (F & 64) + 16 (F & 3) + ((F & 63) >> 2), rows of 80 bytes. A wavefront's lanes hold frames 4 apart, so in frame
+      // order (and any 16-byte-aligned pitch) the sixteen lanes of a b128 phase fell into two bank groups — 8-way
+      // conflicts, 2.5 k LDS cycles per block and CU (SQ_LDS_BANK_CONFLICT), all of it in front of a barrier or of the
+      // first MFMA. This way they sit in consecutive rows, and 5 sixteen-byte slots per row walk all 16 bank groups.
+      constexpr unsigned kRowB = 80u;
+      static_assert(2 * kBlock * kRowB <= (unsigned)kIlWinB, "p2 exchange window");
+      auto win_off = [&](unsigned F) { return ((F & 64u) + ((F & 3u) << 4) + ((F & 63u) >> 2)) * kRowB; };
       constexpr unsigned wb = (unsigned)(JI & 1) * (unsigned)kIlWinB;
       if (gl16 <= g16max)
       {
-        lds_st4(lds, wb + (unsigned)(kBlock + tl) * kIlWinRowB + gl16, x);
-        lds_st4(lds, wb + (unsigned)tl * kIlWinRowB + gl16, Sa);
+        lds_st4(lds, wb + win_off((unsigned)(kBlock + tl)) + gl16, x);
+        lds_st4(lds, wb + win_off((unsigned)tl) + gl16, Sa);
       }
       lds_barrier();
       const unsigned chan = NK == 4 ? min(gl16, g16max) : v_gh8;
-      const unsigned r1 = wb + (unsigned)(kBlock + tl - J.dil) * kIlWinRowB + chan;
-      const unsigned r0 = wb + (unsigned)(kBlock + tl - 2 * J.dil) * kIlWinRowB + chan;
+      const unsigned r1 = wb + win_off((unsigned)(kBlock + tl - J.dil)) + chan;
+      const unsigned r0 = wb + win_off((unsigned)(kBlock + tl - 2 * J.dil)) + chan;
       if constexpr (NK == 4)
       {
         bt1 = lds_ld4(lds, r1);
