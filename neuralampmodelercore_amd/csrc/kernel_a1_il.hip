@@ -274,17 +274,22 @@ __global__ __launch_bounds__(320) void nam_a1_il_kernel(const A1Plan* __restrict
           {
             // IL_EXCH: every wave publishes its frames (and the same frames of the previous block) to the window,
             // one workgroup barrier, then each lane reads the two shifted rows
+            // (rows in (frame & 3, frame >> 2) order, 80 bytes each: the wavefront's lanes hold frames 4 apart, and in
+            // frame order the sixteen lanes of a b128 phase shared two bank groups — see kernel_a1_p2.hip)
+            constexpr unsigned kRowB = 80u;
+            static_assert(2 * kBlock * kRowB <= (unsigned)kIlWinB, "exchange window");
+            auto win_off = [](unsigned F) { return ((F & 64u) + ((F & 3u) << 4) + ((F & 63u) >> 2)) * kRowB; };
             const unsigned wb = win_par * (unsigned)kIlWinB;
             win_par ^= 1u;
             if (v_g16 <= g16max)
             {
-              lds_st4(lds, wb + (unsigned)(kBlock + t) * kIlWinRowB + v_g16, x);
-              lds_st4(lds, wb + (unsigned)t * kIlWinRowB + v_g16, S.a);
+              lds_st4(lds, wb + win_off((unsigned)(kBlock + t)) + v_g16, x);
+              lds_st4(lds, wb + win_off((unsigned)t) + v_g16, S.a);
             }
             lds_barrier();
             const unsigned chan = NK == 4 ? min(v_g16, g16max) : v_gh8;
-            const unsigned r1 = wb + (unsigned)(kBlock + t - J.dil) * kIlWinRowB + chan;
-            const unsigned r0 = wb + (unsigned)(kBlock + t - (J.tap0_lds ? 2 * J.dil : 0)) * kIlWinRowB + chan;
+            const unsigned r1 = wb + win_off((unsigned)(kBlock + t - J.dil)) + chan;
+            const unsigned r0 = wb + win_off((unsigned)(kBlock + t - (J.tap0_lds ? 2 * J.dil : 0))) + chan;
             if constexpr (NK == 4)
             {
               bt1 = lds_ld4(lds, r1);
