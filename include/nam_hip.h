@@ -175,8 +175,10 @@ NAM_HIP_API int nam_hip_batch_process_device(nam_hip_batch* batch, const float* 
 /* Offline render ("re-amp") of whole signals: stream s reads n_frames[s] frames from the planar host buffer
  * in[s] ([in_channels][n_frames[s]]) and writes out[s] ([out_channels][n_frames[s]]). Signals may have different
  * lengths (shorter ones are zero-padded on the device; their tails are discarded). Equivalent to feeding every
- * stream through process() in 64-frame buffers the way tools/render.cpp:129-191 does — results do not depend on
- * the buffer partition — but runs as one resident launch over device-resident audio. Blocking.
+ * stream through process() in 64-frame buffers the way tools/render.cpp:129-191 does — for a given kernel the results do
+ * not depend on the buffer partition (under NAM_HIP_KERNEL_AUTO a launch of four or more blocks may run another kernel of
+ * the same family than a one-block launch: same state, sums associated differently, ~1e-7) — but runs as one resident
+ * launch over device-resident audio. Blocking.
  * Replaces the block loop of the reference's render tool (tools/render.cpp:163-197). */
 NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float* const* out,
                                          const int64_t* n_frames);

@@ -460,7 +460,13 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
   const Plan& p = *g.plan;
   if (p.arch == ARCH_WAVENET)
   {
-    const int kernel = pick_kernel(b, g);
+    int kernel = pick_kernel(b, g);
+    // AUTO, a launch that walks several blocks (offline render, prewarm): the interleaved-frame kernel is the faster one
+    // inside a launch (9.3 vs 11.2 us per block at 256 streams; its longer prologue only hurts one-block launches).
+    // Same rings, same write positions: the two alternate freely.
+    if (b->kernel == NAM_HIP_KERNEL_AUTO && kernel == NAM_HIP_KERNEL_A1_MFMA && p.a1.ws_ok && p.a1.il_ok
+        && n_frames >= 4 * kBlock)
+      kernel = NAM_HIP_KERNEL_A1_IL;
     // the op program and the A1 kernels of a channel-padded model keep different ring layouts: a change of kernel
     // family is only legal on freshly reset state
     const int fam = state_family_of(p, kernel);
