@@ -104,6 +104,12 @@ struct WidthGroup
   // kernels unless they run on zero-padded channels: plan.h, Plan::a1_padded_layout), 1 = the padded A1 rings,
   // 2 = nam_wn_reg_kernel's 64-frame conv-input histories
   int state_family = -1;
+  // Prewarm cache (the reference caches what prewarm leaves in every conv, conv1d.cpp:151-161 / model.cpp:737-775, and
+  // later Resets refill from it): one stream's state right after zero + prewarm — every stream's is the same — keyed by
+  // the kernel that produced it and the frames it ran. A later Reset / SetSlimmableSize copies it instead of running
+  // the silence again.
+  float* d_prewarm = nullptr;
+  int prewarm_kernel = -1, prewarm_len = 0;
 };
 } // namespace
 
@@ -451,6 +457,19 @@ int launch_wr_all(nam_hip_batch* b, const WrGroupList& gs, const float* d_in, fl
   return launch_wr(b, gs.g, maps, counts, gs.n, d_in, d_out, n_frames, io_stride, s);
 }
 
+// The WaveNet kernel a launch of n_frames runs: pick_kernel, except that under AUTO a launch that walks several blocks
+// (offline render, prewarm) takes the interleaved-frame kernel — the faster one inside a launch (9.3 vs 11.2 us per
+// block at 256 streams; its longer prologue only hurts one-block launches). Same rings, same write positions: the two
+// alternate freely.
+int kernel_for_launch(const nam_hip_batch* b, const WidthGroup& g, int n_frames)
+{
+  const int kernel = pick_kernel(b, g);
+  if (b->kernel == NAM_HIP_KERNEL_AUTO && kernel == NAM_HIP_KERNEL_A1_MFMA && g.plan->a1.ws_ok && g.plan->a1.il_ok
+      && n_frames >= 4 * kBlock)
+    return NAM_HIP_KERNEL_A1_IL;
+  return kernel;
+}
+
 // Launch one group's kernel over `n` streams given by `d_map` (nullptr = streams 0..n-1).
 int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const float* d_in, float* d_out,
                  int n_frames, long io_stride, hipStream_t s)
@@ -460,13 +479,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
   const Plan& p = *g.plan;
   if (p.arch == ARCH_WAVENET)
   {
-    int kernel = pick_kernel(b, g);
-    // AUTO, a launch that walks several blocks (offline render, prewarm): the interleaved-frame kernel is the faster one
-    // inside a launch (9.3 vs 11.2 us per block at 256 streams; its longer prologue only hurts one-block launches).
-    // Same rings, same write positions: the two alternate freely.
-    if (b->kernel == NAM_HIP_KERNEL_AUTO && kernel == NAM_HIP_KERNEL_A1_MFMA && p.a1.ws_ok && p.a1.il_ok
-        && n_frames >= 4 * kBlock)
-      kernel = NAM_HIP_KERNEL_A1_IL;
+    const int kernel = kernel_for_launch(b, g, n_frames);
     // the op program and the A1 kernels of a channel-padded model keep different ring layouts: a change of kernel
     // family is only legal on freshly reset state
     const int fam = state_family_of(p, kernel);
@@ -672,22 +685,46 @@ int prewarm_frames(const nam_hip_batch* b, const Plan& p)
   return (p.prewarm_samples + bs - 1) / bs * bs;
 }
 
-int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool prewarm)
+// `first_stream`: one of the n streams (its state seeds the prewarm cache).
+int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool prewarm, int first_stream)
 {
   if (n <= 0)
     return NAM_HIP_OK;
   const Plan& p = *g.plan;
+  const int frames = prewarm ? prewarm_frames(b, p) : 0;
+  const bool all = n == (int)g.streams.size();
   if (p.arch == ARCH_WAVENET)
   {
+    if (frames > 0 && g.d_prewarm)
+    {
+      // a state cached by the same kernel over the same number of frames: copy it (every stream's is identical)
+      const int kernel = kernel_for_launch(b, g, frames);
+      const int fam = state_family_of(p, kernel);
+      if (g.prewarm_kernel == kernel && g.prewarm_len == frames && (all || g.state_family < 0 || g.state_family == fam))
+      {
+        NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, d_map, n, g.d_prewarm, p.state_floats, p.state_floats, b->stream));
+        g.state_family = fam;
+        return NAM_HIP_OK;
+      }
+    }
     NAM_HIP_CHECK(launch_fill_state(g.d_state, g.state_stride, d_map, n, nullptr, 0, p.state_floats, b->stream));
-    if (n == (int)g.streams.size())
+    if (all)
       g.state_family = -1; // every stream of the group is zeroed: either layout may follow
   }
-  if (prewarm)
+  if (frames > 0)
   {
-    const int rc = launch_group(b, g, d_map, n, nullptr, nullptr, prewarm_frames(b, p), 0, b->stream);
+    const int rc = launch_group(b, g, d_map, n, nullptr, nullptr, frames, 0, b->stream);
     if (rc != NAM_HIP_OK)
       return rc;
+    if (p.arch == ARCH_WAVENET && first_stream >= 0)
+    {
+      if (!g.d_prewarm)
+        NAM_HIP_CHECK(hipMalloc(&g.d_prewarm, (size_t)p.state_floats * sizeof(float)));
+      NAM_HIP_CHECK(hipMemcpyAsync(g.d_prewarm, g.d_state + (size_t)first_stream * g.state_stride,
+                                   (size_t)p.state_floats * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+      g.prewarm_kernel = kernel_for_launch(b, g, frames);
+      g.prewarm_len = frames;
+    }
   }
   return NAM_HIP_OK;
 }
@@ -1032,6 +1069,8 @@ void free_group(WidthGroup& g)
     (void)hipFree(g.d_init);
   if (g.d_map)
     (void)hipFree(g.d_map);
+  if (g.d_prewarm)
+    (void)hipFree(g.d_prewarm);
   g = WidthGroup();
 }
 
@@ -1307,7 +1346,7 @@ int nam_hip_batch_reset(nam_hip_batch* batch, int prewarm)
   {
     if (g.streams.empty())
       continue;
-    const int rc = reset_streams(batch, g, g.d_map, (int)g.streams.size(), prewarm != 0);
+    const int rc = reset_streams(batch, g, g.d_map, (int)g.streams.size(), prewarm != 0, g.streams.front());
     if (rc != NAM_HIP_OK)
       return rc;
   }
@@ -1372,7 +1411,7 @@ int nam_hip_batch_set_slimmable_size(nam_hip_batch* batch, const int* stream_ids
   int* d_moved = nullptr;
   NAM_HIP_CHECK(hipMalloc(&d_moved, moved.size() * sizeof(int)));
   NAM_HIP_CHECK(hipMemcpy(d_moved, moved.data(), moved.size() * sizeof(int), hipMemcpyHostToDevice));
-  rc = reset_streams(batch, batch->groups[w], d_moved, (int)moved.size(), batch->was_reset && batch->reset_with_prewarm);
+  rc = reset_streams(batch, batch->groups[w], d_moved, (int)moved.size(), batch->was_reset && batch->reset_with_prewarm, moved.front());
   hipError_t e = hipStreamSynchronize(batch->stream);
   (void)hipFree(d_moved);
   if (rc != NAM_HIP_OK)

@@ -1088,3 +1088,42 @@ def test_lds_ring_kernel_mixed_width_batch_one_launch(nam_lib, oracle):
     full = _oracle_run(oracle, name, x[0, :4 * seg], block, True)
     assert float(np.max(np.abs(full - y[0]))) <= 5e-5
     b.close()
+
+
+@pytest.mark.parametrize("name", ["wavenet_a1_standard", "wavenet_a2_max", "slimmable_wavenet", "A2"])
+def test_prewarm_cache_matches_a_fresh_prewarm(nam_lib, oracle, name):
+    """The prewarm cache (conv1d.cpp:151-161, model.cpp:737-775: the reference caches what prewarm leaves in every conv
+    and refills from it on later Resets): the first Reset runs the silence and keeps one stream's state, later Resets —
+    and per-stream SetSlimmableSize — copy it. Bit-equal to the first run, equal to the oracle, and a Reset without
+    prewarm still starts from zero state."""
+    nam = nam_lib
+    n_streams, block, n = 5, 64, 64 * 4
+    x = stream_bank(n_streams, n, seed=61)
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    b = model.batch(n_streams, block)
+    b.Reset(prewarm=True)
+    y1 = b.process_stream(x, block)  # prewarm ran
+    b.Reset(prewarm=True)
+    y2 = b.process_stream(x, block)  # state copied from the cache
+    np.testing.assert_array_equal(y1, y2)
+    b.Reset(prewarm=False)
+    y0 = b.process_stream(x, block)
+    b.Reset(prewarm=True)
+    np.testing.assert_array_equal(y1, b.process_stream(x, block))
+    r = _oracle_run(oracle, name, x[2], block, True)
+    assert float(np.max(np.abs(r - y1[2]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r))))
+    ref0 = oracle.get_dsp(model_path(name), fast_tanh=True)
+    ref0.Reset(48000.0, block, prewarm=False)
+    r0 = ref0.process_stream(x[2], block)
+    assert float(np.max(np.abs(r0 - y0[2]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r0))))
+    if model.is_slimmable:
+        # stream 1 leaves and comes back: the second visit of a width is served from that width's cache
+        for ratio in (0.0, 1.0, 0.0, 1.0):
+            b.SetSlimmableSize(ratio, [1])
+            y = b.process_stream(x, block)
+            rr = oracle.get_dsp(model_path(name), fast_tanh=True)
+            rr.SetSlimmableSize(ratio)
+            rr.Reset(48000.0, block)
+            want = rr.process_stream(x[1], block)
+            assert float(np.max(np.abs(want - y[1]))) <= 5e-5 * max(1.0, float(np.max(np.abs(want)))), ratio
+    b.close()
