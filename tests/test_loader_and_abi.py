@@ -190,3 +190,22 @@ def test_corrupt_geometry_is_a_load_error(nam_lib, tmp_path, field, value):
         json.dump(j, f)
     with pytest.raises(nam_lib.NamHipError):
         nam_lib.get_dsp(p)
+
+
+def test_register_resident_kernel_state_is_an_image_of_its_lds_rings(nam_lib):
+    """nam_wn_reg_kernel's per-stream state: 64 write positions, then one ring per layer of exactly
+    (K - 1) * dilation + 64 frames, stored in groups of up to four channels and padded to four floats; rounded up to 64
+    floats and never smaller than the other kernels' layout of the same model. Decided by the plan compiler: checkable
+    without a GPU."""
+    def wr_floats(layers):  # [(channels, kernel, dilation)]
+        return (64 + sum((c * ((k - 1) * d + 64) + 3) // 4 * 4 for c, k, d in layers) + 63) // 64 * 64
+
+    D = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+    m = nam_lib.get_dsp(model_path("slimmable_wavenet"))  # full width: 3 channels
+    assert m.info.state_bytes_per_stream == 4 * wr_floats([(3, 3, d) for d in D]) == 32512
+    m = nam_lib.get_dsp(model_path("synth_a1_nano"))  # 4 -> 2 channels: 68 KB of rings, LDS-resident
+    assert m.info.state_bytes_per_stream == 4 * wr_floats([(4, 3, d) for d in D] + [(2, 3, d) for d in D])
+    # wavenet_a2_max: nested condition net (3 channels K = 2 x 2; 4 channels K = 3, dilations 1, 3, 5), main array (4
+    # channels, K = 4, dilations 1, 2); the op program's rings of the same model are the larger layout here
+    m = nam_lib.get_dsp(model_path("wavenet_a2_max"))
+    assert m.info.state_bytes_per_stream >= 4 * wr_floats([(3, 2, 1), (3, 2, 2), (4, 3, 1), (4, 3, 3), (4, 3, 5), (4, 4, 1), (4, 4, 2)])
