@@ -1,6 +1,10 @@
 // render — the reference's offline re-amp tool (tools/render.cpp:63-205) on the MI355X batch path.
 //   render [--slim <0..1>] <model.nam> <input.wav> [output.wav]            (the reference's command line)
-//   render [--slim <0..1>] <model.nam> --batch <out_dir> <in1.wav> <in2.wav> ...
+//   render [--slim <0..1>] [--devices <list>] [--plan-only] <model.nam> --batch <out_dir> <in1.wav> <in2.wav> ...
+// --devices ("all", "0-7", "0,2,5"; duplicates allowed): the files are dealt to the listed GPUs, longest first in snake
+// order, and every GPU renders its share as its own batch on its own host thread (cpp/NAM/multi_device.h; no collective:
+// streams never interact). --plan-only prints that assignment ("device <d>: <file> (<frames> frames)") and exits
+// without touching a GPU (--device-count N stands in for the visible devices).
 // The batch form pushes N files through one model as N independent streams of one GPU batch (files may have
 // different lengths); outputs are <out_dir>/<input stem>.wav. As in the reference: mono input only, the WAV's
 // sample rate must match the model's expected rate when it has one, Reset(rate, 64) with the model's prewarm,
@@ -15,6 +19,7 @@
 #include <vector>
 
 #include "NAM/get_dsp.h"
+#include "NAM/multi_device.h"
 #include "wav_io.h"
 
 int main(int argc, char* argv[])
@@ -25,6 +30,9 @@ int main(int argc, char* argv[])
     bool slim = false;
     double slimValue = -1.0;
     std::string batchDir;
+    std::string devices; // empty: device 0, one batch
+    bool planOnly = false;
+    int deviceCount = -1; // --device-count: stands in for nam_hip_device_count (plan-only runs on boxes without a GPU)
     std::vector<std::string> positional;
   } opt;
   auto value_of = [&](int& i, const char* what) -> const char* {
@@ -51,6 +59,12 @@ int main(int argc, char* argv[])
     }
     else if (!std::strcmp(argv[i], "--batch"))
       opt.batchDir = value_of(i, "--batch requires an output directory");
+    else if (!std::strcmp(argv[i], "--devices"))
+      opt.devices = value_of(i, "--devices requires a list such as all, 0-7 or 0,2,5");
+    else if (!std::strcmp(argv[i], "--device-count"))
+      opt.deviceCount = std::atoi(value_of(i, "--device-count requires a number"));
+    else if (!std::strcmp(argv[i], "--plan-only"))
+      opt.planOnly = true;
     else
       opt.positional.emplace_back(argv[i]);
   }
@@ -62,7 +76,8 @@ int main(int argc, char* argv[])
   if ((!batchMode && (pos.size() < 2 || pos.size() > 3)) || (batchMode && pos.size() < 2))
   {
     std::cerr << "Usage: render [--slim <0.0-1.0>] <model.nam> <input.wav> [output.wav]\n"
-                 "       render [--slim <0.0-1.0>] <model.nam> --batch <out_dir> <in1.wav> [<in2.wav> ...]\n";
+                 "       render [--slim <0.0-1.0>] [--devices <all|0-7|0,2,5>] [--plan-only] <model.nam> --batch <out_dir> <in1.wav> "
+                 "[<in2.wav> ...]\n";
     return 1;
   }
   try
@@ -84,6 +99,27 @@ int main(int argc, char* argv[])
       outputs.push_back(pos.size() >= 3 ? pos[2] : "output.wav");
     }
     const int n = (int)inputs.size();
+
+    // the devices the batch is spread over (multi_device.h); default: one batch on device 0
+    std::vector<int> devices{0};
+    if (!opt.devices.empty())
+    {
+      int count = opt.deviceCount;
+      if (count < 0)
+        nam::detail::check(nam_hip_device_count(&count));
+      devices = nam::parse_device_list(opt.devices, count);
+    }
+    if (opt.planOnly)
+    {
+      std::vector<int64_t> lengths;
+      for (const auto& f : inputs)
+        lengths.push_back((int64_t)wavio::load(f).samples.size());
+      const auto deal = nam::deal_by_length(lengths, (int)devices.size());
+      for (size_t d = 0; d < devices.size(); d++)
+        for (int i : deal[d])
+          std::cout << "device " << devices[d] << " (batch " << d << "): " << inputs[(size_t)i] << " (" << lengths[(size_t)i] << " frames)\n";
+      return 0;
+    }
 
     std::cerr << "Loading model [" << modelPath << "]\n";
     nam_hip_model* raw = nullptr;
@@ -121,16 +157,20 @@ int main(int argc, char* argv[])
       }
     }
 
-    dsp.Reset(sampleRate, 64); // bufferSize 64 as the reference (tools/render.cpp:146-147): fixes the prewarm length
-    if (hasSlim)
+    const bool spread = devices.size() > 1 || devices[0] != 0; // several batches, one per listed device (multi_device.h)
+    if (hasSlim && !dsp.IsSlimmable())
     {
-      if (!dsp.IsSlimmable())
+      std::cerr << "Error: --slim requires a model that implements the SlimmableModel interface\n";
+      return 1;
+    }
+    if (!spread)
+    {
+      dsp.Reset(sampleRate, 64); // bufferSize 64 as the reference (tools/render.cpp:146-147): fixes the prewarm length
+      if (hasSlim)
       {
-        std::cerr << "Error: --slim requires a model that implements the SlimmableModel interface\n";
-        return 1;
+        std::cerr << "Setting slimmable size to " << slimValue << "\n";
+        dsp.SetSlimmableSize(nullptr, 0, slimValue);
       }
-      std::cerr << "Setting slimmable size to " << slimValue << "\n";
-      dsp.SetSlimmableSize(nullptr, 0, slimValue);
     }
 
     const int oc = dsp.NumOutputChannels();
@@ -145,7 +185,10 @@ int main(int argc, char* argv[])
       inp[i] = audio[i].samples.data();
       outp[i] = out[i].data();
     }
-    dsp.render(inp.data(), outp.data(), frames.data());
+    if (spread)
+      nam::render_on_devices(model, devices, inp.data(), outp.data(), frames.data(), n, sampleRate, hasSlim ? slimValue : -1.0);
+    else
+      dsp.render(inp.data(), outp.data(), frames.data());
     for (int i = 0; i < n; i++)
     {
       wavio::save_float32(outputs[i], out[i].data(), audio[i].samples.size(), sampleRate); // channel 0

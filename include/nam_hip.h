@@ -122,11 +122,40 @@ typedef struct nam_hip_load_options
   int32_t fast_tanh;
   int32_t n_luts;
   const nam_hip_lut* luts;
+  /* != 0: the caller has already run the version gate — verify_config_version with its own registered
+   * IVersionSupportChecker objects (NAM/get_dsp.h:19-25,60, get_dsp.cpp:92-128), which can only WIDEN what the core
+   * checker accepts — so the library's built-in gate (0.5.0 <= version, minor <= 0.7) is skipped. */
+  int32_t version_checked_by_caller;
+  int32_t reserved;
 } nam_hip_load_options;
 NAM_HIP_API int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam_hip_load_options* options,
                                       nam_hip_model** out_model);
 NAM_HIP_API void nam_hip_model_free(nam_hip_model* model);
 NAM_HIP_API int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info);
+
+/* ---- nam::dspData (NAM/dsp.h:348-357) across the boundary: get_dsp(dspData&) NAM/get_dsp.h:91, get_dsp(path, dspData&
+ * returnedConfig) :101, get_dsp(json, dspData& returnedConfig) :109, get_sample_rate_from_nam_file :121 ----
+ * nam_hip_model_load_parts builds a model from the fields of a dspData: version, architecture, the "config" value as JSON
+ * text, the "metadata" value as JSON text (NULL or "null": none), the weights, expected_sample_rate (-1.0: unknown).
+ * It runs verify_config_version + the architecture's config parser + weight binding (get_dsp.cpp:232-261), and fails
+ * the way those do. */
+NAM_HIP_API int nam_hip_model_load_parts(const char* version, const char* architecture, const char* config_json,
+                                         const char* metadata_json, const float* weights, int64_t n_weights,
+                                         double expected_sample_rate, const nam_hip_load_options* options,
+                                         nam_hip_model** out_model);
+/* The dspData of a loaded model (populate_dsp_data, get_dsp.cpp:141-154). String fields: */
+#define NAM_HIP_FIELD_VERSION 0
+#define NAM_HIP_FIELD_ARCHITECTURE 1
+#define NAM_HIP_FIELD_CONFIG_JSON 2 /* the "config" value, compact JSON text */
+#define NAM_HIP_FIELD_METADATA_JSON 3 /* the "metadata" value ("null" when the file has none) */
+#define NAM_HIP_FIELD_DESCRIPTION 4 /* not dspData: one line about the device plans (which kernels take the model, and why                                        nam_wn_reg_kernel does not when it does not) */
+/* Copies up to capacity - 1 bytes + NUL into buf (buf may be NULL); returns the full length (>= 0) or an error code. */
+NAM_HIP_API int64_t nam_hip_model_get_string(const nam_hip_model* model, int field, char* buf, int64_t capacity);
+/* Copies up to `capacity` weights (out may be NULL); returns their number. A SlimmableContainer has none of its own. */
+NAM_HIP_API int64_t nam_hip_model_get_weights(const nam_hip_model* model, float* out, int64_t capacity);
+/* get_sample_rate_from_nam_file (NAM/get_dsp.h:121, get_dsp.cpp:275-281) on a .nam document given as a path or as text
+ * (exactly one non-NULL): "sample_rate" if present, else -1.0. */
+NAM_HIP_API int nam_hip_sample_rate_from_nam(const char* nam_path, const char* json_text, double* out_sample_rate);
 
 /* SlimmableModel::GetSlimmableSizeBreakpoints — NAM/slimmable.h:29, NAM/wavenet/slimmable.cpp:108-121.
  * Writes up to `capacity` values, returns the number available (>= 0) or an error code. */
@@ -215,11 +244,23 @@ NAM_HIP_API int nam_hip_batch_n_streams(const nam_hip_batch* batch);
  * "nam_kt_mfma_kernel", "nam_a1_kernel", "nam_generic_kernel", "nam_lstm_mfma_reg_kernel", ...): the name
  * rocprofv3 --kernel-trace reports (without template arguments), so measurements can be attributed to the right kernel. */
 NAM_HIP_API const char* nam_hip_batch_kernel_name(const nam_hip_batch* batch);
+/* The same question for a launch of n_frames (nam_hip_batch_kernel_name answers it for one 64-frame buffer): under
+ * NAM_HIP_KERNEL_AUTO a launch that walks four or more blocks — an offline render, the prewarm of Reset — runs the
+ * interleaved-frame kernel where a one-block launch runs the wave-specialised one. */
+NAM_HIP_API const char* nam_hip_batch_kernel_name_for(const nam_hip_batch* batch, int n_frames);
 
 /* Developer tool, not part of the drop-in surface: runs n_frames of silence through the MFMA kernel's profiling
  * instantiation; out_stamps (96 x 8 int64) receives, per wavefront w of workgroup 0 (row w): barrier cycles, total
  * cycles, and for compute waves five per-job segment sums (tools/mfma_barrier_profile.py). */
 NAM_HIP_API int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* out_stamps);
+
+/* Number of HIP devices this process can see (what `device` of nam_hip_batch_create indexes; honours
+ * HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES). For hosts that spread batches over the GPUs of a node (cpp/NAM/multi_device.h). */
+NAM_HIP_API int nam_hip_device_count(int* out_count);
+
+/* The built-in version gate (CoreVersionSupportChecker, NAM/get_dsp.cpp:18-39): 0 = not supported, 1 = partially (newer
+ * patch level than the latest fully supported file version), 2 = fully. */
+NAM_HIP_API int nam_hip_version_support(const char* nam_file_version);
 
 /* Library identification: "nam_hip <version> gfx950". */
 NAM_HIP_API const char* nam_hip_version(void);

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 __all__ = [
-    "NamHipError", "NamFileValidationError", "Model", "Batch", "get_dsp", "get_dsp_json", "lib_path", "load_library",
+    "NamHipError", "NamFileValidationError", "Model", "Batch", "get_dsp", "get_dsp_json", "get_dsp_data", "get_sample_rate_from_nam_file", "lib_path", "load_library",
     "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_A1", "KERNEL_A1_MFMA", "KERNEL_A1_IL", "KERNEL_WN_REG", "ABI_SYMBOLS",
 ]
 
@@ -37,6 +37,8 @@ ABI_SYMBOLS = [
     "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams", "nam_hip_batch_kernel_name",
     "nam_hip_batch_set_persistent", "nam_hip_batch_flush",
     "nam_hip_batch_debug_timeline",
+    "nam_hip_model_load_parts", "nam_hip_model_get_string", "nam_hip_model_get_weights", "nam_hip_sample_rate_from_nam",
+    "nam_hip_batch_kernel_name_for", "nam_hip_version_support", "nam_hip_device_count",
 ]
 
 
@@ -69,7 +71,8 @@ class _Lut(ctypes.Structure):
 
 
 class _LoadOptions(ctypes.Structure):
-    _fields_ = [("fast_tanh", ctypes.c_int32), ("n_luts", ctypes.c_int32), ("luts", ctypes.POINTER(_Lut))]
+    _fields_ = [("fast_tanh", ctypes.c_int32), ("n_luts", ctypes.c_int32), ("luts", ctypes.POINTER(_Lut)),
+                ("version_checked_by_caller", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def lib_path() -> str:
@@ -142,6 +145,16 @@ def load_library():
     L.nam_hip_batch_kernel_name.argtypes = [vp]
     L.nam_hip_batch_kernel_name.restype = ctypes.c_char_p
     L.nam_hip_batch_debug_timeline.argtypes = [vp, ci, vp]
+    L.nam_hip_batch_kernel_name_for.argtypes = [vp, ci]
+    L.nam_hip_batch_kernel_name_for.restype = ctypes.c_char_p
+    L.nam_hip_model_load_parts.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, vp, ctypes.c_int64, cd,
+                                           ctypes.POINTER(_LoadOptions), ctypes.POINTER(vp)]
+    L.nam_hip_model_get_string.argtypes = [vp, ci, ctypes.c_char_p, ctypes.c_int64]
+    L.nam_hip_model_get_string.restype = ctypes.c_int64
+    L.nam_hip_model_get_weights.argtypes = [vp, vp, ctypes.c_int64]
+    L.nam_hip_model_get_weights.restype = ctypes.c_int64
+    L.nam_hip_version_support.argtypes = [ctypes.c_char_p]
+    L.nam_hip_sample_rate_from_nam.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(cd)]
     _lib = L
     return L
 
@@ -219,6 +232,32 @@ class Model:
     def version(self) -> str:
         return self.info.version.decode()
 
+    # --- nam::dspData (NAM/dsp.h:348-357) of the loaded model: what get_dsp(path, dspData& returnedConfig) hands back ---
+    def _string(self, field: int) -> str:
+        n = _check(self._L.nam_hip_model_get_string(self._h, field, None, 0))
+        buf = ctypes.create_string_buffer(n + 1)
+        _check(self._L.nam_hip_model_get_string(self._h, field, buf, n + 1))
+        return buf.value.decode("utf-8", "replace")
+
+    def dsp_data(self) -> dict:
+        """{version, architecture, config (JSON text), metadata (JSON text), weights (float32 array), expected_sample_rate}."""
+        n = _check(self._L.nam_hip_model_get_weights(self._h, None, 0))
+        w = np.zeros(n, dtype=np.float32)
+        if n:
+            _check(self._L.nam_hip_model_get_weights(self._h, w.ctypes.data_as(ctypes.c_void_p), n))
+        return dict(version=self._string(0), architecture=self._string(1), config=self._string(2), metadata=self._string(3),
+                    weights=w, expected_sample_rate=self.info.expected_sample_rate)
+
+    def describe(self) -> str:
+        """One line about the device plans: which kernels take the model (and why nam_wn_reg_kernel does not)."""
+        return self._string(4)
+
+    def wr_why(self) -> str:
+        """Why the register-resident WaveNet kernel refuses the full-size plan ('' when it takes it)."""
+        import re
+        m = re.findall(r"wn_reg=0 \(([^)]*)\)", self.describe())
+        return m[-1] if m else ""
+
     def GetSlimmableSizeBreakpoints(self) -> List[float]:
         buf = (ctypes.c_double * 64)()
         n = _check(self._L.nam_hip_model_slimmable_breakpoints(self._h, buf, 64))
@@ -276,9 +315,12 @@ class Batch:
         """Wait until every buffer submitted in persistent mode is rendered (``stream``: the hipStream_t they were issued on)."""
         _check(self._L.nam_hip_batch_flush(self._h, ctypes.c_void_p(stream)))
 
-    def kernel_name(self) -> str:
-        """The __global__ function the batch's largest stream group runs (the name rocprofv3 reports)."""
-        return self._L.nam_hip_batch_kernel_name(self._h).decode()
+    def kernel_name(self, n_frames: Optional[int] = None) -> str:
+        """The __global__ function the batch's largest stream group runs (the name rocprofv3 reports) for a launch of
+        n_frames (default: one 64-frame buffer); under AUTO longer launches may run another kernel of the family."""
+        if n_frames is None:
+            return self._L.nam_hip_batch_kernel_name(self._h).decode()
+        return self._L.nam_hip_batch_kernel_name_for(self._h, int(n_frames)).decode()
 
     def synchronize(self):
         _check(self._L.nam_hip_batch_synchronize(self._h))
@@ -387,3 +429,25 @@ def get_dsp_json(text: str, fast_tanh: bool = False, luts=None) -> Model:
     h = ctypes.c_void_p()
     _check(L.nam_hip_model_load_json(text.encode("utf-8"), 1 if fast_tanh else 0, ctypes.byref(h)))
     return Model(h.value)
+
+
+def get_dsp_data(conf: dict, fast_tanh: bool = False) -> Model:
+    """nam::get_dsp(dspData& conf) (NAM/get_dsp.h:91): `conf` as Model.dsp_data() returns it — version, architecture,
+    config / metadata as JSON text, weights, expected_sample_rate."""
+    L = load_library()
+    h = ctypes.c_void_p()
+    w = np.ascontiguousarray(conf["weights"], dtype=np.float32)
+    opts = _LoadOptions(1 if fast_tanh else 0, 0, None)
+    md = conf.get("metadata")
+    _check(L.nam_hip_model_load_parts(conf["version"].encode(), conf["architecture"].encode(), conf["config"].encode("utf-8"),
+                                      md.encode("utf-8") if md else None, w.ctypes.data_as(ctypes.c_void_p), int(w.size),
+                                      float(conf.get("expected_sample_rate", -1.0)), ctypes.byref(opts), ctypes.byref(h)))
+    return Model(h.value)
+
+
+def get_sample_rate_from_nam_file(path: Optional[str] = None, text: Optional[str] = None) -> float:
+    """nam::get_sample_rate_from_nam_file (NAM/get_dsp.h:121): "sample_rate" of the document, or -1.0."""
+    out = ctypes.c_double(0.0)
+    _check(load_library().nam_hip_sample_rate_from_nam(os.fsencode(path) if path is not None else None,
+                                                       text.encode("utf-8") if text is not None else None, ctypes.byref(out)))
+    return out.value

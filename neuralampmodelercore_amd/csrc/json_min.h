@@ -6,6 +6,7 @@
 // the loader exactly as `std::vector<float> weights = j["weights"]` does, NAM/get_dsp.cpp:130-139).
 #pragma once
 
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -412,6 +413,93 @@ inline Value parse(const std::string& text)
   Parser p(text.data(), text.size());
   return p.parse();
 }
+
+// Serialise a value back to JSON text (compact). Numbers print with 17 significant digits: a double read from a
+// .nam file and a float weight both survive the round trip exactly.
+inline void dump_to(const Value& v, std::string& out)
+{
+  switch (v.type)
+  {
+    case Value::Null: out += "null"; break;
+    case Value::Bool: out += v.b ? "true" : "false"; break;
+    case Value::Number:
+    {
+      if (v.num != v.num)
+        out += "NaN";
+      else if (v.num == (double)(long long)v.num && v.num > -1e15 && v.num < 1e15)
+        out += std::to_string((long long)v.num);
+      else
+      {
+        char buf[40];
+        std::snprintf(buf, sizeof(buf), "%.17g", v.num);
+        out += buf;
+      }
+      break;
+    }
+    case Value::String:
+    {
+      out += '"';
+      for (unsigned char c : v.str)
+      {
+        switch (c)
+        {
+          case '"': out += "\\\""; break;
+          case '\\': out += "\\\\"; break;
+          case '\n': out += "\\n"; break;
+          case '\r': out += "\\r"; break;
+          case '\t': out += "\\t"; break;
+          default:
+            if (c < 0x20)
+            {
+              char buf[8];
+              std::snprintf(buf, sizeof(buf), "\\u%04x", (unsigned)c);
+              out += buf;
+            }
+            else
+              out += (char)c;
+        }
+      }
+      out += '"';
+      break;
+    }
+    case Value::Array:
+    {
+      out += '[';
+      for (size_t i = 0; i < v.arr.size(); i++)
+      {
+        if (i)
+          out += ',';
+        dump_to(v.arr[i], out);
+      }
+      out += ']';
+      break;
+    }
+    case Value::Object:
+    {
+      out += '{';
+      for (size_t i = 0; i < v.obj.size(); i++)
+      {
+        if (i)
+          out += ',';
+        Value k;
+        k.type = Value::String;
+        k.str = v.obj[i].first;
+        dump_to(k, out);
+        out += ':';
+        dump_to(v.obj[i].second, out);
+      }
+      out += '}';
+      break;
+    }
+  }
+}
+inline std::string dump(const Value& v)
+{
+  std::string out;
+  dump_to(v, out);
+  return out;
+}
+
 
 } // namespace json
 } // namespace namhip

@@ -481,15 +481,10 @@ namespace
 template <int C0, int C1, int ACT_T, bool WT, bool PERSIST = false>
 hipError_t launch_p2_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 {
-  static bool configured = false;
-  if (!configured)
-  {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, p2::kLdsBytes);
-    if (e != hipSuccess)
-      return e;
-    configured = true;
-  }
+  static DynamicLdsLimit lds_limit; // per instantiation, tracked per device (kernels.h)
+  const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>), p2::kLdsBytes);
+  if (e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(256), p2::kLdsBytes, stream, a.blob, a);
   return hipGetLastError();
 }

@@ -10,6 +10,10 @@ namespace namhip
 // ------------------------------------------------------------------------------------------------
 // LSTM: lanes = streams (a true per-sample recurrence — NAM/lstm.cpp:103-168)
 // ------------------------------------------------------------------------------------------------
+// GS: the per-lane columns (h, c, gate pre-activations) live in a global-memory scratch area instead of LDS — the cell is
+// too large for a CU's 160 KB (the reference has no size limit, NAM/lstm.cpp:31-68); only the I/O tiles stay in LDS.
+// Each lane touches its own column only ([row][64 lanes]: coalesced 256-byte rows).
+template <bool GS>
 __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ blob, const LSTMArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -24,7 +28,7 @@ __global__ __launch_bounds__(64) void nam_lstm_kernel(const float* __restrict__ 
   const int in_ch = a.in_ch, out_ch = a.out_ch;
   float* tile_in = lds; // [in_ch][64][65]
   float* tile_out = tile_in + in_ch * kBlock * 65; // [out_ch][64][65]
-  float* hs = tile_out + out_ch * kBlock * 65; // [NL][H][64]
+  float* hs = GS ? a.scratch + (size_t)blockIdx.x * (size_t)(2 * NL + 4) * H * kBlock : tile_out + out_ch * kBlock * 65; // [NL][H][64]
   float* cs = hs + NL * H * kBlock; // [NL][H][64]
   float* ifgo = cs + NL * H * kBlock; // [4H][64]
 
@@ -880,22 +884,47 @@ __global__ void nam_fill_state_kernel(float* state, long state_stride, const int
 
 int lstm_lds_bytes(const LSTMArgs& a)
 {
-  const int floats = (a.in_ch + a.out_ch) * kBlock * 65 + 2 * a.n_layers * a.hidden * kBlock + 4 * a.hidden * kBlock;
-  return floats * (int)sizeof(float);
+  const long floats = (long)(a.in_ch + a.out_ch) * kBlock * 65 + 2l * a.n_layers * a.hidden * kBlock + 4l * a.hidden * kBlock;
+  return (int)std::min<long>(floats * (long)sizeof(float), 1l << 30);
+}
+// floats of global scratch nam_lstm_kernel<true> needs for `n_streams` (0: the cell fits LDS)
+long lstm_scratch_floats(const LSTMArgs& a)
+{
+  if (lstm_lds_bytes(a) <= 160 * 1024)
+    return 0;
+  const long n_blocks = (a.n_streams + kBlock - 1) / kBlock;
+  return n_blocks * (long)(2 * a.n_layers + 4) * a.hidden * kBlock;
 }
 
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream)
 {
+  const int n_blocks = (a.n_streams + kBlock - 1) / kBlock;
+  if (lstm_scratch_floats(a) > 0)
+  {
+    if (!a.scratch)
+      return hipErrorInvalidValue;
+    const int io_bytes = (a.in_ch + a.out_ch) * kBlock * 65 * (int)sizeof(float);
+    if (io_bytes > 160 * 1024)
+      return hipErrorInvalidValue;
+    static DynamicLdsLimit lim;
+    if (io_bytes > 64 * 1024)
+    {
+      const hipError_t e = lim.ensure(reinterpret_cast<const void*>(nam_lstm_kernel<true>), 160 * 1024);
+      if (e != hipSuccess)
+        return e;
+    }
+    hipLaunchKernelGGL(nam_lstm_kernel<true>, dim3(n_blocks), dim3(64), io_bytes, stream, a.blob, a);
+    return hipGetLastError();
+  }
   const int lds_bytes = lstm_lds_bytes(a);
   if (lds_bytes > 64 * 1024)
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nam_lstm_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    static DynamicLdsLimit lim;
+    const hipError_t e = lim.ensure(reinterpret_cast<const void*>(nam_lstm_kernel<false>), 160 * 1024);
     if (e != hipSuccess)
       return e;
   }
-  const int n_blocks = (a.n_streams + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(nam_lstm_kernel, dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a);
+  hipLaunchKernelGGL(nam_lstm_kernel<false>, dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a);
   return hipGetLastError();
 }
 

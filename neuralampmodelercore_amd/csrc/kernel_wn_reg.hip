@@ -964,18 +964,13 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
     return hipSuccess;
   // more than the default 64 KB of dynamic LDS per workgroup (long dilations at 4+ channels: the official nano size
   // keeps 68 KB of rings): raised once per instantiation
-  static bool raised[16][3] = {}; // per device (the attribute belongs to the device's copy of the function)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev = dev < 0 || dev >= 16 ? 0 : dev;
+  static DynamicLdsLimit lds_limit[3]; // per instantiation, tracked per device (kernels.h)
   auto launch = [&](auto kernel, int set) -> hipError_t {
-    if (lds_bytes > 64 * 1024 && !raised[dev][set])
+    if (lds_bytes > 64 * 1024)
     {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               kWrMaxLdsBytes);
+      const hipError_t e = lds_limit[set].ensure(reinterpret_cast<const void*>(kernel), kWrMaxLdsBytes);
       if (e != hipSuccess)
         return e;
-      raised[dev][set] = true;
     }
     hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
     return hipGetLastError();

@@ -8,6 +8,29 @@
 namespace namhip
 {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the CURRENT DEVICE's copy of a function: a process that runs
+// batches on several GPUs must raise it once per (function, device). One of these per kernel instantiation; devices
+// beyond 63 set the attribute on every launch.
+struct DynamicLdsLimit
+{
+  unsigned long long raised = 0; // bit d: done on device d (launches of one batch come from one host thread at a time;
+                                 // a lost update between threads only repeats the call)
+  hipError_t ensure(const void* fn, int bytes)
+  {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+      return e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((__atomic_load_n(&raised, __ATOMIC_RELAXED) >> dev) & 1ull))
+      return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && tracked)
+      __atomic_fetch_or(&raised, 1ull << dev, __ATOMIC_RELAXED);
+    return e;
+  }
+};
+
 // Persistent session of a one-wavefront-per-workgroup kernel (persist_wave.h); ring == nullptr: an ordinary launch
 struct PersistArgs
 {
@@ -102,6 +125,7 @@ struct LSTMArgs
   int mf_layer_tiles[16];
   int mf_layer_bias[16];
   PersistArgs ps; // nam_lstm_row_kernel / nam_lstm_wide_kernel
+  float* scratch = nullptr; // nam_lstm_kernel<true>: global-memory h / c / gate columns (lstm_scratch_floats)
 };
 
 // nam_wn_reg_kernel (plan.h: WrPlan). One launch serves up to kWrMaxGroups WIDTH GROUPS — streams of a slimmable model
@@ -147,6 +171,7 @@ bool lstm_row_eligible(const LSTMArgs& a);
 hipError_t launch_lstm_wide(const LSTMArgs& a, hipStream_t stream); // 5 .. 32 hidden units: two gate rows per lane
 bool lstm_wide_eligible(const LSTMArgs& a);
 int lstm_lds_bytes(const LSTMArgs& a);
+long lstm_scratch_floats(const LSTMArgs& a); // > 0: the lanes = streams kernel keeps its columns in global scratch
 hipError_t launch_fill_state(float* state, long state_stride, const int* stream_map, int n_streams, const float* init,
                              int n_init, int state_floats, hipStream_t stream);
 

@@ -62,6 +62,7 @@ struct LoadOptions
 {
   bool fast_tanh = false;
   std::vector<LutSpec> luts;
+  bool skip_version_gate = false; // the caller ran verify_config_version with its own checkers (get_dsp.h:60)
 };
 
 enum GatingMode : int
@@ -176,6 +177,9 @@ struct ModelSpec
   bool has_loudness = false, has_input_level = false, has_output_level = false;
   double loudness = 0.0, input_level = 0.0, output_level = 0.0;
   bool fast_tanh = false; // resolved at load time (the reference uses a process-global, activations.cpp:168)
+  // what nam::dspData carries besides the weights (NAM/dsp.h:348-357, filled by populate_dsp_data get_dsp.cpp:141-154):
+  // the architecture string and the "config" / "metadata" values as JSON text ("null" when the file has no metadata)
+  std::string architecture_name, config_text, metadata_text = "null";
   WaveNetSpec wavenet;
   LSTMSpec lstm;
   // ARCH_CONTAINER: submodels sorted by ascending max_value; SetSlimmableSize(v) activates the first one with
@@ -194,6 +198,8 @@ struct ModelSpec
 // nam::get_dsp(path) front half: validate_nam_file + populate_dsp_data + config parse.
 std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, const LoadOptions& lo);
 std::shared_ptr<ModelSpec> load_nam_text(const std::string& json_text, const LoadOptions& lo);
+// get_sample_rate_from_nam_file (get_dsp.cpp:275-281) on the text of a .nam document: "sample_rate" or -1.0
+double sample_rate_from_nam_text(const std::string& json_text);
 
 // Slimmable helpers (slimmable.cpp:80-294)
 int ratio_to_channels(double ratio, const std::vector<int>& allowed);

@@ -97,6 +97,8 @@ struct WidthGroup
   float* d_wr_blob = nullptr; // nam_wn_reg_kernel's weights, tables and macro-ops (plan.h: WrPlan)
   float* d_state = nullptr; // [n_streams][state_stride] (allocated when the first stream joins)
   float* d_init = nullptr; // LSTM initial state
+  float* d_scratch = nullptr; // LSTM cells too large for LDS: nam_lstm_kernel<true>'s h / c / gate columns
+  long scratch_floats = 0;
   long state_stride = 0;
   std::vector<int> streams; // members, ascending
   int* d_map = nullptr; // device copy of `streams` (nullptr when the group is all streams in order)
@@ -148,6 +150,11 @@ struct PersistSession
   int n_wg = 0; // workgroups of the session's launch
   int kind = -1; // PersistKind
   int done_off = 0; // h_words: [0, done_off) progress words, [done_off, 2 done_off) completion words
+  // Sequence numbers are 31-bit (bit 31 of a completion word is the "left" flag): a session START — where every
+  // workgroup stands at exactly `seq` and nothing is in flight — rebases them to 0 once they pass this mark
+  // (NAM_HIP_PERSIST_REBASE_AT overrides it: tests)
+  unsigned rebase_at = 0x40000000u;
+  long timeout_ms = 20000; // a resident launch that makes no progress for this long is a device failure (NAM_HIP_PERSIST_TIMEOUT_MS)
 };
 } // namespace
 
@@ -315,10 +322,14 @@ inline bool persist_eligible(const nam_hip_batch* b)
   return persist_kind(b) != PERSIST_NONE;
 }
 
-const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
+int kernel_for_launch(const nam_hip_batch* b, const WidthGroup& g, int n_frames);
+
+// `n_frames`: the launch length the question is about (under AUTO a launch of four or more blocks runs another kernel
+// of the family than a one-block launch); 64 in persistent mode means "a command of the session"
+const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n_frames)
 {
   const Plan& p = *g.plan;
-  if (b->ps.enabled)
+  if (b->ps.enabled && n_frames == kBlock)
     switch (persist_kind(b)) // persistent block mode
     {
       case PERSIST_A1_P2: return "nam_a1_p2_kernel";
@@ -329,7 +340,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g)
     }
   if (p.arch == ARCH_WAVENET)
   {
-    switch (pick_kernel(b, g))
+    switch (kernel_for_launch(b, g, n_frames))
     {
       case NAM_HIP_KERNEL_GENERIC: return "nam_generic_kernel";
       case NAM_HIP_KERNEL_WN_REG: return "nam_wn_reg_kernel";
@@ -667,8 +678,20 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       NAM_HIP_CHECK(launch_lstm_mfma(a, s));
     else
     {
-      if (lstm_lds_bytes(a) > 160 * 1024)
-        return fail(NAM_HIP_ERR_UNSUPPORTED, "LSTM too large for the LDS-resident kernel");
+      // a cell whose columns exceed a CU's LDS keeps them in global memory (the reference has no size limit,
+      // lstm.cpp:31-68): slower, but it runs
+      const long need = lstm_scratch_floats(a);
+      if (need > g.scratch_floats)
+      {
+        NAM_HIP_CHECK(hipStreamSynchronize(s));
+        if (g.d_scratch)
+          NAM_HIP_CHECK(hipFree(g.d_scratch));
+        g.d_scratch = nullptr;
+        g.scratch_floats = 0;
+        NAM_HIP_CHECK(hipMalloc(&g.d_scratch, (size_t)need * sizeof(float)));
+        g.scratch_floats = need;
+      }
+      a.scratch = g.d_scratch;
       NAM_HIP_CHECK(launch_lstm(a, s));
     }
   }
@@ -816,6 +839,34 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   return rc;
 }
 
+// Watchdog of the host's spins on the session's completion words: the resident launch normally answers within
+// microseconds, so the spin itself stays a plain memory poll; every 4,096 polls it looks at the launch's stream — a
+// launch that has ENDED (or failed: a trap in the kernel, a memory fault, a GPU reset) without every workgroup having
+// set its "left" bit will never set it — and at the clock. Returns NAM_HIP_OK to keep spinning, 1 when the launch is
+// known to have ended (the caller re-reads the words once more), or an error.
+struct PersistWatch
+{
+  long polls = 0;
+  std::chrono::steady_clock::time_point t0{};
+  int check(nam_hip_batch* b)
+  {
+    if ((++polls & 4095) != 0)
+      return NAM_HIP_OK;
+    const auto now = std::chrono::steady_clock::now();
+    if (polls == 4096)
+      t0 = now;
+    const hipError_t q = hipStreamQuery(b->ps.kstream);
+    if (q == hipSuccess)
+      return 1;
+    if (q != hipErrorNotReady)
+      return fail(NAM_HIP_ERR_DEVICE, std::string("persistent session: the resident launch failed: ") + hipGetErrorString(q));
+    if (std::chrono::duration_cast<std::chrono::milliseconds>(now - t0).count() > b->ps.timeout_ms)
+      return fail(NAM_HIP_ERR_DEVICE, "persistent session: the resident launch made no progress for "
+                                        + std::to_string(b->ps.timeout_ms) + " ms (NAM_HIP_PERSIST_TIMEOUT_MS)");
+    return NAM_HIP_OK;
+  }
+};
+
 // Blocks until every submitted command has been consumed by every workgroup and its results are visible.
 // `caller`: the stream the doorbells were rung on.
 int persist_flush(nam_hip_batch* b, hipStream_t caller)
@@ -823,6 +874,8 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
   PersistSession& ps = b->ps;
   if (!ps.active)
     return NAM_HIP_OK;
+  PersistWatch watch;
+  bool ended = false; // the stream reported the launch complete: its words are final
   // The workgroups publish their count (behind a release fence behind their last results) when they LEAVE — which
   // they do as soon as they find the ring empty. The host watches those words rather than the launch's completion
   // signal, which takes an interrupt round trip longer.
@@ -838,7 +891,16 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
       all_left &= v;
     }
     if (ps.outstanding && !all_left)
+    {
+      if (ended) // the launch is gone and a workgroup never said goodbye: it died
+        return fail(NAM_HIP_ERR_DEVICE, "persistent session: the resident launch ended without every workgroup reporting");
+      const int wrc = watch.check(b);
+      if (wrc < 0)
+        return wrc;
+      ended = wrc == 1;
       continue; // the launch is still consuming
+    }
+    ended = false;
     ps.outstanding = false;
     if ((int)(lo - ps.seq) >= 0)
     {
@@ -902,7 +964,29 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     NAM_HIP_CHECK(hipDeviceSynchronize());
     NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
     std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
-    ps.seq = 0; // (sequence numbers run on across sessions: no ring slot ever needs clearing)
+    ps.seq = 0; // (sequence numbers run on across sessions — no ring slot needs clearing — until they are rebased, below)
+    if (const char* e = std::getenv("NAM_HIP_PERSIST_REBASE_AT"))
+      ps.rebase_at = (unsigned)std::max(1l, std::atol(e));
+    if (const char* e = std::getenv("NAM_HIP_PERSIST_TIMEOUT_MS"))
+      ps.timeout_ms = std::max(1l, std::atol(e));
+  }
+  if (ps.seq >= ps.rebase_at)
+  {
+    // a session starts flushed (persist_stop: every workgroup at exactly `seq`, the launch gone): renumber from 0. Stale
+    // ring slots carry tags near the old count, which a small count never matches; cleared anyway.
+    NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
+    NAM_HIP_CHECK(hipMemset(ps.d_ring, 0, kPRing * sizeof(unsigned long long)));
+    NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipDeviceSynchronize());
+    for (int w = 0; w < b->n_streams; w++)
+    {
+      ps.h_words[w] = 0u;
+      ps.h_words[b->n_streams + w] = 0x80000000u;
+    }
+    ps.seq = 0;
+    ps.flushed = 0;
+    ps.flushed_valid = true;
+    ps.outstanding = false;
   }
   const int kind = persist_kind(b);
   if (kind != ps.kind)
@@ -958,7 +1042,8 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   // host waits here for the slowest one to move on — back-pressure, at the pace the device consumes
   if ((ps.seq & 63u) == 0u)
   {
-    for (long spin = 0;; spin++)
+    PersistWatch watch;
+    for (;;)
     {
       unsigned lo = ~0u, all_left = 0x80000000u;
       for (int w = 0; w < ps.n_wg; w++)
@@ -975,8 +1060,12 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
         if (rc != NAM_HIP_OK)
           return rc;
       }
-      else if (spin > (1l << 26))
-        return fail(NAM_HIP_ERR_DEVICE, "persistent session stalled (command ring full)");
+      else
+      {
+        const int wrc = watch.check(b); // (1 = the launch has ended: the next pass sees every "left" bit and flushes)
+        if (wrc < 0)
+          return wrc;
+      }
     }
   }
   // Is a launch of the session needed? None running (none yet, or the last one found the ring empty and left: every
@@ -1005,7 +1094,11 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   if (ps.host_store_ok && (!ps.last_caller || ps.last_caller == caller) && hipStreamQuery(caller) == hipSuccess)
   {
     __atomic_store_n(&ps.d_ring[slot], cmd, __ATOMIC_RELEASE);
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_sfence(); // (the BAR mapping may be write-combining: push the store out now)
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
     if (idle)
     {
       // (when every workgroup stands at the same count, that count and this command travel with the launch itself)
@@ -1067,6 +1160,8 @@ void free_group(WidthGroup& g)
     (void)hipFree(g.d_state);
   if (g.d_init)
     (void)hipFree(g.d_init);
+  if (g.d_scratch)
+    (void)hipFree(g.d_scratch);
   if (g.d_map)
     (void)hipFree(g.d_map);
   if (g.d_prewarm)
@@ -1132,6 +1227,22 @@ const char* nam_hip_last_error(void)
   return g_last_error.c_str();
 }
 
+int nam_hip_device_count(int* out_count)
+{
+  if (!out_count)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_device_count: null argument");
+  *out_count = 0;
+  NAM_HIP_CHECK(hipGetDeviceCount(out_count));
+  return NAM_HIP_OK;
+}
+
+int nam_hip_version_support(const char* nam_file_version)
+{
+  if (!nam_file_version)
+    return 0;
+  return guarded([&]() { return version_support(nam_file_version); });
+}
+
 const char* nam_hip_version(void)
 {
   return "nam_hip 0.1.0 gfx950";
@@ -1168,6 +1279,7 @@ int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam
     if (options)
     {
       lo.fast_tanh = options->fast_tanh != 0;
+      lo.skip_version_gate = options->version_checked_by_caller != 0;
       if (options->n_luts < 0 || (options->n_luts > 0 && !options->luts))
         throw std::runtime_error("nam_hip_model_load_ex: bad lookup-table list");
       for (int i = 0; i < options->n_luts; i++)
@@ -1194,6 +1306,125 @@ int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam
       }
     }
     return build_model(nam_path ? load_nam_file(nam_path, lo) : load_nam_text(json_text, lo), out_model);
+  });
+}
+
+int nam_hip_model_load_parts(const char* version, const char* architecture, const char* config_json, const char* metadata_json,
+                             const float* weights, int64_t n_weights, double expected_sample_rate,
+                             const nam_hip_load_options* options, nam_hip_model** out_model)
+{
+  if (!version || !architecture || !config_json || !out_model || n_weights < 0 || (n_weights > 0 && !weights))
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_load_parts: bad argument");
+  *out_model = nullptr;
+  // the document get_dsp(const nlohmann::json&) would have been given: one code path for every way in
+  std::string doc;
+  doc.reserve((size_t)n_weights * 14 + std::strlen(config_json) + 256);
+  auto quoted = [&](const char* t) {
+    doc += '"';
+    for (const char* c = t; *c; c++)
+    {
+      if (*c == '"' || *c == '\\')
+        doc += '\\';
+      doc += *c;
+    }
+    doc += '"';
+  };
+  doc += "{\"version\":";
+  quoted(version);
+  doc += ",\"architecture\":";
+  quoted(architecture);
+  doc += ",\"config\":";
+  doc += config_json;
+  if (metadata_json && metadata_json[0])
+  {
+    doc += ",\"metadata\":";
+    doc += metadata_json;
+  }
+  if (expected_sample_rate >= 0.0) // NAM_UNKNOWN_EXPECTED_SAMPLE_RATE = -1.0 (dsp.h:28): no key
+  {
+    char buf[48];
+    std::snprintf(buf, sizeof(buf), ",\"sample_rate\":%.17g", expected_sample_rate);
+    doc += buf;
+  }
+  doc += ",\"weights\":[";
+  for (int64_t i = 0; i < n_weights; i++)
+  {
+    char buf[32];
+    std::snprintf(buf, sizeof(buf), i ? ",%.9g" : "%.9g", (double)weights[i]); // 9 digits: float round trip is exact
+    doc += buf;
+  }
+  doc += "]}";
+  return nam_hip_model_load_ex(nullptr, doc.c_str(), options, out_model);
+}
+
+int64_t nam_hip_model_get_string(const nam_hip_model* model, int field, char* buf, int64_t capacity)
+{
+  if (!model || capacity < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_get_string: bad argument");
+  const ModelSpec& s = *model->spec;
+  std::string text;
+  switch (field)
+  {
+    case NAM_HIP_FIELD_VERSION: text = s.version; break;
+    case NAM_HIP_FIELD_ARCHITECTURE: text = s.architecture_name; break;
+    case NAM_HIP_FIELD_CONFIG_JSON: text = s.config_text; break;
+    case NAM_HIP_FIELD_METADATA_JSON: text = s.metadata_text; break;
+    case NAM_HIP_FIELD_DESCRIPTION:
+      for (size_t i = 0; i < model->plans.size(); i++)
+      {
+        const Plan& p = model->plans[i];
+        text += (i ? " | plan " : "plan ") + std::to_string(i) + ": " + p.describe();
+        if (p.arch == ARCH_WAVENET)
+          text += std::string(" a1_valu=") + (p.a1.valid ? "1" : "0") + " a1_mfma=" + ((p.a1.valid && p.a1.ws_ok) ? "1" : "0")
+                  + " kt_mfma=" + ((p.a1.valid && p.a1.kt_ok) ? "1" : "0") + " a1_il=" + ((p.a1.valid && p.a1.il_ok) ? "1" : "0")
+                  + " a1_p2=" + ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? "1" : "0")
+                  + (p.wr.ok ? std::string(" wn_reg=1") : " wn_reg=0 (" + p.wr.why + ")");
+      }
+      break;
+    default: return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_get_string: unknown field");
+  }
+  if (buf && capacity > 0)
+  {
+    const size_t n = std::min((size_t)capacity - 1, text.size());
+    std::memcpy(buf, text.data(), n);
+    buf[n] = 0;
+  }
+  return (int64_t)text.size();
+}
+
+int64_t nam_hip_model_get_weights(const nam_hip_model* model, float* out, int64_t capacity)
+{
+  if (!model || capacity < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_get_weights: bad argument");
+  const ModelSpec& s = *model->spec;
+  const std::vector<float>* w = s.arch == ARCH_WAVENET ? &s.wavenet.weights : s.arch == ARCH_LSTM ? &s.lstm.weights : nullptr;
+  const int64_t n = w ? (int64_t)w->size() : 0;
+  if (out && w)
+    std::memcpy(out, w->data(), (size_t)std::min(n, capacity) * sizeof(float));
+  return n;
+}
+
+int nam_hip_sample_rate_from_nam(const char* nam_path, const char* json_text, double* out_sample_rate)
+{
+  if ((!nam_path) == (!json_text) || !out_sample_rate)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_sample_rate_from_nam: pass exactly one of nam_path / json_text, and out_sample_rate");
+  return guarded([&]() {
+    std::string text;
+    if (nam_path)
+    {
+      FILE* f = std::fopen(nam_path, "rb");
+      if (!f)
+        throw FileValidationError(std::string("Could not validate .nam file [") + nam_path + "]: file does not exist.");
+      char chunk[65536];
+      size_t n;
+      while ((n = std::fread(chunk, 1, sizeof(chunk), f)) > 0)
+        text.append(chunk, n);
+      std::fclose(f);
+    }
+    else
+      text = json_text;
+    *out_sample_rate = sample_rate_from_nam_text(text);
+    return NAM_HIP_OK;
   });
 }
 
@@ -1612,6 +1843,7 @@ int nam_hip_batch_set_kernel(nam_hip_batch* batch, int kernel)
 {
   if (!batch || kernel < NAM_HIP_KERNEL_AUTO || kernel > NAM_HIP_KERNEL_WN_REG)
     return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_set_kernel: bad argument");
+  NAM_HIP_CHECK(hipSetDevice(batch->device)); // (ending a session may relaunch: the launchers configure the current device)
   if (batch->ps.active)
   {
     const int rc = persist_stop(batch);
@@ -1703,6 +1935,11 @@ int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* 
 
 const char* nam_hip_batch_kernel_name(const nam_hip_batch* batch)
 {
+  return nam_hip_batch_kernel_name_for(batch, kBlock);
+}
+
+const char* nam_hip_batch_kernel_name_for(const nam_hip_batch* batch, int n_frames)
+{
   if (!batch)
     return "";
   // the group with the most streams (a uniform batch has exactly one populated group)
@@ -1710,7 +1947,7 @@ const char* nam_hip_batch_kernel_name(const nam_hip_batch* batch)
   for (const auto& g : batch->groups)
     if (g.streams.size() > best->streams.size())
       best = &g;
-  return group_kernel_name(batch, *best);
+  return group_kernel_name(batch, *best, n_frames > 0 ? n_frames : kBlock);
 }
 
 int nam_hip_batch_n_streams(const nam_hip_batch* batch)

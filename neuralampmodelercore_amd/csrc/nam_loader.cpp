@@ -706,12 +706,17 @@ static void check_wavenet_weights(const WaveNetSpec& wc)
   }
 }
 
-static std::shared_ptr<ModelSpec> build_model(const Value& root, const LoadOptions& lo)
+static std::shared_ptr<ModelSpec> build_model(const Value& root, const LoadOptions& lo_outer)
 {
+  // (the caller's own version gate covered this document only: nested documents — a condition_dsp, a container's
+  // submodels — go through the built-in gate)
+  LoadOptions lo = lo_outer;
+  lo.skip_version_gate = false;
   auto m = std::make_shared<ModelSpec>();
   m->fast_tanh = lo.fast_tanh;
   m->version = root.at("version").as_string();
-  verify_config_version(m->version);
+  if (!lo_outer.skip_version_gate)
+    verify_config_version(m->version);
   const Value* w = root.find("weights");
   if (!w)
     throw std::runtime_error("Corrupted model file is missing weights.");
@@ -721,6 +726,10 @@ static std::shared_ptr<ModelSpec> build_model(const Value& root, const LoadOptio
     weights.push_back((float)x.as_double());
   const std::string arch = root.at("architecture").as_string();
   const Value& config = root.at("config");
+  m->architecture_name = arch;
+  m->config_text = json::dump(config);
+  if (const Value* mdv = root.find("metadata"))
+    m->metadata_text = json::dump(*mdv);
   m->sample_rate = root.contains("sample_rate") ? root.at("sample_rate").as_double() : -1.0;
 
   const Value* md = root.find("metadata");
@@ -802,6 +811,14 @@ std::shared_ptr<ModelSpec> load_nam_text(const std::string& text, const LoadOpti
   if (!root.is_object())
     throw std::runtime_error("Invalid .nam JSON: root value must be an object.");
   return build_model(root, lo);
+}
+
+double sample_rate_from_nam_text(const std::string& text)
+{
+  Value root = json::parse(text);
+  if (root.is_object() && root.contains("sample_rate"))
+    return root.at("sample_rate").as_double();
+  return -1.0;
 }
 
 std::shared_ptr<ModelSpec> load_nam_file(const std::string& path, const LoadOptions& lo)

@@ -52,6 +52,7 @@ def lib(a2_fast: bool = False):
         L.ref_set_slimmable.argtypes = [vp, cd]
         L.ref_reset.restype = ci
         L.ref_reset.argtypes = [vp, cd, ci]
+        L.ref_last_error.restype = ctypes.c_char_p
         L.ref_process.restype = ci
         L.ref_process.argtypes = [vp, vp, vp, ctypes.c_long, ci]
         _L[a2_fast] = L
@@ -98,7 +99,7 @@ class RefDSP:
 
     def Reset(self, sample_rate: float, max_buffer_size: int):
         if self._L.ref_reset(self._h, float(sample_rate), int(max_buffer_size)) != 0:
-            raise RuntimeError("Reset failed")
+            raise RuntimeError("Reset failed: " + (self._L.ref_last_error() or b"").decode(errors="replace"))
         self.max_buffer_size = int(max_buffer_size)
 
     def process_stream(self, x: np.ndarray, block: int) -> np.ndarray:

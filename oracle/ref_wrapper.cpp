@@ -30,6 +30,7 @@ void apply_mode(const Handle* h)
   else
     nam::activations::Activation::disable_fast_tanh();
 }
+thread_local std::string g_last; // what the last failing ref_reset / ref_process threw (ref_last_error)
 void set_err(char* err, int n, const std::string& s)
 {
   if (err && n > 0)
@@ -137,10 +138,20 @@ int ref_reset(void* p, double sample_rate, int max_buffer)
       h->outp[c] = h->out[c].data();
     return 0;
   }
-  catch (...)
+  catch (const std::exception& e)
   {
+    g_last = e.what();
     return -1;
   }
+  catch (...)
+  {
+    g_last = "unknown exception";
+    return -1;
+  }
+}
+const char* ref_last_error(void)
+{
+  return g_last.c_str();
 }
 // in: planar float32 [in_channels][n_frames], out: [out_channels][n_frames]; fed in `block`-frame process() calls
 int ref_process(void* p, const float* in, float* out, long n_frames, int block)

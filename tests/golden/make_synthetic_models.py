@@ -137,6 +137,256 @@ GENERAL = {
 }
 
 
+# ---- feature-rich WaveNets: gating / blending / FiLM / grouped convs / head1x1 / bottleneck / nested condition_dsp ----
+# Schema: NAM/wavenet/model.cpp:913-1276 (parse_config_json); weight order per layer NAM/wavenet/model.cpp:152-181:
+# conv (+bias), input_mixin, layer1x1 (+bias)?, head1x1 (+bias)?, then the eight FiLMs in the fixed order conv_pre,
+# conv_post, input_mixin_pre, input_mixin_post, activation_pre, activation_post, layer1x1_post, head1x1_post — each a
+# Conv1x1(condition -> (shift ? 2 : 1) * D, bias, groups) (NAM/film.h:28-32). The cases follow the reference's own
+# feature tests: tools/test/test_wavenet_configurable_gating.cpp:86-264 (per-layer gating modes, secondary
+# activations), test_film.cpp:26-480 (scale only / scale + shift, groups), test_wavenet/test_head1x1.cpp,
+# test_wavenet/test_condition_processing.cpp (condition_dsp), test_wavenet_gating_compatibility.cpp (legacy "gated").
+FILM_KEYS = ["conv_pre_film", "conv_post_film", "input_mixin_pre_film", "input_mixin_post_film", "activation_pre_film",
+             "activation_post_film", "layer1x1_post_film", "head1x1_post_film"]
+
+
+def _divisors(*ns):
+    g = int(np.gcd.reduce([int(n) for n in ns]))
+    return [d for d in range(1, g + 1) if g % d == 0]
+
+
+def _random_activation(rng, rows, allow_prelu=True):
+    """An activation in one of the JSON forms ActivationConfig::from_json accepts (activations.cpp:59-130).
+    PReLU slopes: one per row of the matrix the activation sees (`rows`), or a single slope."""
+    names = ["Tanh", "ReLU", "Sigmoid", "Hardtanh", "SiLU", "Softsign", "Hardswish", "LeakyReLU", "LeakyHardtanh", "Fasttanh"]
+    if allow_prelu:
+        names.append("PReLU")
+    t = names[int(rng.integers(len(names)))]
+    if t == "LeakyReLU":
+        return dict(type="LeakyReLU", negative_slope=round(float(rng.uniform(0.005, 0.3)), 4)) if rng.integers(2) else "LeakyReLU"
+    if t == "LeakyHardtanh":
+        if rng.integers(3) == 0:
+            return "LeakyHardtanh"
+        return dict(type="LeakyHardtanh", min_val=round(float(rng.uniform(-0.9, -0.1)), 3), max_val=round(float(rng.uniform(0.1, 0.9)), 3),
+                    min_slope=round(float(rng.uniform(0.0, 0.1)), 3), max_slope=round(float(rng.uniform(0.0, 0.1)), 3))
+    if t == "PReLU":
+        if rows == 1 and rng.integers(2):  # (one slope for several rows trips the reference's channel-count check, activations.h:300-307)
+            return dict(type="PReLU", negative_slope=round(float(rng.uniform(0.01, 0.3)), 3))
+        return dict(type="PReLU", negative_slopes=[round(float(v), 3) for v in rng.uniform(0.01, 0.3, rows)])
+    return dict(type=t) if rng.integers(2) else t
+
+
+def random_featured_array(rng, input_size, condition_size, head_size=None, shape=None, max_dilation=40, later=False):
+    """One layer array with random features. `shape` pins (channels, bottleneck, kernel_size, head1x1 out or 0, gated?) —
+    the dimensions nam_wn_reg_kernel instantiates (plan.h: WR_LAYER_SHAPES) — and leaves FiLM sets, activations, groups,
+    dilations and the gating flavour random; None draws everything. Returns the JSON layer-array config."""
+    n_layers = int(rng.integers(1, 5))
+    if shape is not None:
+        C, B, K, HO, gated = shape
+        kernel_sizes = [K] * n_layers
+    else:
+        C = int(rng.integers(1, 9))
+        B = C if rng.integers(3) else int(rng.integers(1, 9))
+        kernel_sizes = [int(rng.choice([1, 2, 2, 3, 3, 3, 4, 5]))] * n_layers if rng.integers(3) else [int(rng.integers(1, 6)) for _ in range(n_layers)]
+        HO = int(rng.integers(1, 9)) if rng.integers(2) else 0
+        gated = None
+        if later:
+            # a later array's head accumulator starts as the previous array's head output, whose size must equal this
+            # array's channels (model.cpp:476-484, 643-649): head1x1 -> C outputs, or no head1x1 and bottleneck = C
+            if HO or B != C:
+                HO = C
+    dil = [int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 13, 16, max_dilation])) for _ in range(n_layers)]
+    if gated is None:
+        form = int(rng.integers(5))
+        modes = (["none"] * n_layers if form == 0 else ["gated"] * n_layers if form == 1 else ["blended"] * n_layers if form == 2
+                 else [str(rng.choice(["none", "gated", "blended"])) for _ in range(n_layers)])
+    else:
+        modes = [str(rng.choice(["gated", "blended"])) for _ in range(n_layers)] if gated else ["none"] * n_layers
+    a = dict(input_size=input_size, condition_size=condition_size, channels=C, dilations=dil)
+    if B != C or rng.integers(2):
+        a["bottleneck"] = B
+    if len(set(kernel_sizes)) == 1 and rng.integers(2):
+        a["kernel_size"] = kernel_sizes[0]
+    else:
+        a["kernel_sizes"] = kernel_sizes
+    # the activation sees 2B rows through GatingActivation's per-frame apply on the top B, B rows otherwise: B slopes
+    a["activation"] = ([_random_activation(rng, B) for _ in range(n_layers)] if rng.integers(2) else _random_activation(rng, B))
+    if all(m == "none" for m in modes) and rng.integers(3) == 0:
+        a["gated"] = False  # legacy spelling (model.cpp:1164)
+    elif all(m == "gated" for m in modes) and rng.integers(3) == 0:
+        a["gated"] = True  # legacy: secondary activation Sigmoid
+    else:
+        a["gating_mode"] = modes[0] if len(set(modes)) == 1 and rng.integers(2) else modes
+        if any(m != "none" for m in modes):
+            # (a single gating_mode string takes a single secondary activation: model.cpp:1140-1160)
+            k = int(rng.integers(3)) if isinstance(a["gating_mode"], list) else int(rng.integers(1, 3))
+            if k == 0:
+                a["secondary_activation"] = [_random_activation(rng, B, allow_prelu=False) for _ in range(n_layers)]
+            elif k == 1:
+                a["secondary_activation"] = _random_activation(rng, B, allow_prelu=False)
+            # else: absent -> Sigmoid (model.cpp:1111-1113)
+    # groups: must divide both sides of every layer's matrix (zc = B or 2B depending on the layer's gating mode)
+    a["groups_input"] = int(rng.choice(_divisors(C, B)))
+    a["groups_input_mixin"] = int(rng.choice(_divisors(condition_size, B)))
+    l1_active = True if B != C else bool(rng.integers(4))
+    a["layer1x1"] = dict(active=l1_active, groups=int(rng.choice(_divisors(B, C))))
+    if HO:
+        a["head1x1"] = dict(active=True, out_channels=HO, groups=int(rng.choice(_divisors(B, HO))))
+    elif rng.integers(2):
+        a["head1x1"] = dict(active=False, out_channels=C, groups=1)
+    film_dims = dict(zip(FILM_KEYS, [C, None, condition_size, None, None, B, C, HO]))
+    p_film = float(rng.choice([0.0, 0.3, 0.6, 1.0]))
+    for key in FILM_KEYS:
+        if key == "layer1x1_post_film" and not l1_active:
+            continue
+        if key == "head1x1_post_film" and not HO:
+            continue
+        if rng.uniform() >= p_film:
+            if rng.integers(4) == 0:
+                a[key] = False if rng.integers(2) else dict(active=False, shift=True, groups=1)
+            continue
+        shift = bool(rng.integers(2))
+        D = film_dims[key]
+        # zc-wide FiLMs see B or 2B rows depending on the layer: a group count that divides B divides both
+        g = int(rng.choice(_divisors(condition_size, (2 if shift else 1) * (D if D is not None else B))))
+        f = dict(active=True, shift=shift, groups=g)
+        if rng.integers(4) == 0 and shift and g == 1:
+            f = dict()  # every default (model.cpp:1232-1236)
+        a[key] = f
+    hs = head_size if head_size is not None else int(rng.integers(1, 5))
+    if rng.integers(2):
+        a["head_size"] = hs
+        a["head_bias"] = bool(rng.integers(2))
+    else:
+        a["head"] = dict(out_channels=hs, kernel_size=int(rng.choice([1, 1, 2, 3])), bias=bool(rng.integers(2)))
+        if rng.integers(3) == 0:
+            a["head"]["head_dilation"] = int(rng.choice([1, 2, 3]))
+    return a
+
+
+def _arr_dims(a):
+    C = a["channels"]
+    B = a.get("bottleneck", C)
+    n = len(a["dilations"])
+    ks = a["kernel_sizes"] if "kernel_sizes" in a else [a["kernel_size"]] * n
+    if "gating_mode" in a:
+        modes = a["gating_mode"] if isinstance(a["gating_mode"], list) else [a["gating_mode"]] * n
+    else:
+        modes = ["gated" if a.get("gated", False) else "none"] * n
+    h1 = a.get("head1x1", dict(active=False))
+    HO = h1["out_channels"] if h1.get("active") else 0
+    l1 = a.get("layer1x1", dict(active=True, groups=1))
+    if "head" in a:
+        hs, hk, hb = a["head"]["out_channels"], a["head"]["kernel_size"], a["head"]["bias"]
+    else:
+        hs, hk, hb = a["head_size"], 1, a["head_bias"]
+    return C, B, n, ks, modes, h1, HO, l1, hs, hk, hb
+
+
+def head_input_size(a):
+    """Rows of the array's head accumulator: head1x1.out_channels if active, else the bottleneck (model.cpp:397-401)."""
+    C, B, n, ks, modes, h1, HO, l1, hs, hk, hb = _arr_dims(a)
+    return HO if HO else B
+
+
+def featured_weight_count(arrays, post_head=None):
+    """Length of the flat weight stream the reference consumes for these layer arrays (+ post-stack head + head_scale)."""
+    total = 0
+    for a in arrays:
+        C, B, n, ks, modes, h1, HO, l1, hs, hk, hb = _arr_dims(a)
+        cond = a["condition_size"]
+        total += C * a["input_size"]
+        for i in range(n):
+            zc = B if modes[i] == "none" else 2 * B
+            total += C * zc // a.get("groups_input", 1) * ks[i] + zc
+            total += cond * zc // a.get("groups_input_mixin", 1)
+            if l1["active"]:
+                total += B * C // l1["groups"] + C
+            if HO:
+                total += B * HO // h1["groups"] + HO
+            dims = [C, zc, cond, zc, zc, B, C, HO]
+            for key, D in zip(FILM_KEYS, dims):
+                f = a.get(key, False)
+                if f is False or not f.get("active", True):
+                    continue
+                m = 2 if f.get("shift", True) else 1
+                total += cond * m * D // f.get("groups", 1) + m * D
+        total += (HO if HO else B) * hs * hk + (hs if hb else 0)
+    if post_head is not None:
+        cin = _arr_dims(arrays[-1])[8]
+        for i, k in enumerate(post_head["kernel_sizes"]):
+            cout = post_head["out_channels"] if i + 1 == len(post_head["kernel_sizes"]) else post_head["channels"]
+            total += cout * cin * k + cout
+            cin = cout
+    return total + 1
+
+
+# (channels, bottleneck, kernel, head1x1 outputs, gated) by condition size: the layer dimensions kernel_wn_reg.hip
+# instantiates with run-time FiLM / activation flags (plan.h: WR_LAYER_SHAPES ids 5..14, 18)
+WR_DIMS = {8: [(4, 4, 4, 4, False)], 1: [(3, 6, 2, 6, True), (4, 2, 3, 4, True), (4, 4, 3, 0, False), (3, 3, 3, 0, False),
+                                          (2, 2, 3, 0, False), (8, 8, 3, 0, False), (1, 1, 3, 0, False)],
+           3: [(3, 3, 3, 0, False), (4, 4, 3, 0, False), (2, 2, 3, 0, False)]}
+
+
+def random_featured(rng, wr_shapes=False, allow_condition_dsp=True, in_channels=1, out_size=None, depth=0):
+    """A whole feature-rich WaveNet .nam (dict). wr_shapes: layer dimensions from WR_DIMS (what nam_wn_reg_kernel
+    instantiates); otherwise free dimensions (the op interpreter). A nested condition_dsp (model.cpp:919-922: its own
+    weights inside its JSON) with probability 1/2 at depth 0."""
+    cond_dsp = None
+    cond = in_channels
+    if allow_condition_dsp and depth == 0 and rng.integers(2):
+        want = 8 if (wr_shapes and rng.integers(2)) else (int(rng.choice([1, 3])) if wr_shapes else int(rng.integers(1, 7)))
+        cond_dsp = random_featured(rng, wr_shapes=wr_shapes, allow_condition_dsp=False, in_channels=in_channels, out_size=want, depth=1)
+        cond = want
+    elif wr_shapes and in_channels == 1 and depth == 0 and rng.integers(4) == 0:
+        in_channels = cond = 3  # multi-channel input: condition = the input channels
+    n_arr = int(rng.integers(1, 3)) if depth else int(rng.integers(1, 4))
+    shapes = None
+    if wr_shapes:
+        pool = WR_DIMS.get(cond)
+        if pool is None:
+            raise ValueError(f"no instantiated shapes for condition size {cond}")
+        later = [sh for sh in pool if (sh[3] == sh[0] if sh[3] else sh[1] == sh[0])]  # usable behind another array
+        shapes = [(pool if i == 0 else later)[int(rng.integers(len(pool if i == 0 else later)))] for i in range(n_arr)]
+    arrays = []
+    for i in range(n_arr):
+        arrays.append(random_featured_array(rng, in_channels if i == 0 else arrays[-1]["channels"], cond,
+                                            shape=shapes[i] if shapes else None, later=i > 0))
+    # chain the head sizes: array i's head output seeds array i+1's head accumulator (model.cpp:476-484) and must be
+    # as wide as array i+1's channels (:643-649)
+    for i in range(n_arr):
+        hs = arrays[i + 1]["channels"] if i + 1 < n_arr else (out_size if out_size is not None else int(rng.choice([1, 1, 1, 2])))
+        if "head" in arrays[i]:
+            arrays[i]["head"]["out_channels"] = hs
+        else:
+            arrays[i]["head_size"] = hs
+    n_w = featured_weight_count(arrays)
+    scale = float(rng.choice([0.02, 0.1, 0.5]))
+    w = (rng.standard_normal(n_w).astype(np.float32) * np.float32(0.35)).tolist()
+    w[-1] = scale  # head_scale comes from the last weight (model.cpp:670)
+    config = dict(layers=arrays, head=None, head_scale=scale)
+    if in_channels != 1:
+        config["in_channels"] = in_channels
+    if cond_dsp is not None:
+        config["condition_dsp"] = cond_dsp
+    return dict(version="0.6.0", architecture="WaveNet", config=config,
+                metadata=dict(name="featured fuzz model", note="synthetic test fixture (seeded random weights)"), weights=w,
+                sample_rate=48000)
+
+
+def write_featured(path, seed, wr_shapes=False):
+    """Seeded feature-rich model -> `path`; returns the model dict."""
+    rng = np.random.default_rng(seed)
+    while True:
+        try:
+            m = random_featured(rng, wr_shapes=wr_shapes)
+            break
+        except ValueError:
+            continue
+    with open(path, "w") as f:
+        json.dump(m, f)
+    return m
+
+
 def build_lstm(name, num_layers, input_size, hidden, out_channels, seed):
     """LSTM weight stream (lstm.cpp:9-29, 70-101): per layer W [4H][I+H] row-major, b [4H], h0 [H], c0 [H];
     then head W [out][H], b [out]."""

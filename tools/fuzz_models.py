@@ -1,7 +1,11 @@
 """Developer tool: random A1-family models (seeded) through every kernel that can run them, against the oracle.
 Single-array models with random per-layer kernel sizes / dilations / head taps reach the K-tap MFMA kernel;
 multi-array kernel-size-3 models reach the wave-specialised one; narrow ones (1 .. 4 channels, odd dilations up to 700)
-the register-resident kernel's LDS rings, plain-layer runs and run-time-flag layers. Usage: python tools/fuzz_models.py [n] [seed]"""
+the register-resident kernel's LDS rings, plain-layer runs and run-time-flag layers; every fourth model is FEATURE-RICH
+(make_synthetic_models.random_featured: per-layer gating / blending, FiLM subsets with and without shift, grouped input /
+mixin / 1x1 / head1x1, bottleneck != channels, a nested condition_dsp, PReLU / LeakyHardtanh / Hardswish secondaries —
+alternately with free dimensions (op interpreter) and with the dimensions nam_wn_reg_kernel instantiates).
+Usage: python tools/fuzz_models.py [n] [seed]"""
 import json, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,19 +71,31 @@ def random_narrow(rng, tmp, idx):
     return os.path.join(tmp, "models", name + ".nam"), dict(arrays=arrays)
 
 
+def random_featured(rng, tmp, idx):
+    """Feature-rich WaveNet (schema NAM/wavenet/model.cpp:913-1276): see make_synthetic_models.random_featured."""
+    os.makedirs(os.path.join(tmp, "models"), exist_ok=True)
+    path = os.path.join(tmp, "models", f"fuzz_ft_{idx}.nam")
+    wr = bool((idx // 4) % 2)
+    msm.write_featured(path, int(rng.integers(1 << 30)), wr_shapes=wr)
+    return path, dict(featured=True, wr_shapes=wr)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(n):
-            path, spec = (random_multi, random_ktap, random_narrow)[i % 3](rng, tmp, i)
+            path, spec = (random_multi, random_ktap, random_narrow, random_featured)[i % 4](rng, tmp, i)
             ft = bool(rng.integers(2))
             model = nam.get_dsp(path, fast_tanh=ft)
             bits = model.info.has_a1_kernel
             n_streams, block = 3, 64
             T = 64 * int(rng.integers(3, 7)) + int(rng.integers(0, 64))
             x = stream_bank(n_streams, T, seed=i)
+            ic = model.NumInputChannels()
+            if ic > 1:  # every input channel carries the stream's signal, scaled differently
+                x = np.ascontiguousarray(np.stack([x * (1.0 - 0.3 * c) for c in range(ic)], axis=1))
             ref = nam_oracle.get_dsp(path, fast_tanh=ft)
             ref.Reset(48000.0, block)
             r = ref.process_stream(x[1], block)
