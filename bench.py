@@ -43,6 +43,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SR = 48000.0
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 vector == FP32 (f32-in) MFMA
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_ACHIEVABLE_GBS = 6300.0
+LDS_PEAK_TBS = 150.0  # MI355X_MICROARCH.md, LDS: ~150 TB/s for ds_read_b64/b128 with every CU streaming at ~2.4 GHz
+LDS_CLOCK_HZ = 2.4e9
 
 
 def wavenet_history_bytes_per_sample(cfg: dict) -> int:
@@ -136,7 +139,7 @@ def model_macs(path: str) -> int:
     return sum(4 * H * ((I if l == 0 else H) + H) for l in range(L)) + H * c.get("out_channels", 1)
 
 
-def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: float = 12.0):
+def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: float = 12.0, extras: bool = True):
     """CPU oracle ("port": our Eigen-free restatement of the reference path; the reference's own
     Eigen binary cannot be built here) on ONE host core, benchmodel protocol (64-frame blocks,
     Reset + prewarm first), on a bounded sample of the same workload."""
@@ -171,6 +174,24 @@ def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: f
         "sample": f"1 stream x {secs_audio:.1f} s of two-tone audio in {block}-frame blocks after Reset+prewarm, "
                   f"oracle/nam_oracle.c built {kind_flags}, {dt:.2f} s of CPU",
     }
+    # BASELINE.md section 3's PRIMARY figure is the -O2 build ("g++ -O2 -march=native, and separately -Ofast")
+    try:
+        o2_so = os.path.join("/tmp", f"libnam_oracle_o2_{os.getpid()}.so")
+        nam_oracle.build_fast(o2_so, "-O2")
+        nam_oracle.use_library(o2_so)
+        m2 = nam_oracle.get_dsp(model_path, fast_tanh=fast_tanh)
+        m2.Reset(SR, block)
+        x2 = x[:max(int(SR), int(len(x) * min(1.0, (target_seconds / 3.0) / max(dt, 1e-6))))]
+        t0 = time.perf_counter()
+        m2.process_stream(x2, block)
+        dt2 = time.perf_counter() - t0
+        out["O2"] = {"value": round(len(x2) / SR / dt2, 3), "cores": 1,
+                     "note": f"same port built -O2 -march=native (BASELINE.md section 3 primary), {len(x2) / SR:.1f} s of audio, {dt2:.2f} s of CPU"}
+        os.remove(o2_so)
+    except Exception as e:
+        out["O2"] = {"error": str(e)[:200]}
+    if not extras:
+        return out
     # alongside: every host core at once (SURVEY 8d asks for the multi-core figure next to the single-thread one):
     # one worker process per core, one stream each, same protocol; the aggregate is what the host could sustain
     try:
@@ -238,6 +259,35 @@ def cpu_worker(argv):
     t0 = time.perf_counter()
     m.process_stream(x, block)
     print(len(x) / SR / (time.perf_counter() - t0), flush=True)
+
+
+def run_other_configs(args):
+    """Brief runs of BASELINE.json configs 3, 4, 5 for the default line (`other_configs`): one subprocess each (a failure
+    of one cannot take the headline with it), `--brief`: 500 timed steps x 11 regions, no side runs, ~2 s CPU baseline."""
+    import subprocess
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "max_abs_err_vs_oracle", "cpu_baseline",
+            "finite", "region_us")
+    res = {}
+    for c in (3, 4, 5):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--gpus", "1", "--steps", "500", "--warmup", "50",
+               "--brief", "--persistent", str(args.persistent), "--fast-tanh", str(args.fast_tanh)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                res[str(c)] = {"error": (p.stderr or p.stdout)[-400:], "rc": p.returncode}
+                continue
+            j = json.loads(line[-1])
+            r = {k: j.get(k) for k in keep}
+            r["workload"] = CONFIGS[c]["name"]
+            r["run_s"] = round(time.perf_counter() - t0, 1)
+            res[str(c)] = r
+        except Exception as e:  # noqa: BLE001
+            res[str(c)] = {"error": str(e)[:400]}
+    return res
 
 
 class HipEngine:
@@ -368,7 +418,14 @@ def main():
                     help="run the distributed branch (RCCL process group, model broadcast, scatter / gather, barriers, all_reduce) even "
                          "with WORLD_SIZE=1: the only way to execute it on a one-GPU box (tests/test_gpu_parity.py)")
     ap.add_argument("--dry-run", action="store_true", help="CPU tensors + gloo + a stub instead of the kernels (plumbing test)")
+    ap.add_argument("--brief", action="store_true",
+                    help="a short run for the `other_configs` block of the default invocation: no latency pass / side runs / "
+                         "resident comparison, a ~2 s CPU baseline")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default invocation (config 2, one GPU): do not append brief runs of configs 3, 4 and 5")
     args = ap.parse_args()
+    if args.brief:
+        args.no_side_runs = True
     cfg = CONFIGS[args.config]
     model_name = args.model or cfg["model"]
     n_streams = args.streams or cfg["streams"]
@@ -510,7 +567,7 @@ def main():
     # alongside (not `value`): the same K blocks as ONE resident launch — the offline re-amp shape, no per-block kernel
     # boundary — timed the same way
     other = None
-    if args.launch == "block":
+    if args.launch == "block" and not args.brief:
         fence(engine)
         t1 = time.perf_counter()
         engine.run_steps(W, K, "resident")
@@ -612,13 +669,27 @@ def main():
         kname = engine.kernel_name()
         tr = measured_traffic(kname, model_name, n_streams, block, args.launch)
         lds = None
-        if tr and tr.get("lds_idx_active_cycles") is not None and tr.get("kernel_cycles"):
-            # SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones (MI355X_MICROARCH.md, LDS);
-            # peak = every CU's LDS array busy for the whole kernel
-            busy = tr["lds_idx_active_cycles"] / (256.0 * tr["kernel_cycles"])
-            lds = {"achieved": round(busy, 4), "peak": 1.0, "unit": "fraction of LDS-array cycles busy (SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles))",
-                   "frac": round(busy, 4), "bank_conflict_frac_of_active": round(tr.get("lds_bank_conflict_cycles", 0) / max(tr["lds_idx_active_cycles"], 1), 4),
-                   "note": tr.get("lds_note", "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT, per launch")}
+        if tr and tr.get("lds_idx_active_cycles") is not None and tr.get("rocprof_avg_launch_us"):
+            # SQ_LDS_IDX_ACTIVE = all LDS-array cycles of the dispatch, summed over the CUs; SQ_LDS_BANK_CONFLICT = the extra
+            # ones (MI355X_MICROARCH.md, LDS). Normalised by the PROFILED dispatch's own duration x the 2.4 GHz clock x 256
+            # CUs (GRBM_GUI_ACTIVE is summed over the XCDs and is not a per-CU cycle count: round 2 divided by it and
+            # printed a figure ten times too small). An LDS-array cycle moves at most 256 B, so the same counter bounds
+            # the bytes per second: against the guide's ~150 TB/s for wide ds_reads chip-wide.
+            cycles_avail = 256.0 * tr["rocprof_avg_launch_us"] * 1e-6 * LDS_CLOCK_HZ
+            busy = tr["lds_idx_active_cycles"] / cycles_avail
+            tbs = tr["lds_idx_active_cycles"] * 256.0 / (tr["rocprof_avg_launch_us"] * 1e-6) / 1e12
+            lds = {"achieved": round(tbs, 2), "peak": LDS_PEAK_TBS, "unit": "TB/s (upper bound: LDS-array cycles x 256 B per profiled dispatch)",
+                   "frac": round(tbs / LDS_PEAK_TBS, 4),
+                   "array_busy_frac": round(busy, 4),
+                   "bank_conflict_frac_of_active": round(tr.get("lds_bank_conflict_cycles", 0) / max(tr["lds_idx_active_cycles"], 1), 4),
+                   "note": tr.get("lds_note", "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT, per launch")
+                           + f"; normalised by the profiled dispatch ({tr['rocprof_avg_launch_us']} us) x 2.4 GHz x 256 CUs"}
+        # fractions against the WALL ms_per_step the line reports (round 2 divided by the host-visible time next to it)
+        wall_launch_s = wall_med / launches
+        contract_gbs_wall = bytes_per_sample * samples_per_launch / wall_launch_s / 1e9
+        traffic_b = tr["hbm_bytes_per_launch"] if tr else None
+        counter_frac = None if traffic_b is None else round(traffic_b / wall_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+        floor_us = None if traffic_b is None else round(max(traffic_b / (HBM_ACHIEVABLE_GBS * 1e9), flops_per_launch / (FP32_PEAK_TFLOPS * 1e12)) * 1e6, 3)
         out = {
             "metric": f"real-time audio streams (xRT) at 48 kHz, {model_name}",
             "value": round(xrt, 1),
@@ -654,10 +725,16 @@ def main():
             # The WaveNet path is bound by history traffic through HBM / Infinity Cache (the per-stream state cannot stay
             # in LDS): e.g. a1_standard 8 TB/s / 3,848 B / 48 kHz = 43 k xRT, below its fp32 ceiling of 123 k xRT.
             "roofline": {
-                "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "bound": "hbm", "achieved": round(contract_gbs_wall, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(contract_gbs_wall / HBM_PEAK_GBS, 4),
+                "frac_basis": "algorithmic (contract) bytes per step / the wall ms_per_step of this line",
+                "kernel_time_frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                 "kernel": kname,
-                "traffic": (tr["hbm_bytes_per_launch"] if tr else None),
+                "traffic": traffic_b,
+                "counter_frac": counter_frac,
+                "floor_us": floor_us,
+                "floor_note": "max(traffic / 6.3 TB/s achievable, algorithmic flops / 157.3 TFLOP/s): the physical lower bound "
+                              "of one step; counter_frac = PMC traffic / wall time per step / 8 TB/s",
                 "traffic_note": (tr["note"] if tr else "no PMC pass committed for this exact kernel / model / launch shape"),
                 "note": f"algorithmic {bytes_per_sample} B/stream-sample ({hist} history + {4 * (ic + oc)} I/O) x "
                         f"{samples_per_launch} stream-samples per launch; avg launch {avg_launch_s * 1e6:.2f} us "
@@ -681,9 +758,23 @@ def main():
         if args.dry_run:
             out["data"] = "dry-run (stub compute on CPU tensors over gloo): plumbing only, not a measurement"
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
-            out["cpu_baseline"] = cpu_baseline(model_path, bool(args.fast_tanh), block)
+            out["cpu_baseline"] = cpu_baseline(model_path, bool(args.fast_tanh), block, target_seconds=2.0 if args.brief else 12.0,
+                                               extras=not args.brief)
+    # the default invocation (what the driver runs: config 2, one GPU) also carries BRIEF runs of configs 3, 4 and 5 — each
+    # its own process with the same protocol (persistent block mode, median of the regions, roofline, parity against the
+    # oracle, a ~2 s CPU baseline) — so that one driver-timed line holds every BASELINE.json configuration a GPU can run
+    if (rank == 0 and world == 1 and not distributed and args.config == 2 and args.model is None and args.streams is None
+            and not args.brief and not args.no_other_configs and not args.dry_run):
+        engine.close()
+        engine = None
+        if scratch is not None:
+            scratch.close()
+            scratch = None
+        out["other_configs"] = run_other_configs(args)
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    engine.close()
+    if engine is not None:
+        engine.close()
     if scratch is not None:
         scratch.close()
     if distributed:

@@ -178,6 +178,7 @@ struct nam_hip_batch
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
+  bool no_p3 = false; // developer switch (NAM_HIP_NO_P3=1): nam_a1_p2_kernel where nam_a1_p3_kernel would run (A/B runs)
   PersistSession ps;
   bool ps_launching = false; // launch_group is starting the session's resident launch
   int n_cus = 0; // compute units of the device
@@ -323,6 +324,13 @@ inline bool persist_eligible(const nam_hip_batch* b)
 }
 
 int kernel_for_launch(const nam_hip_batch* b, const WidthGroup& g, int n_frames);
+// nam_a1_p3_kernel (the official topology as two pipelined wave sets) instead of nam_a1_p2_kernel: whenever a launch
+// holds more than one buffer — a persistent session, an offline render, a prewarm. A launch of one block has nothing
+// to overlap (array 1 waits for array 0) and keeps the four-wave kernel.
+inline bool use_p3(const nam_hip_batch* b, int n_frames)
+{
+  return !b->no_p3 && (b->ps_launching || n_frames > kBlock);
+}
 
 // `n_frames`: the launch length the question is about (under AUTO a launch of four or more blocks runs another kernel
 // of the family than a one-block launch); 64 in persistent mode means "a command of the session"
@@ -332,7 +340,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
   if (b->ps.enabled && n_frames == kBlock)
     switch (persist_kind(b)) // persistent block mode
     {
-      case PERSIST_A1_P2: return "nam_a1_p2_kernel";
+      case PERSIST_A1_P2: return b->no_p3 ? "nam_a1_p2_kernel" : "nam_a1_p3_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
       case PERSIST_LSTM_WIDE: return "nam_lstm_wide_kernel";
@@ -345,7 +353,8 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
       case NAM_HIP_KERNEL_GENERIC: return "nam_generic_kernel";
       case NAM_HIP_KERNEL_WN_REG: return "nam_wn_reg_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
-      case NAM_HIP_KERNEL_A1_IL: return (p.a1.p2_ok && !b->il_generic) ? "nam_a1_p2_kernel" : "nam_a1_il_kernel";
+      case NAM_HIP_KERNEL_A1_IL:
+        return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_p3 && n_frames > kBlock) ? "nam_a1_p3_kernel" : "nam_a1_p2_kernel") : "nam_a1_il_kernel";
       default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
     }
   }
@@ -563,7 +572,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
+        if (p.a1.p2_ok && !b->il_generic && use_p3(b, n_frames))
+          // ... with two wavefronts per SIMD: the two arrays as two wave sets pipelined across consecutive buffers
+          NAM_HIP_CHECK(launch_a1_p3(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
+        else if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
           NAM_HIP_CHECK(launch_a1_p2(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
         else
           NAM_HIP_CHECK(launch_a1_il(a, n, act, s));
@@ -1502,6 +1514,8 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   {
     const char* e = std::getenv("NAM_HIP_IL_GENERIC");
     b->il_generic = e && e[0] == '1';
+    const char* e3 = std::getenv("NAM_HIP_NO_P3");
+    b->no_p3 = e3 && e3[0] == '1';
   }
   b->n_streams = n_streams;
   b->max_frames = max_frames;

@@ -79,11 +79,12 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-def build_fast(out_path: str) -> str:
+def build_fast(out_path: str, opt: str = "-Ofast") -> str:
     """Timing-only build for bench.py's cpu_baseline: same source with the reference's Release flags
-    (-Ofast, tools/CMakeLists.txt:176) and -march=native. Built on the machine that runs it."""
+    (-Ofast, tools/CMakeLists.txt:176) — or `opt` = "-O2", BASELINE.md's primary figure — and -march=native. Built on the
+    machine that runs it."""
     src = os.path.join(_HERE, "nam_oracle.c")
-    subprocess.check_call(["gcc", "-Ofast", "-march=native", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c99",
+    subprocess.check_call(["gcc", opt, "-march=native", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c99",
                            "-o", out_path, src, "-lm"])
     return out_path
 

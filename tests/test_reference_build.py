@@ -138,3 +138,28 @@ def test_reference_error_messages_match_the_loader(nam_lib, tmp_path):
         with pytest.raises(Exception) as our_err:
             nam_lib.get_dsp(p)
         assert str(ref_err.value) in str(our_err.value), (tag, str(ref_err.value), str(our_err.value))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_featured_models_oracle_bit_exact_with_the_reference(oracle, nam_lib, tmp_path, seed):
+    """The seeded feature-rich models of tests/test_gpu_breadth.py (per-layer gating / blending, FiLM subsets, grouped
+    convs, head1x1, bottlenecks, nested condition_dsp — the cases of the reference's own feature tests,
+    tools/test/test_wavenet_configurable_gating.cpp:86-264, test_film.cpp:26-480, test_wavenet/test_head1x1.cpp,
+    test_wavenet/test_condition_processing.cpp): the reference loads every one (its weight-count check is the pin of
+    the generator), the oracle reproduces it bit for bit in both tanh modes, and the product's loader accepts it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_synthetic_models as msm
+    path = str(tmp_path / f"featured_{seed}.nam")
+    msm.write_featured(path, 7000 + seed, wr_shapes=bool(seed % 2))
+    model = nam_lib.get_dsp(path)
+    for fast_tanh in (False, True):
+        ref = nam_ref.get_dsp(path, fast_tanh)
+        orc = oracle.get_dsp(path, fast_tanh=fast_tanh)
+        assert (ref.NumInputChannels(), ref.NumOutputChannels()) == (orc.NumInputChannels(), orc.NumOutputChannels()) == (
+            model.NumInputChannels(), model.NumOutputChannels())
+        assert ref.GetPrewarmSamples() == orc.GetPrewarmSamples() == model.GetPrewarmSamples()
+        x = _signal(ref.NumInputChannels(), 300, seed=seed)
+        for block in (64, 37):
+            ref.Reset(48000.0, block)
+            orc.Reset(48000.0, block)
+            np.testing.assert_array_equal(ref.process_stream(x, block), orc.process_stream(x, block))
