@@ -162,8 +162,8 @@ hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_a1_il(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
-// nam_a1_p3_kernel: the same models as launch_a1_p2, two wavefronts per SIMD (kernel_a1_p3.hip)
-hipError_t launch_a1_p3(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
+// nam_a1_p4_kernel: the same models as a pipeline of wave sets decoupled through LDS (kernel_a1_p4.hip)
+hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
 hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,
                           hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);

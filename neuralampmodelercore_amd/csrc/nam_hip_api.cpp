@@ -178,7 +178,7 @@ struct nam_hip_batch
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
-  bool no_p3 = false; // developer switch (NAM_HIP_NO_P3=1): nam_a1_p2_kernel where nam_a1_p3_kernel would run (A/B runs)
+  bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
   bool ps_launching = false; // launch_group is starting the session's resident launch
   int n_cus = 0; // compute units of the device
@@ -311,7 +311,7 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 enum PersistKind : int
 {
   PERSIST_NONE = -1,
-  PERSIST_A1_P2 = 0, // nam_a1_p2_kernel: one workgroup (4 wavefronts, most of a CU's LDS) per stream
+  PERSIST_A1_P2 = 0, // nam_a1_p4_kernel (nam_a1_p2_kernel with NAM_HIP_NO_PIPE=1): one workgroup (most of a CU's LDS) per stream
   PERSIST_WN_REG = 1, // nam_wn_reg_kernel: one wavefront per stream
   PERSIST_LSTM_ROW = 2, // nam_lstm_row_kernel: one wavefront per four streams
   PERSIST_LSTM_WIDE = 3 // nam_lstm_wide_kernel: one wavefront per stream
@@ -324,12 +324,12 @@ inline bool persist_eligible(const nam_hip_batch* b)
 }
 
 int kernel_for_launch(const nam_hip_batch* b, const WidthGroup& g, int n_frames);
-// nam_a1_p3_kernel (the official topology as two pipelined wave sets) instead of nam_a1_p2_kernel: whenever a launch
-// holds more than one buffer — a persistent session, an offline render, a prewarm. A launch of one block has nothing
-// to overlap (array 1 waits for array 0) and keeps the four-wave kernel.
-inline bool use_p3(const nam_hip_batch* b, int n_frames)
+// nam_a1_p4_kernel (the official topology as a pipeline of wave sets, consecutive buffers in flight at once) instead of
+// nam_a1_p2_kernel: whenever a launch holds more than one buffer — a persistent session, an offline render, a prewarm. A
+// launch of one block has nothing to overlap (every stage waits for the one before) and keeps the four-wave kernel.
+inline bool use_pipeline(const nam_hip_batch* b, int n_frames)
 {
-  return !b->no_p3 && (b->ps_launching || n_frames > kBlock);
+  return !b->no_pipe && (b->ps_launching || n_frames > kBlock);
 }
 
 // `n_frames`: the launch length the question is about (under AUTO a launch of four or more blocks runs another kernel
@@ -340,7 +340,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
   if (b->ps.enabled && n_frames == kBlock)
     switch (persist_kind(b)) // persistent block mode
     {
-      case PERSIST_A1_P2: return b->no_p3 ? "nam_a1_p2_kernel" : "nam_a1_p3_kernel";
+      case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : "nam_a1_p4_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
       case PERSIST_LSTM_WIDE: return "nam_lstm_wide_kernel";
@@ -354,7 +354,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
       case NAM_HIP_KERNEL_WN_REG: return "nam_wn_reg_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
       case NAM_HIP_KERNEL_A1_IL:
-        return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_p3 && n_frames > kBlock) ? "nam_a1_p3_kernel" : "nam_a1_p2_kernel") : "nam_a1_il_kernel";
+        return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_pipe && n_frames > kBlock) ? "nam_a1_p4_kernel" : "nam_a1_p2_kernel") : "nam_a1_il_kernel";
       default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
     }
   }
@@ -572,9 +572,9 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (p.a1.p2_ok && !b->il_generic && use_p3(b, n_frames))
-          // ... with two wavefronts per SIMD: the two arrays as two wave sets pipelined across consecutive buffers
-          NAM_HIP_CHECK(launch_a1_p3(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
+        if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames))
+          // ... as a pipeline of wave sets (three wavefronts per SIMD) across consecutive buffers
+          NAM_HIP_CHECK(launch_a1_p4(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
         else if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
           NAM_HIP_CHECK(launch_a1_p2(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
         else
@@ -1514,8 +1514,8 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   {
     const char* e = std::getenv("NAM_HIP_IL_GENERIC");
     b->il_generic = e && e[0] == '1';
-    const char* e3 = std::getenv("NAM_HIP_NO_P3");
-    b->no_p3 = e3 && e3[0] == '1';
+    const char* e3 = std::getenv("NAM_HIP_NO_PIPE");
+    b->no_pipe = e3 && e3[0] == '1';
   }
   b->n_streams = n_streams;
   b->max_frames = max_frames;
