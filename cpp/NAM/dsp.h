@@ -210,6 +210,10 @@ protected:
     nam_hip_batch* b = nullptr;
     detail::check(nam_hip_batch_create(mModel.get(), mDevice, NumStreams(), maxBufferSize, &b));
     mBatch.reset(b);
+    // persistent block mode where the model's kernel has one (include/nam_hip.h): process() then costs a command and a
+    // wait on host-mapped buffers instead of two copies, a launch and a stream synchronise per buffer (buffers of a
+    // multiple of 64 frames; anything else falls back to a launch, transparently)
+    (void)nam_hip_batch_set_persistent(b, 1);
     mMaxBufferSize = maxBufferSize;
     mIn.assign((size_t)NumInputChannels() * NumStreams() * maxBufferSize, NAM_SAMPLE(0));
     mOut.assign((size_t)NumOutputChannels() * NumStreams() * maxBufferSize, NAM_SAMPLE(0));

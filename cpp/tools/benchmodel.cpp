@@ -89,6 +89,7 @@ int main(int argc, char* argv[])
   double slim = -1.0;
   bool fast_tanh = true;
   int streams = 1;
+  int bufferSize = AUDIO_BUFFER_SIZE;
   bool count_allocs = false;
   for (int i = 2; i < argc; i++)
   {
@@ -100,23 +101,25 @@ int main(int argc, char* argv[])
       fast_tanh = false;
     else if (!std::strcmp(argv[i], "--streams") && i + 1 < argc)
       streams = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--buffer") && i + 1 < argc) // frames per process() call (the reference's tool: 64)
+      bufferSize = std::atoi(argv[++i]);
   }
   if (fast_tanh)
     nam::activations::Activation::enable_fast_tanh();
   try
   {
     std::cout << "Loading model " << modelPath << "\n";
-    const size_t numBuffers = (48000 / AUDIO_BUFFER_SIZE) * 2;
+    const size_t numBuffers = (48000 / bufferSize) * 2;
     if (streams <= 1)
     {
       auto model = nam::get_dsp(modelPath);
       if (slim >= 0.0)
         if (auto* s = dynamic_cast<nam::SlimmableModel*>(model.get()))
           s->SetSlimmableSize(slim);
-      model->Reset(model->GetExpectedSampleRate(), AUDIO_BUFFER_SIZE);
+      model->Reset(model->GetExpectedSampleRate(), bufferSize);
       const int ic = model->NumInputChannels(), oc = model->NumOutputChannels();
-      std::vector<std::vector<NAM_SAMPLE>> in(ic, std::vector<NAM_SAMPLE>(AUDIO_BUFFER_SIZE, 0.0)),
-        out(oc, std::vector<NAM_SAMPLE>(AUDIO_BUFFER_SIZE, 0.0));
+      std::vector<std::vector<NAM_SAMPLE>> in(ic, std::vector<NAM_SAMPLE>(bufferSize, 0.0)),
+        out(oc, std::vector<NAM_SAMPLE>(bufferSize, 0.0));
       std::vector<NAM_SAMPLE*> inp(ic), outp(oc);
       for (int c = 0; c < ic; c++)
         inp[c] = in[c].data();
@@ -125,13 +128,13 @@ int main(int argc, char* argv[])
       std::cout << "Running benchmark\n";
       std::vector<double> us(numBuffers, 0.0);
       for (int i = 0; i < 8; i++) // (first-launch costs stay outside, as the reference's prewarm does for its rings)
-        model->process(inp.data(), outp.data(), AUDIO_BUFFER_SIZE);
+        model->process(inp.data(), outp.data(), bufferSize);
       g_counting = count_allocs;
       auto t1 = high_resolution_clock::now();
       for (size_t i = 0; i < numBuffers; i++)
       {
         auto a = high_resolution_clock::now();
-        model->process(inp.data(), outp.data(), AUDIO_BUFFER_SIZE);
+        model->process(inp.data(), outp.data(), bufferSize);
         us[i] = duration<double, std::micro>(high_resolution_clock::now() - a).count();
       }
       auto t2 = high_resolution_clock::now();
@@ -146,19 +149,19 @@ int main(int argc, char* argv[])
       nam::detail::check(nam_hip_model_load(modelPath, fast_tanh ? 1 : 0, &raw));
       std::shared_ptr<nam_hip_model> m(raw, nam::detail::ModelDeleter());
       nam::BatchDSP batch(m, streams);
-      batch.Reset(48000.0, AUDIO_BUFFER_SIZE);
-      std::vector<float> in((size_t)streams * batch.NumInputChannels() * AUDIO_BUFFER_SIZE, 0.0f),
-        out((size_t)streams * batch.NumOutputChannels() * AUDIO_BUFFER_SIZE, 0.0f);
+      batch.Reset(48000.0, bufferSize);
+      std::vector<float> in((size_t)streams * batch.NumInputChannels() * bufferSize, 0.0f),
+        out((size_t)streams * batch.NumOutputChannels() * bufferSize, 0.0f);
       std::cout << "Running benchmark (" << streams << " streams, host buffers)\n";
       std::vector<double> us(numBuffers, 0.0);
       for (int i = 0; i < 8; i++)
-        batch.process_batch(in.data(), out.data(), AUDIO_BUFFER_SIZE);
+        batch.process_batch(in.data(), out.data(), bufferSize);
       g_counting = count_allocs;
       auto t1 = high_resolution_clock::now();
       for (size_t i = 0; i < numBuffers; i++)
       {
         auto a = high_resolution_clock::now();
-        batch.process_batch(in.data(), out.data(), AUDIO_BUFFER_SIZE);
+        batch.process_batch(in.data(), out.data(), bufferSize);
         us[i] = duration<double, std::micro>(high_resolution_clock::now() - a).count();
       }
       auto t2 = high_resolution_clock::now();

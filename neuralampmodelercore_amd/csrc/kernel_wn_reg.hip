@@ -331,7 +331,7 @@ __device__ __forceinline__ void wr_act(int type, f2* v, const WrActP<N>& ap)
 // not depend on the conv, is moved in front of it so that it runs while the conv's taps come back from LDS).
 // FM >= 0: FiLM mask / shift mask / blend / activation types are compile-time (one straight-line block); FM < 0: run-time
 // flags from the op
-template <int COND, int C, int B, bool G, int K, int HO, int FM, int SM, int BL, int A1, int A2>
+template <int COND, int C, int B, bool G, int K, int HO, int FM, int SM, int BL, int A1, int A2, int L1>
 __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, int lane, int posv)
 {
   constexpr WrLayerLayout L = wr_layer_layout(COND, C, B, G, K, HO);
@@ -442,7 +442,8 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
 #pragma unroll
   for (int c = 0; c < wr_pairs(ZC); c++)
     z[c] += m[c];
-  wr_ld(m_l1, lds, wb + L.l1 * 4u, true, wb + L.l1_b * 4u);
+  if constexpr (L1 != 0)
+    wr_ld(m_l1, lds, wb + L.l1 * 4u, true, wb + L.l1_b * 4u);
   wr_fence();
   if (on(FILM_ACT_PRE))
     wr_film<ZC, COND>(z, r.cond, f_apre, sh(FILM_ACT_PRE));
@@ -467,24 +468,23 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
   if constexpr (HO > 0)
     wr_ld(m_h1, lds, wb + L.h1 * 4u, true, wb + L.h1_b * 4u);
   wr_fence();
-  if (on(FILM_ACT_POST))
-  {
-    if constexpr (G && (B & 1)) // (an odd B would share its last pair with a gate row: not instantiated)
-      __builtin_trap();
+  if (on(FILM_ACT_POST)) // (an odd B shares its last pair with gate row B: dead after the gating, its scale / shift columns are padding)
     wr_film<B, COND>(z, r.cond, f_apost, sh(FILM_ACT_POST));
-  }
   float zb[B]; // the B rows the 1x1s read
   wr_unpack<B>(zb, z);
-  const bool l1_film = G && blended && on(FILM_LAYER1X1_POST); // quirk kept: only in the BLENDED branch, model.cpp:282-286
+  const bool l1_film = L1 != 0 && G && blended && on(FILM_LAYER1X1_POST); // quirk kept: only in the BLENDED branch, model.cpp:282-286
   if (l1_film)
     wr_ld(f_l1, lds, fb(FILM_LAYER1X1_POST), sh(FILM_LAYER1X1_POST));
   if (HO > 0 && on(FILM_HEAD1X1_POST))
     wr_ld(f_h1, lds, fb(FILM_HEAD1X1_POST), sh(FILM_HEAD1X1_POST));
   wr_fence();
   f2 l1[wr_pairs(C)];
-  wr_mv(l1, zb, m_l1);
-  if (l1_film)
-    wr_film<C, COND>(l1, r.cond, f_l1, sh(FILM_LAYER1X1_POST));
+  if constexpr (L1 != 0)
+  {
+    wr_mv(l1, zb, m_l1);
+    if (l1_film)
+      wr_film<C, COND>(l1, r.cond, f_l1, sh(FILM_LAYER1X1_POST));
+  }
 
   // head contribution — model.cpp:290-352, accumulated by the array (:513-531)
   if constexpr (HO > 0)
@@ -503,10 +503,13 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
     for (int c = 0; c < B; c++)
       r.hacc[c] += zb[c];
   }
-  // residual — model.cpp:354-392
+  // residual — model.cpp:354-392 (without a layer1x1 the layer's output is its input: :380-391)
+  if constexpr (L1 != 0)
+  {
 #pragma unroll
-  for (int i = 0; i < C; i++)
-    r.x[i] += pget(l1, i);
+    for (int i = 0; i < C; i++)
+      r.x[i] += pget(l1, i);
+  }
 }
 
 // WR_RUN: consecutive PLAIN layers (model.cpp:183-393 with no FiLM, no gating, no head1x1, condition size 1, kernel size
@@ -630,13 +633,41 @@ __device__ __forceinline__ void wr_array_end(WrRegs& r, const WrOpS& op, const c
   wr_unpack<HS>(r.hout, o);
 }
 
+// head rechannel with taps (model.cpp:399-400, 547-548): a Conv1D(kernel KH, dilation op.dil) over the head accumulator,
+// which therefore has a ring like a layer's conv input; W^T = [KH * HI][pad4(HS)], row = tap * HI + input
+template <int HI, int HS, int KH>
+__device__ __forceinline__ void wr_array_end_k(WrRegs& r, const WrOpS& op, char* lds, int lane, int posv)
+{
+  WrMat<HS, KH * HI> m;
+  wr_ld(m, lds, (unsigned)op.w * 4u, true, (unsigned)op.w * 4u + (unsigned)(KH * HI * wr_pad4(HS)) * 4u); // (a zero bias when none)
+  const int R = op.ring;
+  int widx = __builtin_amdgcn_readlane(posv, op.slot) + lane;
+  widx -= widx >= R ? R : 0;
+  const unsigned hb = (unsigned)op.hist * 4u;
+  wr_ring_put<HI>(lds, hb, widx, R, r.hacc);
+  float taps[KH * HI];
+#pragma unroll
+  for (int k = 0; k + 1 < KH; k++)
+  {
+    int idx = widx - (KH - 1 - k) * op.dil;
+    idx += idx < 0 ? R : 0;
+    wr_ring_get<HI>(lds, hb, idx, R, taps + k * HI);
+  }
+#pragma unroll
+  for (int i = 0; i < HI; i++)
+    taps[(KH - 1) * HI + i] = r.hacc[i];
+  f2 o[wr_pairs(HS)];
+  wr_mv(o, taps, m);
+  wr_unpack<HS>(r.hout, o);
+}
+
 } // namespace
 
 // SET: which layer code the instantiation carries — 0: the fully described WR_LAYER shapes only (wavenet_a2_max: 344
 // registers, no spills), 1: WR_RUN shapes only (plain stacks: 278 registers, a short dispatch), 2: everything (the
 // run-time-flag layer shapes spill).
 template <int SET>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_kernel(const WrArgs a)
+__device__ __forceinline__ void wn_reg_body(const WrArgs& a)
 {
   extern __shared__ __attribute__((aligned(16))) char lds_wr[];
   char* const lds = lds_wr;
@@ -829,10 +860,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           {
             switch (cur.shape)
             {
-#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
+#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2, L1) \
   case ID: \
     if constexpr (SET == 2 || FM >= 0) \
-      wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2>(r, cur, lds, lane, posv); \
+      wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2, L1>(r, cur, lds, lane, posv); \
     else \
       __builtin_trap(); \
     break;
@@ -875,6 +906,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #define X(ID, IN, OUT) \
   case ID: wr_array_end<IN, OUT>(r, cur, lds); break;
             WR_PAIR_SHAPES(X)
+#undef X
+            default: __builtin_trap();
+          }
+          break;
+        case WR_ARRAY_END_K:
+          switch (cur.shape)
+          {
+#define X(ID, IN, OUT, KH) \
+  case ID: wr_array_end_k<IN, OUT, KH>(r, cur, lds, lane, posv); break;
+            WR_HEADK_SHAPES(X)
 #undef X
             default: __builtin_trap();
           }
@@ -957,6 +998,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     pw.leave(a.ps, (int)blockIdx.x);
 }
 
+#ifdef NAM_WR_JIT_SHAPES
+// The per-model build (wr_jit.cpp): this file compiled with the model's own shape tables in front of it, one kernel
+// holding exactly those shapes, found by name in the code object.
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_jit(const WrArgs a)
+{
+  wn_reg_body<2>(a);
+}
+#else
+template <int SET>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_kernel(const WrArgs a)
+{
+  wn_reg_body<SET>(a);
+}
+
+// a kernel compiled for one model's shapes (`fn`: hipFunction_t of nam_wn_reg_jit in that model's code object)
+hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream)
+{
+  if (n_workgroups <= 0 || a.n_frames <= 0)
+    return hipSuccess;
+  WrArgs args = a;
+  size_t size = sizeof(args);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(fn), (unsigned)n_workgroups, 1, 1, 64, 1, 1, (unsigned)lds_bytes, stream,
+                               nullptr, config);
+}
+
 hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers,
                          hipStream_t stream)
 {
@@ -981,5 +1048,6 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
     return launch(nam_wn_reg_kernel<1>, 1);
   return launch(nam_wn_reg_kernel<0>, 0);
 }
+#endif
 
 } // namespace namhip

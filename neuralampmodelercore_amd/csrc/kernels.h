@@ -157,6 +157,8 @@ struct WrArgs
 
 hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers,
                          hipStream_t stream);
+// the same kernel compiled for one model's own layer shapes (wr_jit.cpp); fn = hipFunction_t of the model's code object
+hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream);
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "kernels.h"
 #include "model_spec.h"
 #include "plan.h"
+#include "wr_jit.h"
 
 using namespace namhip;
 
@@ -170,6 +172,11 @@ struct nam_hip_batch
   float* d_in = nullptr; // staging for the host-pointer entry points
   float* d_out = nullptr;
   float* h_stage = nullptr; // pinned, used by the f64 path
+  // host-mapped staging of the blocking entry points in persistent mode: the session's kernel reads the input from and
+  // writes the output to host memory itself (its input loads / output stores are system-scope anyway), so a blocking
+  // call is: copy in, store the command(s), watch the completion words, copy out — no launch of a copy, no stream sync
+  float *h_in_map = nullptr, *h_out_map = nullptr; // host addresses
+  float *d_in_map = nullptr, *d_out_map = nullptr; // the same memory as the device sees it
   int kernel = NAM_HIP_KERNEL_AUTO;
   long long* dbg = nullptr; // device buffer of the profiling instantiation (nam_hip_batch_debug_timeline)
   bool was_reset = false;
@@ -387,6 +394,37 @@ PersistArgs persist_args(const nam_hip_batch* b)
   return pa;
 }
 
+// The function of a per-model code object on the current device (hipModuleLoad is per device: cached per path and
+// device for the life of the process; a handful of entries).
+int wr_jit_function(const std::string& path, int device, void** fn)
+{
+  struct Entry
+  {
+    std::string path;
+    int device;
+    hipModule_t module;
+    hipFunction_t fn;
+  };
+  static std::vector<Entry> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Entry& e : cache)
+    if (e.device == device && e.path == path)
+    {
+      *fn = reinterpret_cast<void*>(e.fn);
+      return NAM_HIP_OK;
+    }
+  Entry e{path, device, nullptr, nullptr};
+  NAM_HIP_CHECK(hipModuleLoad(&e.module, path.c_str()));
+  NAM_HIP_CHECK(hipModuleGetFunction(&e.fn, e.module, "nam_wn_reg_jit"));
+  // more than the default 64 KB of dynamic LDS per workgroup (long dilations: up to 156 KB of rings)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
+  (void)hipGetLastError();
+  cache.push_back(e);
+  *fn = reinterpret_cast<void*>(e.fn);
+  return NAM_HIP_OK;
+}
+
 // nam_wn_reg_kernel over up to kWrMaxGroups width groups in ONE launch (kernels.h: WrArgs): group k's `counts[k]` streams
 // (`maps[k]`: position -> stream index, nullptr = identity) become consecutive workgroups.
 int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* maps, const int* counts, int n_groups,
@@ -435,6 +473,20 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   a.in_ch = groups[0]->plan->in_channels;
   a.out_ch = groups[0]->plan->out_channels;
   a.ps = persist_args(b);
+  // every group on the model's own code object (they share one: build_model), or every group on the ahead-of-time kernel
+  const std::string& module = groups[0]->plan->wr.jit_module;
+  for (int k = 1; k < n_groups; k++)
+    if (groups[k]->plan->wr.jit_module != module)
+      return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_wn_reg_kernel: the groups of one launch run different code objects");
+  if (!module.empty())
+  {
+    void* fn = nullptr;
+    const int rc = wr_jit_function(module, b->device, &fn);
+    if (rc != NAM_HIP_OK)
+      return rc;
+    NAM_HIP_CHECK(launch_wn_reg_jit(fn, a, total, lds_bytes, s));
+    return NAM_HIP_OK;
+  }
   NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, layers, runs, rt_layers, s));
   return NAM_HIP_OK;
 }
@@ -455,7 +507,8 @@ WrGroupList wr_groups(nam_hip_batch* b)
     if (g.streams.empty())
       continue;
     if (out.n == kWrMaxGroups || g.plan->arch != ARCH_WAVENET || !g.d_wr_blob || pick_kernel(b, g) != NAM_HIP_KERNEL_WN_REG
-        || g.plan->in_channels != full.in_channels || g.plan->out_channels != full.out_channels)
+        || g.plan->in_channels != full.in_channels || g.plan->out_channels != full.out_channels
+        || (out.n > 0 && g.plan->wr.jit_module != out.g[0]->plan->wr.jit_module)) // (one launch = one code object)
     {
       out.n = 0;
       return out;
@@ -1029,11 +1082,25 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
 
 // One 64-frame buffer for every stream of the batch through the session. Returns 1 when this call cannot be expressed
 // as a command of a session (the caller then launches as usual).
+int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long stride, hipStream_t caller);
+// A buffer of any multiple of 64 frames (what hosts send: NAM/dsp.h:97 takes any num_frames <= maxBufferSize; plugins run
+// 64 ... 1,024) is that many commands, submitted back to back: the session renders them without a kernel boundary in between.
 int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_frames, long stride, hipStream_t caller)
 {
-  PersistSession& ps = b->ps;
-  if (n_frames != kBlock)
+  if (n_frames <= 0 || n_frames % kBlock != 0)
     return 1;
+  for (int f = 0; f < n_frames; f += kBlock)
+  {
+    const int rc = persist_submit_block(b, d_in + f, d_out + f, stride, caller);
+    if (rc != NAM_HIP_OK)
+      return rc < 0 ? rc : (f == 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: a buffer was split across sessions"));
+  }
+  return NAM_HIP_OK;
+}
+
+int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long stride, hipStream_t caller)
+{
+  PersistSession& ps = b->ps;
   if (ps.active)
   {
     const long off_in = d_in - ps.in_base, off_out = d_out - ps.out_base;
@@ -1185,6 +1252,11 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
 {
   auto m = std::make_unique<nam_hip_model>();
   m->spec = std::move(spec);
+  // layer shapes outside nam_wn_reg_kernel's ahead-of-time tables: collected over every plan of the model (the widths of
+  // a slimmable WaveNet, the submodels of a container) and compiled as ONE code object (wr_jit.cpp), so that a batch with
+  // mixed widths still runs as one launch
+  WrShapeSet jit_shapes;
+  WrShapeSet* const js = wr_jit_enabled() ? &jit_shapes : nullptr;
   if (m->spec->arch == ARCH_WAVENET && m->spec->wavenet.slimmable)
   {
     // enumerate the distinct widths: one probe ratio per interval between breakpoints
@@ -1204,7 +1276,7 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
       if (std::find(m->width_channels.begin(), m->width_channels.end(), ch) == m->width_channels.end())
       {
         m->width_channels.push_back(ch);
-        m->plans.push_back(build_wavenet_plan(slim_wavenet(m->spec->wavenet, ch)));
+        m->plans.push_back(build_wavenet_plan(slim_wavenet(m->spec->wavenet, ch), js));
       }
     }
     m->full_width = m->width_for_ratio(1.0);
@@ -1215,18 +1287,96 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
     // SetSlimmableSize to its children); a fresh container has the last submodel active (container.cpp:49)
     for (const auto& sm : m->spec->submodels)
     {
-      m->plans.push_back(build_plan(*sm));
+      m->plans.push_back(build_plan(*sm, js));
       m->width_channels.push_back({});
     }
     m->full_width = (int)m->plans.size() - 1;
   }
   else
   {
-    m->plans.push_back(build_plan(*m->spec));
+    m->plans.push_back(build_plan(*m->spec, js));
     m->width_channels.push_back({});
     m->full_width = 0;
   }
+  bool any_jit = false;
+  for (const Plan& p : m->plans)
+    any_jit = any_jit || (p.wr.ok && p.wr.jit);
+  if (any_jit)
+  {
+    std::string why;
+    const std::string module = wr_jit_build(jit_shapes, why);
+    for (size_t i = 0; i < m->plans.size(); i++)
+    {
+      Plan& p = m->plans[i];
+      if (!(p.wr.ok && p.wr.jit))
+        continue;
+      if (!module.empty())
+        p.wr.jit_module = module;
+      else
+      {
+        // no compiler / sources here: plan again without the model's own shapes (run-time-flag instantiations if the
+        // model fits them, else the other kernels take it)
+        const ModelSpec& sp = m->spec->arch == ARCH_CONTAINER ? *m->spec->submodels[i] : *m->spec;
+        Plan again = (sp.arch == ARCH_WAVENET && sp.wavenet.slimmable) ? build_wavenet_plan(slim_wavenet(sp.wavenet, m->width_channels[i]))
+                                                                       : build_plan(sp);
+        if (!again.wr.ok)
+          again.wr.why += " [" + why + "]";
+        p = std::move(again);
+      }
+    }
+  }
   *out = m.release();
+  return NAM_HIP_OK;
+}
+
+// The blocking entry points inside a persistent session: the kernel reads the buffer from and writes it to HOST-MAPPED
+// memory (float32 rows [stream][channel][max_frames]); in_f32 / in_f64 and out_f32 / out_f64: exactly one of each.
+// Returns 0 when the buffer went through the session, 1 when the mode does not apply (not enabled / not eligible /
+// n_frames not a multiple of 64), < 0 on failure.
+int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_f64, float* out_f32, double* out_f64, int n_frames)
+{
+  if (!b->ps.enabled || n_frames % kBlock != 0 || !persist_eligible(b))
+    return 1;
+  for (auto& g0 : b->groups)
+    if (!g0.streams.empty() && g0.plan->arch == ARCH_WAVENET && g0.state_family >= 0 && g0.state_family != persist_family(b, g0))
+      return 1; // (the copying path reports the layout clash)
+  const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
+  const long stride = b->max_frames;
+  if (!b->h_in_map)
+  {
+    const size_t in_floats = (size_t)b->n_streams * ic * b->max_frames, out_floats = (size_t)b->n_streams * oc * b->max_frames;
+    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_in_map), in_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_out_map), out_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_in_map), b->h_in_map, 0));
+    NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_out_map), b->h_out_map, 0));
+  }
+  const size_t rows_in = (size_t)b->n_streams * ic, rows_out = (size_t)b->n_streams * oc;
+  for (size_t r = 0; r < rows_in; r++)
+  {
+    float* dst = b->h_in_map + r * stride;
+    if (in_f32)
+      std::memcpy(dst, in_f32 + r * n_frames, (size_t)n_frames * sizeof(float));
+    else // double -> float exactly as _set_condition_array does (NAM/wavenet/model.cpp:817)
+      for (int i = 0; i < n_frames; i++)
+        dst[i] = (float)in_f64[r * n_frames + i];
+  }
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  const int rc = persist_submit(b, b->d_in_map, b->d_out_map, n_frames, stride, b->stream);
+  if (rc != NAM_HIP_OK)
+    return rc < 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: the host-mapped buffer was refused");
+  const int rw = persist_flush(b, b->stream);
+  if (rw != NAM_HIP_OK)
+    return rw;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (size_t r = 0; r < rows_out; r++)
+  {
+    const float* src = b->h_out_map + r * stride;
+    if (out_f32)
+      std::memcpy(out_f32 + r * n_frames, src, (size_t)n_frames * sizeof(float));
+    else
+      for (int i = 0; i < n_frames; i++)
+        out_f64[r * n_frames + i] = (double)src[i];
+  }
   return NAM_HIP_OK;
 }
 
@@ -1574,6 +1724,10 @@ void nam_hip_batch_destroy(nam_hip_batch* batch)
     (void)hipFree(batch->d_out);
   if (batch->h_stage)
     (void)hipHostFree(batch->h_stage);
+  if (batch->h_in_map)
+    (void)hipHostFree(batch->h_in_map);
+  if (batch->h_out_map)
+    (void)hipHostFree(batch->h_out_map);
   if (batch->stream)
     (void)hipStreamDestroy(batch->stream);
   delete batch;
@@ -1721,6 +1875,11 @@ int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out,
   NAM_HIP_CHECK(hipSetDevice(batch->device));
   const size_t in_bytes = (size_t)batch->n_streams * batch->model->spec->in_channels() * n_frames * sizeof(float);
   const size_t out_bytes = (size_t)batch->n_streams * batch->model->spec->out_channels() * n_frames * sizeof(float);
+  {
+    const int rc = process_host_mapped(batch, in, nullptr, out, nullptr, n_frames);
+    if (rc <= 0)
+      return rc; // done through the session (0) or failed (< 0); 1 = not applicable: the copying path below
+  }
   NAM_HIP_CHECK(hipMemcpyAsync(batch->d_in, in, in_bytes, hipMemcpyHostToDevice, batch->stream));
   const int rc = nam_hip_batch_process_device(batch, batch->d_in, batch->d_out, n_frames, n_frames, nullptr);
   if (rc != NAM_HIP_OK)
@@ -1794,6 +1953,11 @@ int nam_hip_batch_process_f64(nam_hip_batch* batch, const double* in, double* ou
   NAM_HIP_CHECK(hipSetDevice(batch->device));
   const size_t n_in = (size_t)batch->n_streams * batch->model->spec->in_channels() * n_frames;
   const size_t n_out = (size_t)batch->n_streams * batch->model->spec->out_channels() * n_frames;
+  {
+    const int rc = process_host_mapped(batch, nullptr, in, nullptr, out, n_frames);
+    if (rc <= 0)
+      return rc;
+  }
   // double -> float exactly as _set_condition_array does (NAM/wavenet/model.cpp:817)
   for (size_t i = 0; i < n_in; i++)
     batch->h_stage[i] = (float)in[i];
@@ -1836,6 +2000,12 @@ int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable)
     const int rc = persist_stop(batch);
     if (rc != NAM_HIP_OK)
       return rc;
+  }
+  if (enable)
+  {
+    const char* e = std::getenv("NAM_HIP_NO_PERSISTENT"); // developer switch (A/B runs of callers that opt in themselves)
+    if (e && e[0] == '1')
+      enable = 0;
   }
   batch->ps.enabled = enable != 0;
   return (batch->ps.enabled && persist_eligible(batch)) ? 1 : 0;

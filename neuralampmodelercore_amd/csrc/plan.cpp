@@ -1259,7 +1259,24 @@ struct WrBuilder
   };
   std::vector<Entry> rows, pf;
   std::vector<int32_t> ring_of_slot;
-  explicit WrBuilder(WrPlan& w) : wr(w) {}
+  // where shapes are looked up: the ahead-of-time tables (nullptr), or the model's own shape set (per-model compile)
+  WrShapeSet* dyn = nullptr;
+  enum Policy
+  {
+    AOT_EXACT_ONLY, // only fully described ahead-of-time shapes (and runs / pairs)
+    AOT_ANY, // run-time-flag instantiations too
+    JIT // register every shape in `dyn`
+  } policy = AOT_ANY;
+  WrBuilder(WrPlan& w, Policy p, WrShapeSet* d) : wr(w), dyn(d), policy(p) {}
+  int shape_layer(int cond, int C, int B, bool G, int K, int HO, int flags, int act, int act2, bool l1)
+  {
+    if (policy == JIT)
+      return dyn->layer(cond, C, B, G, K, HO, flags, act, act2, l1);
+    const int id = wr_layer_shape(cond, C, B, G, K, HO, flags, act, act2, l1);
+    return (id >= 0 && policy == AOT_EXACT_ONLY && !wr_layer_shape_is_exact(id)) ? -1 : id;
+  }
+  int shape_run(int C, int act) { return policy == JIT ? dyn->run(C, act) : wr_run_shape(C, act); }
+  int shape_pair(int n_in, int n_out) { return policy == JIT ? dyn->pair(n_in, n_out) : wr_pair_shape(n_in, n_out); }
 
   // A layer's conv-input ring: [ceil(C / 4)][R][gs] floats; table entries for its channels. Returns the float offset
   // of the area (relative to the ring area's start).
@@ -1399,10 +1416,10 @@ struct WrBuilder
       const int C = A.channels, B = A.bottleneck, HO = A.head_output_size();
       if (A.condition_size != cond_dim)
         throw std::runtime_error("plan: condition_size does not match the condition signal");
-      if (!A.layer1x1_active)
-        throw Unsupported("a layer without its 1x1");
-      if (A.head_kernel_size != 1)
-        throw Unsupported("a head rechannel with a kernel");
+      if (!A.layer1x1_active && policy != JIT)
+        throw Unsupported("a layer without its 1x1"); // (compiled per model: the ahead-of-time shapes all have one)
+      if (A.head_kernel_size != 1 && policy != JIT)
+        throw Unsupported("a head rechannel with a kernel"); // (compiled per model only)
       if (ai > 0 && wn.arrays[ai - 1].head_size != HO)
         throw std::runtime_error("plan: head sizes of consecutive arrays do not chain");
       {
@@ -1410,7 +1427,7 @@ struct WrBuilder
         op.flags = ai == 0 ? 1 : 0;
         op.n_in = A.input_size;
         op.n_out = C;
-        op.shape = wr_pair_shape(A.input_size, C);
+        op.shape = shape_pair(A.input_size, C);
         if (op.shape < 0)
           throw Unsupported("a rechannel of " + std::to_string(A.input_size) + " -> " + std::to_string(C));
         const int off = reserve(A.input_size * wr_pad4(C));
@@ -1439,8 +1456,12 @@ struct WrBuilder
             flags |= (1 << k) | (A.film[k].shift ? 1 << (8 + k) : 0);
         // a PLAIN layer (no gating, FiLM or head1x1; condition size 1, kernel size 3, at most four channels, a
         // parameterless activation) joins a WR_RUN and takes the compact weight block
-        const int run_shape = (cond_dim == 1 && B == C && !G && K == 3 && h1o == 0 && flags == 0) ? wr_run_shape(C, a1.type) : -1;
-        const int shape = wr_layer_shape(cond_dim, C, B, G, K, h1o, flags, a1.type, G ? a2.type : (int)ACT_IDENTITY);
+        const bool plain = cond_dim == 1 && B == C && C <= 4 && !G && K == 3 && h1o == 0 && flags == 0 && A.layer1x1_active
+                           && (a1.type == ACT_RELU || a1.type == ACT_TANH || a1.type == ACT_FASTTANH);
+        const int run_shape = plain ? shape_run(C, a1.type) : -1;
+        const int shape = run_shape >= 0 ? -1
+                                         : shape_layer(cond_dim, C, B, G, K, h1o, flags, a1.type, G ? a2.type : (int)ACT_IDENTITY,
+                                                       A.layer1x1_active);
         if (shape < 0 && run_shape < 0)
           throw Unsupported("layer shape cond=" + std::to_string(cond_dim) + " C=" + std::to_string(C) + " B=" + std::to_string(B)
                             + (G ? " gating" : "") + " K=" + std::to_string(K) + " head1x1=" + std::to_string(h1o));
@@ -1468,9 +1489,12 @@ struct WrBuilder
           for (int i = 0; i < zc; i++)
             d[L.conv_b + i] = *(w++);
           dense(d + L.mixin, w, cond_dim, zc, 1, A.groups_input_mixin);
-          dense(d + L.l1, w, B, C, 1, A.layer1x1_groups);
-          for (int i = 0; i < C; i++)
-            d[L.l1_b + i] = *(w++);
+          if (A.layer1x1_active)
+          {
+            dense(d + L.l1, w, B, C, 1, A.layer1x1_groups);
+            for (int i = 0; i < C; i++)
+              d[L.l1_b + i] = *(w++);
+          }
           if (A.head1x1_active)
           {
             dense(d + L.h1, w, B, h1o, 1, A.head1x1_groups);
@@ -1514,12 +1538,13 @@ struct WrBuilder
         op.act2 = G ? a2.type : ACT_IDENTITY;
         wr.n_layers++;
       }
+      if (A.head_kernel_size == 1)
       {
         WrOp& op = push(WR_ARRAY_END);
         op.flags = A.head_bias ? 1 : 0;
         op.n_in = HO;
         op.n_out = A.head_size;
-        op.shape = wr_pair_shape(HO, A.head_size);
+        op.shape = shape_pair(HO, A.head_size);
         if (op.shape < 0)
           throw Unsupported("a head rechannel of " + std::to_string(HO) + " -> " + std::to_string(A.head_size));
         const int off = reserve(HO * wr_pad4(A.head_size) + wr_pad4(A.head_size));
@@ -1528,6 +1553,29 @@ struct WrBuilder
         if (A.head_bias)
           for (int i = 0; i < A.head_size; i++)
             wr.blob[(size_t)off + (size_t)HO * wr_pad4(A.head_size) + i] = *(w++);
+      }
+      else
+      {
+        // a Conv1D over the head accumulator: [K_h * HO][pad4(head size)] (row = tap * HO + input) + bias, its own ring
+        const int KH = A.head_kernel_size;
+        if (KH * HO > 64)
+          throw Unsupported("a head rechannel of more than 64 tap inputs");
+        const int off = reserve(KH * HO * wr_pad4(A.head_size) + wr_pad4(A.head_size));
+        dense(&wr.blob[(size_t)off], w, HO, A.head_size, KH, 1);
+        if (A.head_bias)
+          for (int i = 0; i < A.head_size; i++)
+            wr.blob[(size_t)off + (size_t)KH * HO * wr_pad4(A.head_size) + i] = *(w++);
+        WrOp& op = push(WR_ARRAY_END_K);
+        op.flags = A.head_bias ? 1 : 0;
+        op.n_in = HO;
+        op.n_out = A.head_size;
+        op.shape = dyn->head(HO, A.head_size, KH);
+        op.w = off;
+        op.slot = (int)ring_of_slot.size();
+        op.hist = ring_area(HO, KH, A.head_dilation); // + the ring area's base, below
+        op.ring = (KH - 1) * A.head_dilation + kBlock;
+        op.dil = A.head_dilation;
+        wr.n_layers++; // (a slot: one write position per ring)
       }
     }
     const float head_scale = *(w++);
@@ -1544,11 +1592,11 @@ struct WrBuilder
 } // namespace
 
 int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out, int flags, int act,
-                   int act2)
+                   int act2, bool l1)
 {
   // `flags` as in WrOp::flags: bits 0-7 FiLM slots, 8-15 their shifts, bit 16 blended
-#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
-  if (cond == COND && channels == C && bottleneck == B && gating == G && kernel == K && head_out == HO \
+#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2, L1) \
+  if (cond == COND && channels == C && bottleneck == B && gating == G && kernel == K && head_out == HO && l1 == (L1 != 0) \
       && (FM < 0 || (flags == (FM | (SM << 8) | (BL << 16)) && act == A1 && act2 == A2))) \
     return ID;
   WR_LAYER_SHAPES(X)
@@ -1558,7 +1606,7 @@ int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kern
 
 bool wr_layer_shape_is_exact(int id)
 {
-#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2) \
+#define X(ID, COND, C, B, G, K, HO, FM, SM, BL, A1, A2, L1) \
   if (id == ID) \
     return FM >= 0;
   WR_LAYER_SHAPES(X)
@@ -1586,12 +1634,73 @@ int wr_pair_shape(int n_in, int n_out)
   return -1;
 }
 
-void build_wr(const WaveNetSpec& wn, Plan& plan)
+int WrShapeSet::layer(int cond, int C, int B, bool G, int K, int HO, int flags, int act, int act2, bool l1)
 {
-  WrPlan wr;
-  try
+  const Layer want{cond, C, B, G ? 1 : 0, K, HO, flags, act, act2, l1 ? 1 : 0};
+  for (size_t i = 0; i < layers.size(); i++)
   {
-    WrBuilder b(wr);
+    const Layer& o = layers[i];
+    if (o.cond == want.cond && o.C == want.C && o.B == want.B && o.G == want.G && o.K == want.K && o.HO == want.HO
+        && o.flags == want.flags && o.act == want.act && o.act2 == want.act2 && o.l1 == want.l1)
+      return (int)i;
+  }
+  layers.push_back(want);
+  return (int)layers.size() - 1;
+}
+int WrShapeSet::run(int C, int act)
+{
+  for (size_t i = 0; i < runs.size(); i++)
+    if (runs[i].C == C && runs[i].act == act)
+      return (int)i;
+  runs.push_back({C, act});
+  return (int)runs.size() - 1;
+}
+int WrShapeSet::head(int n_in, int n_out, int K)
+{
+  for (size_t i = 0; i < heads.size(); i++)
+    if (heads[i].n_in == n_in && heads[i].n_out == n_out && heads[i].K == K)
+      return (int)i;
+  heads.push_back({n_in, n_out, K});
+  return (int)heads.size() - 1;
+}
+int WrShapeSet::pair(int n_in, int n_out)
+{
+  for (size_t i = 0; i < pairs.size(); i++)
+    if (pairs[i].n_in == n_in && pairs[i].n_out == n_out)
+      return (int)i;
+  pairs.push_back({n_in, n_out});
+  return (int)pairs.size() - 1;
+}
+std::string WrShapeSet::header_text() const
+{
+  // the tables of plan.h, generated: every layer fully described (FiLM set, blend, activation types compiled in)
+  std::stringstream ss;
+  ss << "#define NAM_WR_JIT_SHAPES 1\n#define WR_LAYER_SHAPES(X)";
+  for (size_t i = 0; i < layers.size(); i++)
+  {
+    const Layer& o = layers[i];
+    ss << " X(" << i << ", " << o.cond << ", " << o.C << ", " << o.B << ", " << (o.G ? "true" : "false") << ", " << o.K << ", " << o.HO
+       << ", " << (o.flags & 0xff) << ", " << ((o.flags >> 8) & 0xff) << ", " << ((o.flags >> 16) & 1) << ", " << o.act << ", " << o.act2
+       << ", " << o.l1 << ")";
+  }
+  ss << "\n#define WR_RUN_SHAPES(X)";
+  for (size_t i = 0; i < runs.size(); i++)
+    ss << " X(" << i << ", " << runs[i].C << ", " << runs[i].act << ")";
+  ss << "\n#define WR_PAIR_SHAPES(X)";
+  for (size_t i = 0; i < pairs.size(); i++)
+    ss << " X(" << i << ", " << pairs[i].n_in << ", " << pairs[i].n_out << ")";
+  ss << "\n#define WR_HEADK_SHAPES(X)";
+  for (size_t i = 0; i < heads.size(); i++)
+    ss << " X(" << i << ", " << heads[i].n_in << ", " << heads[i].n_out << ", " << heads[i].K << ")";
+  ss << "\n";
+  return ss.str();
+}
+
+// One attempt under one shape policy; throws WrBuilder::Unsupported
+static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy policy, WrShapeSet* dyn)
+{
+  {
+    WrBuilder b(wr, policy, dyn);
     b.net(wn, false);
     static_assert(sizeof(WrBuilder::Entry) == 16, "table entries are int4");
     // consecutive plain layers of one shape (weight blocks at the layout's stride) become one WR_RUN
@@ -1638,7 +1747,7 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
       {
         wr.has_layers = wr.has_layers || o.type == WR_LAYER;
         wr.has_runs = wr.has_runs || o.type == WR_RUN;
-        wr.has_rt_layers = wr.has_rt_layers || (o.type == WR_LAYER && !wr_layer_shape_is_exact(o.shape));
+        wr.has_rt_layers = wr.has_rt_layers || (o.type == WR_LAYER && policy != WrBuilder::JIT && !wr_layer_shape_is_exact(o.shape));
       }
     }
     wr.tab_rows = b.table(b.rows);
@@ -1651,7 +1760,7 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
     wr.tab_ops = b.reserve((int)wr.ops.size() * 16); // the macro-ops themselves: fetched from LDS, one op ahead
     const int hist_base = (int)wr.blob.size(); // LDS: weights, tables, program | rings
     for (auto& op : wr.ops)
-      if (op.type == WR_LAYER)
+      if (op.type == WR_LAYER || op.type == WR_ARRAY_END_K)
         op.hist += hist_base;
     for (const auto& run : runs)
     {
@@ -1671,17 +1780,55 @@ void build_wr(const WaveNetSpec& wn, Plan& plan)
       throw WrBuilder::Unsupported("more than 156 KB of weights and rings");
     wr.ok = true;
   }
-  catch (const WrBuilder::Unsupported& e)
+}
+
+// nam_wn_reg_kernel's plan: with the fully described ahead-of-time shapes if the model consists of them (the shipped
+// examples: nothing to compile); else, when the caller offers a shape set, with the model's own shapes (the kernel is
+// then compiled for them: wr_jit.cpp); else with the run-time-flag instantiations; else not at all (`why` says why).
+void build_wr(const WaveNetSpec& wn, Plan& plan, WrShapeSet* jit_shapes)
+{
+  WrPlan wr;
+  std::string why;
+  bool done = false;
+  auto attempt = [&](WrBuilder::Policy policy, WrShapeSet* dyn) {
+    if (done)
+      return;
+    try
+    {
+      WrPlan w;
+      build_wr_with(wn, w, policy, dyn);
+      wr = std::move(w);
+      done = true;
+    }
+    catch (const WrBuilder::Unsupported& e)
+    {
+      if (why.empty() || policy == WrBuilder::JIT)
+        why = e.what();
+    }
+  };
+  attempt(WrBuilder::AOT_EXACT_ONLY, nullptr);
+  if (!done && jit_shapes)
+  {
+    WrShapeSet trial = *jit_shapes; // (only a plan that succeeds leaves its shapes in the caller's set)
+    attempt(WrBuilder::JIT, &trial);
+    if (done)
+    {
+      *jit_shapes = std::move(trial);
+      wr.jit = true;
+    }
+  }
+  attempt(WrBuilder::AOT_ANY, nullptr);
+  if (!done)
   {
     wr = WrPlan{};
-    wr.why = e.what();
+    wr.why = why;
   }
   plan.wr = std::move(wr);
   if (plan.wr.ok)
     plan.state_floats = std::max(plan.state_floats, plan.wr.state_floats);
 }
 
-Plan build_wavenet_plan(const WaveNetSpec& wn)
+Plan build_wavenet_plan(const WaveNetSpec& wn, WrShapeSet* jit_shapes)
 {
   validate_wavenet_geometry(wn);
   Plan plan;
@@ -1766,7 +1913,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn)
     build_a1_kt(plan);
     build_a1_il(plan);
   }
-  build_wr(wn, plan);
+  build_wr(wn, plan, jit_shapes);
   return plan;
 }
 
@@ -1875,13 +2022,13 @@ static Plan build_lstm_plan(const ModelSpec& model)
   return plan;
 }
 
-Plan build_plan(const ModelSpec& model)
+Plan build_plan(const ModelSpec& model, WrShapeSet* jit_shapes)
 {
   if (model.arch == ARCH_WAVENET)
   {
     if (model.wavenet.slimmable)
-      return build_wavenet_plan(slim_wavenet(model.wavenet, channels_for_ratio(model.wavenet, 1.0)));
-    return build_wavenet_plan(model.wavenet);
+      return build_wavenet_plan(slim_wavenet(model.wavenet, channels_for_ratio(model.wavenet, 1.0)), jit_shapes);
+    return build_wavenet_plan(model.wavenet, jit_shapes);
   }
   if (model.arch == ARCH_LSTM)
     return build_lstm_plan(model);

@@ -396,7 +396,10 @@ enum WrOpType : int32_t
   // gating / FiLM / head1x1, a parameterless activation): one dispatch for the run, the next layer's weights requested
   // while the current layer computes. `n_in` = layers, `w` = the first layer's weight block (the others follow at the
   // layout's stride), `hist` = LDS float offset of the per-layer records {unused, ring area offset, R, dilation | slot << 24}
-  WR_RUN = 5
+  WR_RUN = 5,
+  // head rechannel WITH TAPS (model.cpp:399-400, 547-548: a Conv1D of kernel size K_h over the head accumulator): the
+  // head accumulator has a ring of its own (`hist`, `ring`, `dil`, `slot` as in WR_LAYER). Per-model compile only.
+  WR_ARRAY_END_K = 6
 };
 
 struct WrOp // 16 x int32 = 64 bytes
@@ -441,37 +444,46 @@ struct WrPlan
   int tab_pf = 0, n_pf = 0; // ... of the one-block prefetch windows
   int tab_ring = 0; // ... of R per slot (n_layers ints, padded to 4)
   int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
+  // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
+  // object compiled for it ("" until nam_hip_api.cpp has prepared it — the plan is not runnable before)
+  bool jit = false;
+  std::string jit_module;
 };
 
-// The layer shapes kernel_wn_reg.hip instantiates — (id, condition size, channels, bottleneck, gating, kernel size,
-// head1x1 outputs (0 = no head1x1), FiLM mask, shift mask, blended, activation, secondary activation). A FiLM mask of
-// -1 leaves the FiLM slots, the blend and the activation types to run-time flags (wavefront-uniform branches); a
-// full description makes the layer one straight-line block the compiler can schedule weight reads across. The first
-// match wins: exact descriptions first.
+// The layer shapes kernel_wn_reg.hip instantiates AHEAD OF TIME — (id, condition size, channels, bottleneck, gating,
+// kernel size, head1x1 outputs (0 = no head1x1), FiLM mask, shift mask, blended, activation, secondary activation,
+// layer1x1 active). A FiLM mask of -1 leaves the FiLM slots, the blend and the activation types to run-time flags
+// (wavefront-uniform branches); a full description makes the layer one straight-line block the compiler can schedule
+// weight reads across. The first match wins: exact descriptions first.
+// Any OTHER model within the kernel's limits (<= 8 channels / condition rows / head1x1 outputs, <= 16 conv outputs,
+// <= 156 KB of weights and rings) gets the same kernel compiled for exactly ITS shapes when it is loaded (wr_jit.cpp: the
+// tables below are then generated per model, NAM_WR_JIT_SHAPES) — the way the reference templates its fast path on the
+// channel count (NAM/wavenet/a2_fast.cpp:57), extended to every layer description.
+#ifndef NAM_WR_JIT_SHAPES
 #define WR_LAYER_SHAPES(X) \
   /* example_models/wavenet_a2_max.nam: main array; its condition_dsp's array 0 and the three layers of array 1 */ \
-  X(0, 8, 4, 4, false, 4, 4, 0xff, 0xff, 0, ACT_SOFTSIGN, ACT_IDENTITY) \
-  X(1, 1, 3, 6, true, 2, 6, 0xff, 0xff, 0, ACT_SILU, ACT_HARDSWISH) \
-  X(2, 1, 4, 2, true, 3, 4, 0xff, 0x00, 1, ACT_PRELU, ACT_LEAKYHARDTANH) \
-  X(3, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_PRELU, ACT_RELU) \
-  X(4, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_SOFTSIGN, ACT_SIGMOID) \
+  X(0, 8, 4, 4, false, 4, 4, 0xff, 0xff, 0, ACT_SOFTSIGN, ACT_IDENTITY, 1) \
+  X(1, 1, 3, 6, true, 2, 6, 0xff, 0xff, 0, ACT_SILU, ACT_HARDSWISH, 1) \
+  X(2, 1, 4, 2, true, 3, 4, 0xff, 0x00, 1, ACT_PRELU, ACT_LEAKYHARDTANH, 1) \
+  X(3, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_PRELU, ACT_RELU, 1) \
+  X(4, 1, 4, 2, true, 3, 4, 0xff, 0x00, 0, ACT_SOFTSIGN, ACT_SIGMOID, 1) \
   /* example_models/slimmable_wavenet.nam at its three widths (plain ReLU layers, dilations 1 .. 512) */ \
-  X(15, 1, 3, 3, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY) \
-  X(16, 1, 2, 2, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY) \
-  X(17, 1, 1, 1, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY) \
-  /* run-time flags: the same shapes with other FiLM sets / activations, plain small stacks (no head1x1), */ \
-  /* example_models/wavenet_condition_dsp.nam, multi-channel fixtures */ \
-  X(5, 8, 4, 4, false, 4, 4, -1, 0, 0, -1, -1) \
-  X(6, 1, 3, 6, true, 2, 6, -1, 0, 0, -1, -1) \
-  X(7, 1, 4, 2, true, 3, 4, -1, 0, 0, -1, -1) \
-  X(8, 1, 4, 4, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(9, 1, 3, 3, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(10, 1, 2, 2, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(11, 1, 8, 8, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(12, 3, 3, 3, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(13, 3, 4, 4, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(14, 3, 2, 2, false, 3, 0, -1, 0, 0, -1, -1) \
-  X(18, 1, 1, 1, false, 3, 0, -1, 0, 0, -1, -1)
+  X(15, 1, 3, 3, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY, 1) \
+  X(16, 1, 2, 2, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY, 1) \
+  X(17, 1, 1, 1, false, 3, 0, 0x00, 0x00, 0, ACT_RELU, ACT_IDENTITY, 1) \
+  /* run-time flags (used when the per-model compile is switched off or unavailable): the same shapes with other FiLM */ \
+  /* sets / activations, plain small stacks (no head1x1), example_models/wavenet_condition_dsp.nam, multi-channel fixtures */ \
+  X(5, 8, 4, 4, false, 4, 4, -1, 0, 0, -1, -1, 1) \
+  X(6, 1, 3, 6, true, 2, 6, -1, 0, 0, -1, -1, 1) \
+  X(7, 1, 4, 2, true, 3, 4, -1, 0, 0, -1, -1, 1) \
+  X(8, 1, 4, 4, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(9, 1, 3, 3, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(10, 1, 2, 2, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(11, 1, 8, 8, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(12, 3, 3, 3, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(13, 3, 4, 4, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(14, 3, 2, 2, false, 3, 0, -1, 0, 0, -1, -1, 1) \
+  X(18, 1, 1, 1, false, 3, 0, -1, 0, 0, -1, -1, 1)
 // plain-layer runs (WR_RUN): (id, channels, activation)
 #define WR_RUN_SHAPES(X) \
   X(0, 1, ACT_RELU) X(1, 2, ACT_RELU) X(2, 3, ACT_RELU) X(3, 4, ACT_RELU) \
@@ -480,9 +492,43 @@ struct WrPlan
 #define WR_PAIR_SHAPES(X) \
   X(0, 1, 3) X(1, 3, 4) X(2, 1, 4) X(3, 6, 4) X(4, 4, 8) X(5, 4, 1) X(6, 4, 4) X(7, 1, 2) X(8, 2, 1) X(9, 3, 1) X(10, 1, 8) \
   X(11, 8, 1) X(12, 8, 4) X(13, 4, 2) X(14, 2, 2) X(15, 3, 3) X(16, 8, 8) X(17, 2, 4) X(18, 3, 2) X(19, 6, 1) X(20, 1, 1) X(21, 2, 3) X(22, 4, 3) X(23, 3, 8) X(24, 2, 8)
-// id of a shape, -1 = not instantiated
+// head rechannels with taps: (id, head accumulator rows, head size, kernel size) — none ahead of time
+#define WR_HEADK_SHAPES(X)
+#endif
+// The shapes of one model (or of all the sub-models of a slimmable one), collected while it is planned, for the
+// per-model compile: ids are positions in these lists.
+struct WrShapeSet
+{
+  struct Layer
+  {
+    int cond, C, B, G, K, HO, flags, act, act2, l1;
+  };
+  struct Run
+  {
+    int C, act;
+  };
+  struct Pair
+  {
+    int n_in, n_out;
+  };
+  struct HeadK
+  {
+    int n_in, n_out, K;
+  };
+  std::vector<Layer> layers;
+  std::vector<Run> runs;
+  std::vector<Pair> pairs;
+  std::vector<HeadK> heads; // head rechannels with kernel size > 1
+  int head(int n_in, int n_out, int K);
+  int layer(int cond, int C, int B, bool G, int K, int HO, int flags, int act, int act2, bool l1);
+  int run(int C, int act);
+  int pair(int n_in, int n_out);
+  bool empty() const { return layers.empty() && runs.empty() && pairs.empty() && heads.empty(); }
+  std::string header_text() const; // the generated tables: "#define NAM_WR_JIT_SHAPES 1 / #define WR_LAYER_SHAPES(X) ..."
+};
+// id of a shape in the ahead-of-time tables, -1 = not instantiated
 int wr_layer_shape(int cond, int channels, int bottleneck, bool gating, int kernel, int head_out, int flags, int act,
-                   int act2);
+                   int act2, bool l1 = true);
 int wr_pair_shape(int n_in, int n_out);
 bool wr_layer_shape_is_exact(int id); // FiLM set, blend and activations compiled in
 int wr_run_shape(int channels, int act);
@@ -591,7 +637,9 @@ struct Plan
 };
 
 // Build the plan for a (non-slimmable view of a) model. Throws std::runtime_error on unsupported shapes.
-Plan build_plan(const ModelSpec& model);
-Plan build_wavenet_plan(const WaveNetSpec& wn);
+// `jit_shapes` (optional): where nam_wn_reg_kernel's plan may register layer shapes the ahead-of-time tables do not
+// hold — the plan then has wr.jit set and needs the kernel compiled for that shape set.
+Plan build_plan(const ModelSpec& model, WrShapeSet* jit_shapes = nullptr);
+Plan build_wavenet_plan(const WaveNetSpec& wn, WrShapeSet* jit_shapes = nullptr);
 
 } // namespace namhip

@@ -1,0 +1,32 @@
+"""Loads every fixture and every seeded feature-rich test model once on this machine (no GPU needed): models whose layer
+shapes are outside nam_wn_reg_kernel's ahead-of-time tables get the kernel compiled for them here, and the code objects
+land in neuralampmodelercore_amd/lib/jit/ — next to the library, so they travel with it (the GPU box then finds them by
+hash instead of compiling). Run by __graft_entry__.build()."""
+import glob, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import neuralampmodelercore_amd as nam
+import make_synthetic_models as msm
+
+
+def main():
+    t0 = time.time()
+    n = acc = 0
+    for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "models", "*.nam"))):
+        for ft in (False, True):
+            nam.get_dsp(p, fast_tanh=ft)
+            n += 1
+    with tempfile.TemporaryDirectory() as tmp:
+        for seed in range(40):  # tests/test_gpu_breadth.py: FEATURED_SEEDS
+            p = os.path.join(tmp, f"featured_{seed}.nam")
+            msm.write_featured(p, 7000 + seed, wr_shapes=bool(seed % 2))
+            m = nam.get_dsp(p, fast_tanh=seed % 3 == 0)
+            acc += bool(m.info.has_a1_kernel & 16)
+            n += 1
+    cache = os.path.join(ROOT, "neuralampmodelercore_amd", "lib", "jit")
+    print(f"warm_jit_cache: {n} loads in {time.time() - t0:.1f} s, {acc} / 40 feature-rich models on nam_wn_reg_kernel, "
+          f"{len(glob.glob(os.path.join(cache, '*.hsaco')))} code objects in {cache}")
+
+
+if __name__ == "__main__":
+    main()
