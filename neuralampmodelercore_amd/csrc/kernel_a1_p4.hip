@@ -218,6 +218,11 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
   f4 sa[MAXJ], sb[MAXJ];
   float inp = 0.0f;
 
+  // PERSIST + WT: a session whose output window is HOST memory (the blocking host entry points, A1Args::p_out_host): the
+  // results are plain stores and one release fence per workgroup publishes them when the launch leaves. (Ring appends stay
+  // write-back as in every session: written through as well, the buffer takes 44 us instead of 37 at 256 streams,
+  // profiles/r03/persist_io_store_scope_variants.txt.) WT without PERSIST: a short launch, ring appends written through.
+  constexpr bool kOutHost = PERSIST && WT;
   constexpr int kInAux = PERSIST ? 17 : 0; // session inputs bypass the caches (the caller may rewrite the buffer between commands)
   auto ring_load = [&](unsigned s_) {
     return __hip_atomic_load(a.p_ring + (s_ & (unsigned)a.p_ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
     {
       const unsigned v = (unsigned)(wpj + (arr1 ? tl_app1 : tl_app0));
       const int widx = (int)min(v, v - (unsigned)J.R);
-      p4_sb_store(x, arr1 ? rs_a1 : rs_a0, widx, (int)gl16, J.ring_b, WT ? 17 : 0);
+      p4_sb_store(x, arr1 ? rs_a1 : rs_a0, widx, (int)gl16, J.ring_b, WT && !PERSIST ? 17 : 0);
     }
     // persistent session, stage 0: every wave looks at the next ring slot in job 1 and, when the command is already
     // there, requests the next buffer's input sample from it in job 3 (unconditional load, out-of-range offset on a miss)
@@ -523,8 +528,12 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
     {
       const float yout = head_scale * mfma_n<NK>(xt, head, ev)[0];
       const bool ok = gl16 == 0 && tl < nvalid;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob,
-                                            uni((int)boff), PERSIST ? 17 : 0);
+      // a session's results: written through to DEVICE memory (sc0 sc1: whoever reads them next may not be ordered
+      // behind this launch's end). To HOST memory such stores complete one at a time (~1 us each, 1 ms per buffer at
+      // 256 streams: profiles/r03/persist_io_store_scope_variants.txt): plain stores there, made visible by the release
+      // fence before the completion word (kOutHost below)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob, uni((int)boff),
+                                            PERSIST && !kOutHost ? 17 : 0);
     }
     else if constexpr ((flags_j & CD_POST_RECH) != 0)
       x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
@@ -685,6 +694,14 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
     // stage's wave 0 knows it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
+    if constexpr (kOutHost)
+    {
+      // system scope: the plain stores to host memory are out. ONE wave per workgroup: the write-back behind the fence is
+      // the whole L2's, not a wave's, and every wave's stores reached L2 in front of the barrier (twelve waves x 256
+      // workgroups each asking for it: +45 us per buffer)
+      if (S == NST - 1 && w == 0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    }
     if (S == NST - 1 && w == 0 && lane == 0)
     {
       a.p_cons[blockIdx.x] = done;
@@ -715,13 +732,14 @@ hipError_t launch_p4_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 template <int C0, int C1>
 hipError_t launch_p4_shape(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
-  if (a.p_ring) // persistent session: write-back ring appends (kernel_a1_p2.hip: launch_p2_shape)
+  if (a.p_ring) // persistent session: write-back ring appends (kernel_a1_p2.hip: launch_p2_shape) ...
   {
+    const bool oh = a.p_out_host != 0; // ... unless its results go to host memory (kOutHost)
     if (act == ACT_FASTTANH)
-      return launch_p4_inst<C0, C1, ACT_FASTTANH, false, true>(a, n_blocks, stream);
+      return oh ? launch_p4_inst<C0, C1, ACT_FASTTANH, true, true>(a, n_blocks, stream) : launch_p4_inst<C0, C1, ACT_FASTTANH, false, true>(a, n_blocks, stream);
     if (act == ACT_TANH)
-      return launch_p4_inst<C0, C1, ACT_TANH, false, true>(a, n_blocks, stream);
-    return launch_p4_inst<C0, C1, -1, false, true>(a, n_blocks, stream);
+      return oh ? launch_p4_inst<C0, C1, ACT_TANH, true, true>(a, n_blocks, stream) : launch_p4_inst<C0, C1, ACT_TANH, false, true>(a, n_blocks, stream);
+    return oh ? launch_p4_inst<C0, C1, -1, true, true>(a, n_blocks, stream) : launch_p4_inst<C0, C1, -1, false, true>(a, n_blocks, stream);
   }
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (device_common.h: ring_store)
   if (act == ACT_FASTTANH)

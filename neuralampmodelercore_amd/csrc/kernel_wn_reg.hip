@@ -214,6 +214,25 @@ __device__ __forceinline__ void wr_mv(f2* acc, const float* in, const WrMat<OUT,
   }
 }
 
+// acc (pairs) += W in  (no bias: the caller seeded acc)
+template <int OUT, int IN>
+__device__ __forceinline__ void wr_mv_acc(f2* acc, const float* in, const WrMat<OUT, IN>& m)
+{
+  constexpr int Q = wr_pad4(OUT) / 4, P = wr_pairs(OUT);
+#pragma unroll
+  for (int i = 0; i < IN; i++)
+  {
+    const f2 xs = f2{in[i], in[i]};
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+    {
+      acc[2 * q] = __builtin_elementwise_fma(f2{m.w[i][q][0], m.w[i][q][1]}, xs, acc[2 * q]);
+      if (2 * q + 1 < P)
+        acc[2 * q + 1] = __builtin_elementwise_fma(f2{m.w[i][q][2], m.w[i][q][3]}, xs, acc[2 * q + 1]);
+    }
+  }
+}
+
 // film.h:76-204 — v[d] = v[d] * scale[d] (+ shift[d]);  scale = Ws cond + bs, shift = Wh cond + bh
 // block at `fb`: Ws [COND][pad4(D)], Wh [COND][pad4(D)], bs [pad4(D)], bh [pad4(D)]
 template <int D, int COND>
@@ -347,7 +366,10 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
   WrFilm<COND, COND> f_mpre;
   WrMat<ZC, COND> m_mix;
   WrFilm<ZC, COND> f_mpost, f_cpost, f_apre;
-  WrMat<ZC, K * C> m_conv;
+  // the conv matrix [K * C][pad4(ZC)]: whole in registers while the taps arrive — or, for long kernels / wide layers
+  // (more than 256 weights per lane), tap by tap, so that a per-model build never spills its way through a layer
+  constexpr bool kConvByTap = K * C * wr_pad4(ZC) > 256;
+  WrMat<ZC, kConvByTap ? C : K * C> m_conv;
   WrFilm<B, COND> f_apost;
   WrActP<G ? B : ZC> a_1;
   WrActP<B> a_2;
@@ -415,7 +437,7 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
     for (int i = 0; i < COND; i++)
       mi[i] = r.cond[i];
   }
-  wr_ld(m_conv, lds, wb + L.conv * 4u, true, wb + L.conv_b * 4u);
+  wr_ld(m_conv, lds, wb + L.conv * 4u, true, wb + L.conv_b * 4u); // (by tap: tap 0 and the bias)
   wr_fence();
   f2 m[wr_pairs(ZC)];
   wr_mv(m, mi, m_mix);
@@ -431,6 +453,16 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
   // Step 1b: the convolution (+ post FiLM); z = conv + mixin — model.cpp:189-221
   f2 z[wr_pairs(ZC)];
   wr_mv(z, taps, m_conv);
+  if constexpr (kConvByTap)
+  {
+#pragma unroll
+    for (int k = 1; k < K; k++)
+    {
+      wr_ld(m_conv, lds, wb + (unsigned)(L.conv + k * C * wr_pad4(ZC)) * 4u, false, 0u);
+      wr_fence();
+      wr_mv_acc(z, taps + k * C, m_conv);
+    }
+  }
   wr_ld(a_1, lds, wb + L.act * 4u);
   if constexpr (G)
     wr_ld(a_2, lds, wb + L.act2 * 4u);

@@ -102,6 +102,8 @@ struct A1Args
   long long p_seq0; // >= 0: every workgroup has consumed exactly this many commands (p_cons is not read) ...
   unsigned long long p_cmd0; // ... and this is the next command (the ring is not read for it)
   int p_grace; // ticks (100 MHz) a fresh launch looks for its first doorbell before it leaves again
+  int p_out_host; // the session's output window is HOST memory (nam_a1_p4_kernel: kOutHost — plain result stores, ring
+                  // appends written through, one system-scope release fence before the completion word)
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 

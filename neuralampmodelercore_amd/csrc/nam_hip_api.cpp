@@ -148,6 +148,7 @@ struct PersistSession
   unsigned seq = 0; // commands submitted in this session
   const float* in_base = nullptr;
   float* out_base = nullptr;
+  bool out_is_host = false; // the output window is host memory (A1Args::p_out_host)
   long stride = 0;
   int n_wg = 0; // workgroups of the session's launch
   int kind = -1; // PersistKind
@@ -175,8 +176,12 @@ struct nam_hip_batch
   // host-mapped staging of the blocking entry points in persistent mode: the session's kernel reads the input from and
   // writes the output to host memory itself (its input loads / output stores are system-scope anyway), so a blocking
   // call is: copy in, store the command(s), watch the completion words, copy out — no launch of a copy, no stream sync
-  float *h_in_map = nullptr, *h_out_map = nullptr; // host addresses
-  float *d_in_map = nullptr, *d_out_map = nullptr; // the same memory as the device sees it
+  // input: FINE-GRAINED DEVICE memory the host writes through the PCIe BAR (posted writes; the device then reads local
+  // HBM — device reads of host memory serialise at a microsecond or two per wavefront: 1.9 ms per buffer at 256 streams);
+  // output: host-mapped memory the device writes (posted writes again), read by the host from its own DRAM
+  float* in_bar = nullptr; // one address for both sides
+  float *h_out_map = nullptr, *d_out_map = nullptr; // host address / the same memory as the device sees it
+  bool map_failed = false; // the allocation was refused once: the copying path stays
   int kernel = NAM_HIP_KERNEL_AUTO;
   long long* dbg = nullptr; // device buffer of the profiling instantiation (nam_hip_batch_debug_timeline)
   bool was_reset = false;
@@ -592,6 +597,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.p_ring_mask = 0;
       a.p_cons = a.p_prog = a.p_done = nullptr;
       a.p_grace = 0;
+      a.p_out_host = 0;
       a.p_seq0 = -1;
       a.p_cmd0 = 0;
       if (kernel == NAM_HIP_KERNEL_A1_IL)
@@ -622,6 +628,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_prog = b->ps.d_words;
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
+          a.p_out_host = b->ps.out_is_host ? 1 : 0;
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
@@ -819,6 +826,7 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
 
 // ---- persistent block mode -------------------------------------------------------------------------------------
 constexpr int kGraceUs = 40; // how long a fresh launch looks for the doorbell it was started for
+constexpr int kPersistMaxFrames = 2048; // buffers up to this long go through the session as n_frames / 64 commands
 // the state layout the session's kernel keeps (WaveNets only)
 int persist_family(const nam_hip_batch* b, const WidthGroup& g)
 {
@@ -1072,6 +1080,17 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
   }
   ps.in_base = d_in;
   ps.out_base = d_out;
+  {
+    // where the results go decides how nam_a1_p2 / p4 store them (A1Args::p_out_host)
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, d_out) == hipSuccess)
+      ps.out_is_host = at.type == hipMemoryTypeHost;
+    else
+    {
+      (void)hipGetLastError(); // (an address the runtime does not know: treated as device memory)
+      ps.out_is_host = false;
+    }
+  }
   ps.stride = stride;
   ps.done_off = b->n_streams;
   ps.n_wg = kind == PERSIST_LSTM_ROW ? (n + 3) / 4 : n;
@@ -1087,7 +1106,8 @@ int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long
 // 64 ... 1,024) is that many commands, submitted back to back: the session renders them without a kernel boundary in between.
 int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_frames, long stride, hipStream_t caller)
 {
-  if (n_frames <= 0 || n_frames % kBlock != 0)
+  // (longer calls — an offline render of a whole file — are one resident launch of their own: same kernel, no commands)
+  if (n_frames <= 0 || n_frames % kBlock != 0 || n_frames > kPersistMaxFrames)
     return 1;
   for (int f = 0; f < n_frames; f += kBlock)
   {
@@ -1335,33 +1355,44 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
 // n_frames not a multiple of 64), < 0 on failure.
 int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_f64, float* out_f32, double* out_f64, int n_frames)
 {
-  if (!b->ps.enabled || n_frames % kBlock != 0 || !persist_eligible(b))
+  if (!b->ps.enabled || n_frames % kBlock != 0 || n_frames > kPersistMaxFrames || !persist_eligible(b))
     return 1;
   for (auto& g0 : b->groups)
     if (!g0.streams.empty() && g0.plan->arch == ARCH_WAVENET && g0.state_family >= 0 && g0.state_family != persist_family(b, g0))
       return 1; // (the copying path reports the layout clash)
   const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
   const long stride = b->max_frames;
-  if (!b->h_in_map)
+  if (b->map_failed)
+    return 1;
+  if (!b->in_bar)
   {
     const size_t in_floats = (size_t)b->n_streams * ic * b->max_frames, out_floats = (size_t)b->n_streams * oc * b->max_frames;
-    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_in_map), in_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&b->in_bar), in_floats * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      b->in_bar = nullptr;
+      b->map_failed = true; // no host-writable device memory here
+      return 1;
+    }
     NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_out_map), out_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
-    NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_in_map), b->h_in_map, 0));
     NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_out_map), b->h_out_map, 0));
   }
   const size_t rows_in = (size_t)b->n_streams * ic, rows_out = (size_t)b->n_streams * oc;
   for (size_t r = 0; r < rows_in; r++)
   {
-    float* dst = b->h_in_map + r * stride;
+    float* dst = b->in_bar + r * stride;
     if (in_f32)
       std::memcpy(dst, in_f32 + r * n_frames, (size_t)n_frames * sizeof(float));
     else // double -> float exactly as _set_condition_array does (NAM/wavenet/model.cpp:817)
       for (int i = 0; i < n_frames; i++)
         dst[i] = (float)in_f64[r * n_frames + i];
   }
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  const int rc = persist_submit(b, b->d_in_map, b->d_out_map, n_frames, stride, b->stream);
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_sfence(); // (write-combining stores through the BAR: out before the command that points at them)
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+  const int rc = persist_submit(b, b->in_bar, b->d_out_map, n_frames, stride, b->stream);
   if (rc != NAM_HIP_OK)
     return rc < 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: the host-mapped buffer was refused");
   const int rw = persist_flush(b, b->stream);
@@ -1724,8 +1755,8 @@ void nam_hip_batch_destroy(nam_hip_batch* batch)
     (void)hipFree(batch->d_out);
   if (batch->h_stage)
     (void)hipHostFree(batch->h_stage);
-  if (batch->h_in_map)
-    (void)hipHostFree(batch->h_in_map);
+  if (batch->in_bar)
+    (void)hipFree(batch->in_bar);
   if (batch->h_out_map)
     (void)hipHostFree(batch->h_out_map);
   if (batch->stream)
@@ -1927,6 +1958,8 @@ int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float
                            (size_t)n_frames[s] * sizeof(float), ic, hipMemcpyHostToDevice, batch->stream);
   if (e == hipSuccess)
     rc = nam_hip_batch_process_device(batch, d_in, d_out, (int)T, T, nullptr);
+  if (e == hipSuccess && rc == NAM_HIP_OK && batch->ps.active) // (a short render went through the session: it ends here —
+    rc = persist_stop(batch);                                   // the window is about to be freed)
   for (int s = 0; s < N && e == hipSuccess && rc == NAM_HIP_OK; s++)
     if (n_frames[s] > 0)
       e = hipMemcpy2DAsync(out[s], (size_t)n_frames[s] * sizeof(float), d_out + (size_t)s * oc * T, (size_t)T * sizeof(float),

@@ -1450,6 +1450,10 @@ struct WrBuilder
           throw Unsupported("a PReLU whose slope count does not divide the channel count");
         if (zc > 16 || C > kWrRegs || HO > kWrRegs || cond_dim > kWrRegs)
           throw Unsupported("a layer wider than the register files");
+        // the layer keeps its whole conv matrix in registers while the taps arrive ([K * C][pad4(zc)] floats per lane)
+        // (its taps stay in registers for the whole layer: K * C floats per lane)
+        if (K * C > 64)
+          throw Unsupported("a conv of more than 64 tap inputs (kernel size " + std::to_string(K) + " x " + std::to_string(C) + " channels)");
         int flags = gm == GATING_BLENDED ? (1 << 16) : 0;
         for (int k = 0; k < FILM_COUNT; k++)
           if (A.film[k].active && !(k == FILM_HEAD1X1_POST && !A.head1x1_active))
@@ -1558,8 +1562,8 @@ struct WrBuilder
       {
         // a Conv1D over the head accumulator: [K_h * HO][pad4(head size)] (row = tap * HO + input) + bias, its own ring
         const int KH = A.head_kernel_size;
-        if (KH * HO > 64)
-          throw Unsupported("a head rechannel of more than 64 tap inputs");
+        if (KH * HO > 64 || KH * HO * wr_pad4(A.head_size) > 320)
+          throw Unsupported("a head rechannel of more than 64 tap inputs / 320 weights");
         const int off = reserve(KH * HO * wr_pad4(A.head_size) + wr_pad4(A.head_size));
         dense(&wr.blob[(size_t)off], w, HO, A.head_size, KH, 1);
         if (A.head_bias)

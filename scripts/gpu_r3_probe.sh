@@ -1,0 +1,27 @@
+#!/bin/bash
+# where may a persistent session's buffers live (tools/persist_io_probe.py), then the adapter's round trips
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export NAM_HIP_PERSIST_TIMEOUT_MS=8000
+timeout 900 python -m pytest tests/test_gpu_breadth.py tests/test_gpu_parity.py -m gpu -q --timeout=600 -p no:cacheprovider -k "persistent or cpp or adapter or render or pipelined" > gpurun_out/r3_probe_tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/r3_probe_tests.log
+tail -5 gpurun_out/r3_probe_tests.log
+{
+timeout 200 python tools/persist_io_probe.py tests/golden/models/wavenet_a1_standard.nam 256 64 2>&1 | grep -v amdgpu.ids
+timeout 200 python tools/persist_io_probe.py tests/golden/models/wavenet_a1_standard.nam 1 64 2>&1 | grep -v amdgpu.ids
+} 2>&1 | tee gpurun_out/r3_io_probe_after.txt
+{
+for m in wavenet_a1_standard lstm wavenet_a2_max; do
+  for buf in 64 128 256; do
+    for np_ in 0 1; do
+      echo "== benchmodel $m buffer $buf NAM_HIP_NO_PERSISTENT=$np_ (1 stream, nam::DSP::process)"
+      NAM_HIP_NO_PERSISTENT=$np_ timeout 120 cpp/tools/benchmodel tests/golden/models/$m.nam --buffer $buf 2>&1 | grep -i "round trip\|x real\|ms$" | head -3
+    done
+  done
+  for buf in 64 256; do
+    echo "== benchmodel $m 256 streams host buffers, buffer $buf, persistent / launch per buffer"
+    timeout 120 cpp/tools/benchmodel tests/golden/models/$m.nam --streams 256 --buffer $buf 2>&1 | grep -i "round trip\|x real" | head -3
+    NAM_HIP_NO_PERSISTENT=1 timeout 120 cpp/tools/benchmodel tests/golden/models/$m.nam --streams 256 --buffer $buf 2>&1 | grep -i "round trip\|x real" | head -3
+  done
+done
+} 2>&1 | tee gpurun_out/r3_adapter_roundtrip.txt

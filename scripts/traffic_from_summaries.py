@@ -14,6 +14,8 @@ RUNS = [  # (summary tag, kernel function, model, streams, launch)
     ("r02", "c5_wn_reg", "nam_wn_reg_kernel", "slimmable_wavenet", 768, "block"),
     ("r02", "c4_generic", "nam_generic_kernel", "wavenet_a2_max", 512, "block"),
     ("r02", "c2_valu", "nam_a1_kernel", "wavenet_a1_standard", 256, "block"),
+    # round 3: config 4 again (conv-by-tap / shape-set changes since round 2; the container model is an exact ahead-of-time shape set)
+    ("r03", "c4_wn_reg", "nam_wn_reg_kernel", "wavenet_a2_max", 512, "block"),
 ]
 
 
@@ -51,6 +53,7 @@ for rnd, tag, kernel, model, streams, launch in RUNS:
         print("no counters for", tag, file=sys.stderr)
         continue
     fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+    entries = [e for e in entries if (e["kernel"], e["model"], e["streams"], e["launch"]) != (kernel, model, streams, launch)]
     entries.append({
         "kernel": kernel, "model": model, "streams": streams, "block": 64, "launch": launch,
         "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
@@ -64,6 +67,33 @@ for rnd, tag, kernel, model, streams, launch in RUNS:
                 f"(gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE {write_kb:,.0f} KB, separate "
                 "--pmc passes; the persistent block mode runs the same kernel body per command",
         "lds_note": "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE, per launch (kernel-trace only)",
+    })
+# round 3: nam_a1_p4_kernel pipelines CONSECUTIVE buffers, so a single 64-frame launch never runs it: its counters come
+# from a resident launch (one dispatch = 300 steps; scripts/resident_counters.py keeps the dispatches apart) divided by 300.
+# The persistent block mode's session launch runs the same loop body per command.
+RESIDENT = [("r03", "counters_c2_p4_resident.json", "nam_a1_p4_kernel", "wavenet_a1_standard", 256, 300),
+            ("r03", "counters_c2_p4_resident_b.json", "nam_a1_p4_kernel", "wavenet_a1_standard", 256, 300)]
+for rnd, name, kernel, model, streams, steps in RESIDENT:
+    path = os.path.join(ROOT, "profiles", rnd, name)
+    if not os.path.exists(path):
+        continue
+    d = max(json.load(open(path))["dispatches"], key=lambda x: x["ns"])  # the K-step launch
+    per = lambda k: None if d.get(k) is None else d[k] / steps
+    entries = [e for e in entries if not (e["kernel"] == kernel and e["model"] == model and e["streams"] == streams)]
+    entries.append({
+        "kernel": kernel, "model": model, "streams": streams, "block": 64, "launch": "block",
+        "hbm_bytes_per_launch": int((2 * per("FETCH_SIZE") + per("WRITE_SIZE")) * 1024),
+        "kernel_cycles": per("GRBM_GUI_ACTIVE"),
+        "lds_idx_active_cycles": per("SQ_LDS_IDX_ACTIVE"),
+        "lds_bank_conflict_cycles": per("SQ_LDS_BANK_CONFLICT"),
+        "insts_per_launch": {k: per("SQ_INSTS_" + k) for k in ("VALU", "SALU", "SMEM", "LDS", "VMEM_RD", "VMEM_WR")},
+        "mfma_mops_f32": per("SQ_INSTS_VALU_MFMA_MOPS_F32"),
+        "rocprof_avg_launch_us": round(d["ns"] / steps / 1e3, 3),
+        "note": f"profiles/{rnd}/{name}: ONE resident launch of {steps} steps (rocprofv3 --kernel-trace: {d['ns'] / 1e3:,.0f} us), every counter "
+                f"divided by {steps} -> per 64-frame step: FETCH_SIZE {per('FETCH_SIZE'):,.0f} KB x2 (gfx950 reports half of wide coalesced "
+                f"reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE {per('WRITE_SIZE'):,.0f} KB, separate --pmc passes; the kernel pipelines "
+                "consecutive buffers, so a lone 64-frame launch never runs it; the persistent block mode runs the same loop body per command",
+        "lds_note": "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE of the resident launch / steps",
     })
 json.dump({"entries": entries}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for e in entries:

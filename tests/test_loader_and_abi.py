@@ -41,7 +41,8 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
 
 
 @pytest.mark.parametrize("name,bits", [
-    ("wavenet_a1_standard", 15), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3), ("synth_kt_c4", 3),
+    ("wavenet_a1_standard", 15), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3),
+    ("synth_kt_c4", 19),  # (4 channels, 2 taps per layer: small enough for nam_wn_reg_kernel compiled for its shapes; AUTO keeps the matrix cores)
     ("synth_a1_mixed", 7),  # kernel size 3 everywhere, several arrays: the wave-specialised + interleaved MFMA kernels
     ("synth_a1_nano", 17),  # 4 -> 2 channels: VALU kernel, and nam_wn_reg_kernel's plain-layer runs (68 KB of LDS rings)
     ("synth_a1_lite", 15), ("synth_a1_c14", 7),

@@ -12,6 +12,8 @@ import make_synthetic_models as msm
 def main():
     t0 = time.time()
     n = acc = 0
+    cache = os.path.join(ROOT, "neuralampmodelercore_amd", "lib", "jit")
+    stamp = time.time() - 1.0  # code objects a load below neither built nor found are stale (their sources changed): pruned
     for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "models", "*.nam"))):
         for ft in (False, True):
             nam.get_dsp(p, fast_tanh=ft)
@@ -23,9 +25,13 @@ def main():
             m = nam.get_dsp(p, fast_tanh=seed % 3 == 0)
             acc += bool(m.info.has_a1_kernel & 16)
             n += 1
-    cache = os.path.join(ROOT, "neuralampmodelercore_amd", "lib", "jit")
+    pruned = 0
+    for f in glob.glob(os.path.join(cache, "*")):  # (a hit refreshes the file's time stamp, wr_jit.cpp)
+        if os.path.getmtime(f) < stamp:
+            os.remove(f)
+            pruned += 1
     print(f"warm_jit_cache: {n} loads in {time.time() - t0:.1f} s, {acc} / 40 feature-rich models on nam_wn_reg_kernel, "
-          f"{len(glob.glob(os.path.join(cache, '*.hsaco')))} code objects in {cache}")
+          f"{len(glob.glob(os.path.join(cache, '*.hsaco')))} code objects in {cache} ({pruned} stale files pruned)")
 
 
 if __name__ == "__main__":
