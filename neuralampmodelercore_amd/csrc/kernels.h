@@ -168,6 +168,9 @@ hipError_t launch_a1_il(const A1Args& a, int n_blocks, int act, hipStream_t stre
 hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
 // nam_a1_p4_kernel: the same models as a pipeline of wave sets decoupled through LDS (kernel_a1_p4.hip)
 hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
+// nam_kp_kernel (kernel_kp.hip): the A2 topology (kp_table.h) as a pipeline of wave sets; a.tiles_off / consts_off / r1_off =
+// blob offsets of the K-tap kernel's tap tiles, LDS block and rechannel column
+hipError_t launch_kp(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,
                           hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);

@@ -326,7 +326,8 @@ enum PersistKind : int
   PERSIST_A1_P2 = 0, // nam_a1_p4_kernel (nam_a1_p2_kernel with NAM_HIP_NO_PIPE=1): one workgroup (most of a CU's LDS) per stream
   PERSIST_WN_REG = 1, // nam_wn_reg_kernel: one wavefront per stream
   PERSIST_LSTM_ROW = 2, // nam_lstm_row_kernel: one wavefront per four streams
-  PERSIST_LSTM_WIDE = 3 // nam_lstm_wide_kernel: one wavefront per stream
+  PERSIST_LSTM_WIDE = 3, // nam_lstm_wide_kernel: one wavefront per stream
+  PERSIST_KP = 4 // nam_kp_kernel (the A2 topology): one workgroup (most of a CU's LDS) per stream, as PERSIST_A1_P2
 };
 int persist_kind(const nam_hip_batch* b);
 int persist_family(const nam_hip_batch* b, const WidthGroup& g);
@@ -353,6 +354,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
     switch (persist_kind(b)) // persistent block mode
     {
       case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : "nam_a1_p4_kernel";
+      case PERSIST_KP: return "nam_kp_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
       case PERSIST_LSTM_WIDE: return "nam_lstm_wide_kernel";
@@ -367,7 +369,8 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
       case NAM_HIP_KERNEL_A1_IL:
         return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_pipe && n_frames > kBlock) ? "nam_a1_p4_kernel" : "nam_a1_p2_kernel") : "nam_a1_il_kernel";
-      default: return p.a1.ws_ok ? "nam_a1_mfma_kernel" : "nam_kt_mfma_kernel";
+      default:
+        return p.a1.ws_ok ? "nam_a1_mfma_kernel" : (p.a1.kp_ok && !b->no_pipe && n_frames > kBlock) ? "nam_kp_kernel" : "nam_kt_mfma_kernel";
     }
   }
   const LSTMPlan& L = p.lstm;
@@ -644,6 +647,28 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
         // the K-tap kernel addresses the launch's input through a 32-bit buffer descriptor (1 GiB of float32 audio per
         // stream and launch): longer launches take the VALU kernel, same state layout
         NAM_HIP_CHECK(launch_a1(a, n, s));
+      else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && p.a1.kp_ok && use_pipeline(b, n_frames))
+      {
+        // the A2 topology with more than one buffer in the launch (a session, a render, a prewarm): the pipeline of wave
+        // sets compiled for it (kernel_kp.hip); same state, tiles and constants as the K-tap kernel below
+        a.tiles_off = p.a1.kt_desc[0].tile_off;
+        a.consts_off = p.a1.kt_lds_src_off;
+        a.r1_off = p.a1.kt_rech_off;
+        a.act = p.a1.arr[0].act;
+        if (b->ps_launching)
+        {
+          a.p_ring = b->ps.d_ring;
+          a.p_ring_mask = (int)kPRing - 1;
+          a.p_cons = b->ps.d_cons;
+          a.p_prog = b->ps.d_words;
+          a.p_done = b->ps.d_words + b->ps.done_off;
+          a.p_grace = b->ps.grace;
+          a.p_out_host = b->ps.out_is_host ? 1 : 0;
+          a.p_seq0 = b->ps.seq0;
+          a.p_cmd0 = b->ps.cmd0;
+        }
+        NAM_HIP_CHECK(launch_kp(a, n, p.a1.arr[0].act, s));
+      }
       else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok)
         // single-array models with other kernel sizes than 3 (A2): the K-tap MFMA kernel
         NAM_HIP_CHECK(launch_kt_mfma(a, n, p.a1.kt_nk, p.a1.arr[0].channels, p.a1.kt_lds_floats, p.a1.arr[0].act, s));
@@ -862,6 +887,9 @@ int persist_kind(const nam_hip_batch* b)
     if (!b->il_generic && g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= cus
         && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL))
       return PERSIST_A1_P2;
+    if (!b->no_pipe && g.plan->a1.valid && g.plan->a1.kp_ok && !g.plan->a1.ws_ok && b->n_streams <= cus
+        && pick_kernel(b, g) == NAM_HIP_KERNEL_A1_MFMA)
+      return PERSIST_KP;
     return PERSIST_NONE;
   }
   if (g.plan->arch == ARCH_LSTM && b->kernel == NAM_HIP_KERNEL_AUTO)
@@ -1569,7 +1597,7 @@ int64_t nam_hip_model_get_string(const nam_hip_model* model, int field, char* bu
         text += (i ? " | plan " : "plan ") + std::to_string(i) + ": " + p.describe();
         if (p.arch == ARCH_WAVENET)
           text += std::string(" a1_valu=") + (p.a1.valid ? "1" : "0") + " a1_mfma=" + ((p.a1.valid && p.a1.ws_ok) ? "1" : "0")
-                  + " kt_mfma=" + ((p.a1.valid && p.a1.kt_ok) ? "1" : "0") + " a1_il=" + ((p.a1.valid && p.a1.il_ok) ? "1" : "0")
+                  + " kt_mfma=" + ((p.a1.valid && p.a1.kt_ok) ? "1" : "0") + " kp=" + ((p.a1.valid && p.a1.kp_ok) ? "1" : "0") + " a1_il=" + ((p.a1.valid && p.a1.il_ok) ? "1" : "0")
                   + " a1_p2=" + ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? "1" : "0")
                   + (p.wr.ok ? std::string(" wn_reg=1") : " wn_reg=0 (" + p.wr.why + ")");
       }

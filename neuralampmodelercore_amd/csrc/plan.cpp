@@ -8,6 +8,7 @@
 // and the weight blob is built by walking the flat weight stream in set_weights_ order
 // (model.cpp:152-181, 563-569, 661-683; Conv1D conv1d.cpp:40-55; Conv1x1 dsp.cpp:384-397).
 #include "plan.h"
+#include "kp_table.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1135,6 +1136,38 @@ void build_a1_kt(Plan& plan)
   a1.kt_ok = 1;
 }
 
+// nam_kp_kernel (kernel_kp.hip) is compiled for ONE topology (kp_table.h: by default the A2 stack the reference's fused
+// path is written for, a2_fast.cpp:57-764): it may run a model only when the K-tap kernel's plan of that model is, layer by
+// layer, what the kernel's compile-time tables say — kernel sizes, dilations, ring geometry and offsets, chunk and tile
+// offsets, the LDS block.
+void build_a1_kp(Plan& plan)
+{
+  A1Plan& a1 = plan.a1;
+  a1.kp_ok = 0;
+  if (!a1.valid || !a1.kt_ok || a1.kt_nk != 2 || a1.n_arrays != 1)
+    return;
+  const A1Array& A = a1.arr[0];
+  if (A.channels != kp::kC || A.n_layers != kp::kLayers || A.head_k != kp::kKs[kp::kLayers] || A.head_dil != kp::kDs[kp::kLayers]
+      || A.head_ring_id != kp::kLayers || a1.n_rings != kp::kJobs || a1.kt_chunks != kp::kChunks
+      || a1.kt_lds_floats != kp::kLayers * 128 + kp::kJobs * 48)
+    return;
+  for (int l = 0; l < kp::kLayers; l++)
+    if (A.ksize[l] != kp::kKs[l] || A.dil[l] != kp::kDs[l] || A.ring_id[l] != l || A.ring_len[l] != kp::ring_len(l)
+        || A.ring_off[l] != kp::ring_off(l))
+      return;
+  if (A.head_ring_len != kp::ring_len(kp::kLayers) || A.head_ring_off != kp::ring_off(kp::kLayers))
+    return;
+  const int tiles0 = a1.kt_desc[0].tile_off;
+  for (int j = 0; j < kp::kJobs; j++)
+  {
+    const KtDesc& D = a1.kt_desc[kp::chunk0(j)];
+    if (D.tile_off != tiles0 + kp::chunk0(j) * kKtTaps * 128 || !(D.flags & KT_FIRST) || D.ring_b != kp::ring_off(j) * 4 || D.R != kp::ring_len(j)
+        || D.consts_off != kp::kLayers * 512 + j * 192 || (j < kp::kLayers && D.w1_off != j * 512))
+      return;
+  }
+  a1.kp_ok = 1;
+}
+
 // The official "lite" size (12 -> 6 channels) misses the matrix-core kernel only because 6 is not a multiple of 4.
 // Zero-padding such arrays to the next multiple (weights, biases, mixin, rechannels all zero for the extra channels)
 // is exact on the real channels: the padded ones carry f(0) through the activations and meet zero weights everywhere.
@@ -1915,6 +1948,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn, WrShapeSet* jit_shapes)
       plan.a1.vdesc[j].f_rbase += table * 4;
     }
     build_a1_kt(plan);
+    build_a1_kp(plan);
     build_a1_il(plan);
   }
   build_wr(wn, plan, jit_shapes);
