@@ -262,14 +262,17 @@ def cpu_worker(argv):
 
 
 def run_other_configs(args):
-    """Brief runs of BASELINE.json configs 3, 4, 5 for the default line (`other_configs`): one subprocess each (a failure
+    """Brief runs of BASELINE.json configs 3, 4, 5 (+ A2-Full) for the default line (`other_configs`): one subprocess each (a failure
     of one cannot take the headline with it), `--brief`: 500 timed steps x 11 regions, no side runs, ~2 s CPU baseline."""
     import subprocess
     keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "max_abs_err_vs_oracle", "cpu_baseline",
             "finite", "region_us")
     res = {}
-    for c in (3, 4, 5):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--gpus", "1", "--steps", "500", "--warmup", "50",
+    # "A2": not a BASELINE.json config — the reference's own flagship shape (A2.nam's A2-Full submodel, what its fused
+    # wavenet/a2_fast.cpp path is written for), 256 streams, same protocol
+    for c in (3, 4, 5, "A2"):
+        sel = ["--model", "A2", "--streams", "256"] if c == "A2" else ["--config", str(c)]
+        cmd = [sys.executable, os.path.abspath(__file__)] + sel + ["--gpus", "1", "--steps", "500", "--warmup", "50",
                "--brief", "--persistent", str(args.persistent), "--fast-tanh", str(args.fast_tanh)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
@@ -282,7 +285,7 @@ def run_other_configs(args):
                 continue
             j = json.loads(line[-1])
             r = {k: j.get(k) for k in keep}
-            r["workload"] = CONFIGS[c]["name"]
+            r["workload"] = "A2.nam (A2-Full), 256 streams, buffer 64" if c == "A2" else CONFIGS[c]["name"]
             r["run_s"] = round(time.perf_counter() - t0, 1)
             res[str(c)] = r
         except Exception as e:  # noqa: BLE001

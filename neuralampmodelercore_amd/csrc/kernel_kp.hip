@@ -42,7 +42,11 @@ namespace kp
 {
 constexpr int kNoRow = 1 << 26; // a ring row index no descriptor holds: the access is dropped / returns 0
 constexpr int kRows = 1 << 20; // num_records of the ring descriptor (rows); every real row index is far below
-constexpr int kAhead = 2; // a job's ring rows are requested this many jobs earlier (of the same stage, wrapping to the next buffer)
+constexpr int kActLeakyMax = 100; // ACT_T of the LeakyReLU instantiation (slope <= 1)
+#ifndef NAM_KP_AHEAD
+#define NAM_KP_AHEAD 2
+#endif
+constexpr int kAhead = NAM_KP_AHEAD; // a job's ring rows are requested this many jobs earlier (of the same stage, wrapping to the next buffer)
 constexpr int kRowB = (kC + 4) * 4; // LDS pitch of a published frame row
 constexpr int kBufB = (kBlock + 1) * kRowB; // one published buffer: row 0 = zeros, row 1 + t = frame t
 // LDS layout (bytes)
@@ -386,7 +390,8 @@ __global__ __launch_bounds__(NST * 256) void nam_kp_kernel(const float* __restri
             else
             {
               const unsigned ra = (unsigned)max((int)rd_b[RB] - L * kp::kRowB, (int)rd_lo[RB]);
-              bq = *reinterpret_cast<const f2*>(lds + ra) + Rj.r[j]; // exactly one of the two is the operand, the other is 0
+              // exactly one of the two is the operand, the other is 0
+              bq = *reinterpret_cast<const f2*>(lds + ra) + Rj.r[j];
             }
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tt[2 * h], bq[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tt[2 * h + 1], bq[1], acc, 0, 0, 0);
@@ -415,7 +420,11 @@ __global__ __launch_bounds__(NST * 256) void nam_kp_kernel(const float* __restri
     {
       const f4 b1v = lds_ld4(lds, (unsigned)kp::kConstB(JI) + 128u + quad_b);
       const f2 w1 = *reinterpret_cast<const f2*>(lds + (unsigned)kp::kW1B(JI) + (unsigned)lane * 8u);
-      const f4 z = act4<ACT_T>(act, acc, act_p0);
+      f4 z;
+      if constexpr (ACT_T == kp::kActLeakyMax) // LeakyReLU with a slope <= 1: max(v, slope * v) (launch_kp checks the slope)
+        z = __builtin_elementwise_max(acc, acc * act_p0);
+      else
+        z = act4<ACT_T>(act, acc, act_p0);
       head += z;
       asm volatile("" : "+v"(head)); // (pin the accumulator: kernel_a1_p2.hip)
       f4 y = x + b1v;
@@ -628,8 +637,8 @@ hipError_t launch_kp_act(const A1Args& a, int n_blocks, hipStream_t stream)
 // constants) and of the rechannel column; a.act: the array's activation
 hipError_t launch_kp(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
-  if (act == ACT_LEAKYRELU)
-    return launch_kp_act<ACT_LEAKYRELU>(a, n_blocks, stream);
+  if (act == ACT_LEAKYRELU && a.act_p0 <= 1.0f) // (A2: 0.01)
+    return launch_kp_act<kp::kActLeakyMax>(a, n_blocks, stream);
   return launch_kp_act<-1>(a, n_blocks, stream);
 }
 
