@@ -851,6 +851,7 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
 
 // ---- persistent block mode -------------------------------------------------------------------------------------
 constexpr int kGraceUs = 40; // how long a fresh launch looks for the doorbell it was started for
+constexpr int kPersistTurns = 8; // one-workgroup-per-stream sessions: at most this many streams per CU (they take turns on the chip)
 constexpr int kPersistMaxFrames = 2048; // buffers up to this long go through the session as n_frames / 64 commands
 // the state layout the session's kernel keeps (WaveNets only)
 int persist_family(const nam_hip_batch* b, const WidthGroup& g)
@@ -884,10 +885,15 @@ int persist_kind(const nam_hip_batch* b)
     return PERSIST_NONE;
   if (g.plan->arch == ARCH_WAVENET)
   {
-    if (!b->il_generic && g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= cus
+    // One workgroup per stream holding most of a CU's LDS: `cus` of them are on the chip at once. More streams than
+    // that still make a session — the workgroups never wait for a command, so the resident ones drain the ring and
+    // leave, the next ones start behind them and consume the same commands (every workgroup resumes from its own
+    // count) — in as many turns as it takes; bounded so that the completion words stay a short scan for the host.
+    const int wg_limit = kPersistTurns * cus;
+    if (!b->il_generic && g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= wg_limit
         && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL))
       return PERSIST_A1_P2;
-    if (!b->no_pipe && g.plan->a1.valid && g.plan->a1.kp_ok && !g.plan->a1.ws_ok && b->n_streams <= cus
+    if (!b->no_pipe && g.plan->a1.valid && g.plan->a1.kp_ok && !g.plan->a1.ws_ok && b->n_streams <= wg_limit
         && pick_kernel(b, g) == NAM_HIP_KERNEL_A1_MFMA)
       return PERSIST_KP;
     return PERSIST_NONE;
