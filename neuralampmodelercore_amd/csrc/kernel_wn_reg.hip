@@ -698,12 +698,19 @@ __device__ __forceinline__ void wr_array_end_k(WrRegs& r, const WrOpS& op, char*
 // SET: which layer code the instantiation carries — 0: the fully described WR_LAYER shapes only (wavenet_a2_max: 344
 // registers, no spills), 1: WR_RUN shapes only (plain stacks: 278 registers, a short dispatch), 2: everything (the
 // run-time-flag layer shapes spill).
-template <int SET>
+// NST = 2: the op program cut in two (WrGroup::split_op, balanced on weights by the planner); wave 0 runs ops [0, split) on
+// buffer k while wave 1 runs [split, n_ops) on buffer k - 1 — the pipeline of wave sets of kernel_a1_p4.hip for this
+// kernel. A launch of S streams then keeps 2 S wavefronts busy instead of S: config 4's 512 streams fill the chip's
+// 1,024 SIMDs. Every ring belongs to the wave that runs its layer; the registers (WrRegs: 40 floats per lane) travel
+// through a one-slot LDS queue with single-writer "produced" / "consumed" words polled from inline asm. Only launches
+// that hold more than one buffer (sessions, renders, prewarm) are started this way.
+template <int SET, int NST = 1>
 __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
 {
   extern __shared__ __attribute__((aligned(16))) char lds_wr[];
   char* const lds = lds_wr;
-  const int lane = (int)threadIdx.x;
+  const int lane = (int)threadIdx.x & 63;
+  const int S = NST == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0; // stage (wave) of this thread
   // the width group of this workgroup (wavefront-uniform: everything below stays in scalar registers)
   int gi = 0;
 #pragma unroll
@@ -717,16 +724,45 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
   const bool pers = a.ps.ring != nullptr;
   PersistWave pw;
   unsigned cmd_off = 0;
-  if (pers && !pw.begin(a.ps, (int)blockIdx.x, cmd_off))
-  {
-    pw.leave(a.ps, (int)blockIdx.x); // nothing to do
-    return;
-  }
   float* const st = G.state + (long)stream * G.state_stride;
   int* const sti = reinterpret_cast<int*>(st);
   float* const st_ring = st + kWrPosInts;
   const int blob_floats = G.blob_floats, hist_floats = G.hist_floats;
-  const unsigned ring_b = (unsigned)blob_floats * 4u; // LDS: [blob][rings]
+  const unsigned ring_b = (unsigned)blob_floats * 4u; // LDS: [blob][rings][queue (NST = 2)]
+  const unsigned queue_b = ring_b + (unsigned)hist_floats * 4u;
+  int* const qwords = reinterpret_cast<int*>(lds + queue_b + 5u * kWrRegs * 64u * 4u); // token [0..3] | produced [4] | consumed [5] | ready, first count [6, 7]
+  unsigned done = 0; // NST = 2, wave 1: commands finished
+  if constexpr (NST == 1)
+  {
+    if (pers && !pw.begin(a.ps, (int)blockIdx.x, cmd_off))
+    {
+      pw.leave(a.ps, (int)blockIdx.x); // nothing to do
+      return;
+    }
+  }
+  else
+  {
+    // wave 0 looks for the launch's first command; its answer is the workgroup's
+    if (S == 0)
+    {
+      const bool ready = !pers || pw.begin(a.ps, (int)blockIdx.x, cmd_off);
+      if (lane == 0)
+      {
+        qwords[4] = qwords[5] = 0;
+        qwords[6] = ready ? 1 : 0;
+        qwords[7] = (int)pw.seq;
+      }
+    }
+    __syncthreads();
+    const bool ready = __builtin_amdgcn_readfirstlane(qwords[6]) != 0;
+    done = (unsigned)__builtin_amdgcn_readfirstlane(qwords[7]);
+    if (!ready)
+    {
+      if (S == 0)
+        pw.leave(a.ps, (int)blockIdx.x); // nothing to do
+      return;
+    }
+  }
   const bool whole = pers || a.n_frames > kBlock; // more than one block: the whole ring area comes in (and goes back)
 
   // Prologue. The write positions first (lane = slot): every ring address depends on them. A one-block launch then
@@ -755,7 +791,7 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     for (int u = 0; u < kWin; u++)
       window(min(u, n_pf - 1), win[u], win_off[u]);
   }
-  for (int base = 0; base < blob_floats; base += 8 * 256)
+  for (int base = 0; base < (NST == 2 && S == 1 ? 0 : blob_floats); base += 8 * 256) // (NST = 2: wave 0 the blob, wave 1 the rings)
   {
     f4 v[8];
 #pragma unroll
@@ -774,7 +810,7 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
   }
   if (whole)
   {
-    for (int base = 0; base < hist_floats; base += 8 * 256)
+    for (int base = 0; base < (NST == 2 && S == 0 ? 0 : hist_floats); base += 8 * 256)
     {
       f4 v[8];
 #pragma unroll
@@ -840,33 +876,107 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
         dst[c] = pers ? persist_in(in + (long)c * a.io_stride + off + lane) : in[(long)c * a.io_stride + off + lane];
     }
   };
-  const int pf_at = n_ops >> 1;
-  for (int f0 = pers ? (int)cmd_off : 0;;)
-  {
-    n = pers ? kBlock : min(kBlock, a.n_frames - f0);
-    if (pers)
-      pw.look_ahead(a.ps);
-    WrRegs r;
-    if (pf_off == f0)
+  // NST = 2: this wave's share of the program, and the queue between the two (kernel_a1_p4.hip: wait_word, queue_put / take)
+  const int split = NST == 2 ? max(1, min(G.split_op, n_ops - 1)) : 0;
+  const int oi0 = NST == 2 && S == 1 ? split : 0, oi1 = NST == 2 && S == 0 ? split : n_ops;
+  auto wait_word = [&](unsigned byte_addr, int want) { // until the LDS word has reached `want`
+    int tmp;
+    asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_sub_u32 %0, %0, %2\n\tv_cmp_gt_i32 vcc, 0, %0\n\t"
+                 "s_cbranch_vccz 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 : "=&v"(tmp)
+                 : "v"(byte_addr), "v"(want)
+                 : "vcc");
+  };
+  const unsigned qw_b = queue_b + 5u * kWrRegs * 64u * 4u;
+  auto queue_put = [&](int k, const WrRegs& q, int f0_, int n_, bool is_exit) {
+    wait_word(qw_b + 20u, k); // the slot is free once buffer k - 1 has been taken out of it
+    asm volatile("" ::: "memory");
+    if (!is_exit)
     {
 #pragma unroll
       for (int c = 0; c < kWrRegs; c++)
-        r.in[c] = in_pf[c];
+      {
+        lds_st1(lds, queue_b + (unsigned)((0 * kWrRegs + c) * 64 + lane) * 4u, q.in[c]);
+        lds_st1(lds, queue_b + (unsigned)((1 * kWrRegs + c) * 64 + lane) * 4u, q.x[c]);
+        lds_st1(lds, queue_b + (unsigned)((2 * kWrRegs + c) * 64 + lane) * 4u, q.cond[c]);
+        lds_st1(lds, queue_b + (unsigned)((3 * kWrRegs + c) * 64 + lane) * 4u, q.hacc[c]);
+        lds_st1(lds, queue_b + (unsigned)((4 * kWrRegs + c) * 64 + lane) * 4u, q.hout[c]);
+      }
     }
-    else
-      load_in(r.in, f0, n);
-    pf_off = -1;
+    if (lane == 0)
+    {
+      qwords[0] = f0_;
+      qwords[1] = n_;
+      qwords[2] = is_exit ? 1 : 0;
+    }
+    asm volatile("" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_store(qwords + 4, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto queue_take = [&](int k, WrRegs& q, int& f0_, int& n_, bool& is_exit) {
+    wait_word(qw_b + 16u, k + 1);
+    asm volatile("" ::: "memory");
+    f0_ = __builtin_amdgcn_readfirstlane(qwords[0]);
+    n_ = __builtin_amdgcn_readfirstlane(qwords[1]);
+    is_exit = __builtin_amdgcn_readfirstlane(qwords[2]) != 0;
 #pragma unroll
     for (int c = 0; c < kWrRegs; c++)
     {
-      r.cond[c] = r.in[c]; // a net without condition_dsp (and the nested net itself) is conditioned on its input
-      r.x[c] = r.hacc[c] = r.hout[c] = 0.0f;
+      q.in[c] = lds_ld1(lds, queue_b + (unsigned)((0 * kWrRegs + c) * 64 + lane) * 4u);
+      q.x[c] = lds_ld1(lds, queue_b + (unsigned)((1 * kWrRegs + c) * 64 + lane) * 4u);
+      q.cond[c] = lds_ld1(lds, queue_b + (unsigned)((2 * kWrRegs + c) * 64 + lane) * 4u);
+      q.hacc[c] = lds_ld1(lds, queue_b + (unsigned)((3 * kWrRegs + c) * 64 + lane) * 4u);
+      q.hout[c] = lds_ld1(lds, queue_b + (unsigned)((4 * kWrRegs + c) * 64 + lane) * 4u);
     }
-    WrOpS cur = wr_fetch(lds, ops_b, 0);
-    for (int oi = 0; oi < n_ops; oi++)
+#pragma unroll
+    for (int c = 0; c < kWrRegs; c++)
+      asm volatile("" ::"v"(q.in[c]), "v"(q.x[c]), "v"(q.cond[c]), "v"(q.hacc[c]), "v"(q.hout[c]) : "memory"); // (in registers: the slot may be reused)
+    if (lane == 0)
+      __hip_atomic_store(qwords + 5, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  if constexpr (NST == 2)
+    __syncthreads(); // the blob (wave 0) and the rings (wave 1) are in LDS
+  const int pf_at = (oi0 + oi1) >> 1;
+  int kbuf = 0; // NST = 2: buffers this wave has handed over / taken
+  for (int f0 = pers ? (int)cmd_off : 0;;)
+  {
+    WrRegs r;
+    if (NST == 1 || S == 0)
+    {
+      n = pers ? kBlock : min(kBlock, a.n_frames - f0);
+      if (pers)
+        pw.look_ahead(a.ps);
+      if (pf_off == f0)
+      {
+#pragma unroll
+        for (int c = 0; c < kWrRegs; c++)
+          r.in[c] = in_pf[c];
+      }
+      else
+        load_in(r.in, f0, n);
+      pf_off = -1;
+#pragma unroll
+      for (int c = 0; c < kWrRegs; c++)
+      {
+        r.cond[c] = r.in[c]; // a net without condition_dsp (and the nested net itself) is conditioned on its input
+        r.x[c] = r.hacc[c] = r.hout[c] = 0.0f;
+      }
+    }
+    else
+    {
+      bool is_exit = false;
+      queue_take(kbuf, r, f0, n, is_exit);
+      kbuf++;
+      if (is_exit)
+        break;
+    }
+    WrOpS cur = wr_fetch(lds, ops_b, oi0);
+    for (int oi = oi0; oi < oi1; oi++)
     {
       const WrOpS nxt = wr_fetch(lds, ops_b, min(oi + 1, n_ops - 1)); // requested before this op runs
-      if (oi == pf_at)
+      if (oi == pf_at && (NST == 1 || S == 0))
       {
         int nf = -1, nn = kBlock;
         if (pers)
@@ -973,28 +1083,46 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     // every ring moves on by the block's n frames (lane = slot; lanes without a slot stay at 0)
     posv += ring_len > 0 ? n : 0;
     posv -= posv >= ring_len ? ring_len : 0;
+    if constexpr (NST == 2)
+    {
+      if (S == 1)
+      {
+        done++; // (the next buffer comes out of the queue)
+        continue;
+      }
+      queue_put(kbuf, r, f0, n, false);
+      kbuf++;
+    }
+    bool more;
     if (pers)
     {
-      if (!pw.next(a.ps, (int)blockIdx.x, cmd_off))
-        break; // ring empty: leave
+      more = pw.next(a.ps, (int)blockIdx.x, cmd_off); // false: ring empty, leave
       f0 = (int)cmd_off;
     }
     else
     {
       f0 += kBlock;
-      if (f0 >= a.n_frames)
-        break;
+      more = f0 < a.n_frames;
+    }
+    if (!more)
+    {
+      if constexpr (NST == 2)
+        queue_put(kbuf, r, 0, 0, true); // EXIT: wave 1 finishes what is in front of it and leaves
+      break;
     }
   }
+  if constexpr (NST == 2)
+    __syncthreads(); // both waves are done with their rings
   // the state goes back: everything, or the frames this launch's single block appended
   if (whole)
   {
-    for (int base = 0; base < hist_floats; base += 4 * 256)
+    const int t4 = (S * 64 + lane) * 4; // (NST = 2: both waves copy)
+    for (int base = 0; base < hist_floats; base += 4 * 256 * NST)
     {
 #pragma unroll
       for (int u = 0; u < 4; u++)
       {
-        const int i = base + u * 256 + lane * 4;
+        const int i = base + u * 256 * NST + t4;
         if (i < hist_floats)
           *reinterpret_cast<f4*>(st_ring + i) = lds_ld4(lds, ring_b + (unsigned)i * 4u);
       }
@@ -1025,9 +1153,32 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
           st_ring[off[u]] = v[u];
     }
   }
-  sti[lane] = posv;
-  if (pers)
-    pw.leave(a.ps, (int)blockIdx.x);
+  if constexpr (NST == 1)
+  {
+    sti[lane] = posv;
+    if (pers)
+      pw.leave(a.ps, (int)blockIdx.x);
+  }
+  else
+  {
+    if (S == 1)
+      sti[lane] = posv;
+    if (pers)
+    {
+      // results visible, then the consumed-command count (PersistWave::leave): wave 1 knows it; wave 0's ring copy is
+      // ordered in front of the fence by the barrier below
+      __syncthreads();
+      if (S == 1)
+      {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane == 0)
+        {
+          a.ps.cons[blockIdx.x] = done;
+          __hip_atomic_store(a.ps.done + blockIdx.x, done | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
 }
 
 #ifdef NAM_WR_JIT_SHAPES
@@ -1037,30 +1188,58 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
 {
   wn_reg_body<2>(a);
 }
+extern "C" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_jit2(const WrArgs a)
+{
+  wn_reg_body<2, 2>(a); // two stages (two wavefronts per stream)
+}
 #else
 template <int SET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_kernel(const WrArgs a)
 {
   wn_reg_body<SET>(a);
 }
+template <int SET>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg2_kernel(const WrArgs a)
+{
+  wn_reg_body<SET, 2>(a); // two stages (two wavefronts per stream)
+}
 
-// a kernel compiled for one model's shapes (`fn`: hipFunction_t of nam_wn_reg_jit in that model's code object)
-hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream)
+// a kernel compiled for one model's shapes (`fn`: hipFunction_t of nam_wn_reg_jit / nam_wn_reg_jit2 in that model's code object)
+hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int lds_bytes, int stages, hipStream_t stream)
 {
   if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
   WrArgs args = a;
   size_t size = sizeof(args);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(fn), (unsigned)n_workgroups, 1, 1, 64, 1, 1, (unsigned)lds_bytes, stream,
-                               nullptr, config);
+  return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(fn), (unsigned)n_workgroups, 1, 1, 64u * (unsigned)stages, 1, 1,
+                               (unsigned)lds_bytes, stream, nullptr, config);
 }
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers,
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers, int stages,
                          hipStream_t stream)
 {
   if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
+  if (stages == 2)
+  {
+    static DynamicLdsLimit lds_limit2[3];
+    auto launch2 = [&](auto kernel, int set) -> hipError_t {
+      if (lds_bytes > 64 * 1024)
+      {
+        const hipError_t e = lds_limit2[set].ensure(reinterpret_cast<const void*>(kernel), kWrMaxLdsBytes);
+        if (e != hipSuccess)
+          return e;
+      }
+      hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(128), lds_bytes, stream, a);
+      return hipGetLastError();
+    };
+    if ((layers && runs) || rt_layers)
+      return launch2(nam_wn_reg2_kernel<2>, 2);
+    if (runs)
+      return launch2(nam_wn_reg2_kernel<1>, 1);
+    return launch2(nam_wn_reg2_kernel<0>, 0);
+  }
   // more than the default 64 KB of dynamic LDS per workgroup (long dilations at 4+ channels: the official nano size
   // keeps 68 KB of rings): raised once per instantiation
   static DynamicLdsLimit lds_limit[3]; // per instantiation, tracked per device (kernels.h)

@@ -144,6 +144,7 @@ struct WrGroup
   int n_slots; // layers (write positions)
   int tab_rows, n_rows, tab_pf, n_pf, tab_ring, tab_ops; // blob float offsets / entry counts of the tables
   int first; // first workgroup of the group
+  int split_op; // two-stage launches (nam_wn_reg2_kernel): wave 0 runs ops [0, split_op), wave 1 the rest
 };
 struct WrArgs
 {
@@ -157,10 +158,11 @@ struct WrArgs
   PersistArgs ps;
 };
 
-hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers,
+// stages = 2: two wavefronts per stream (the op program cut at WrGroup::split_op), lds_bytes including kWrQueueBytes
+hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers, int stages,
                          hipStream_t stream);
 // the same kernel compiled for one model's own layer shapes (wr_jit.cpp); fn = hipFunction_t of the model's code object
-hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int lds_bytes, hipStream_t stream);
+hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int lds_bytes, int stages, hipStream_t stream);
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);

@@ -404,14 +404,14 @@ PersistArgs persist_args(const nam_hip_batch* b)
 
 // The function of a per-model code object on the current device (hipModuleLoad is per device: cached per path and
 // device for the life of the process; a handful of entries).
-int wr_jit_function(const std::string& path, int device, void** fn)
+int wr_jit_function(const std::string& path, int device, int stages, void** fn)
 {
   struct Entry
   {
     std::string path;
     int device;
     hipModule_t module;
-    hipFunction_t fn;
+    hipFunction_t fn, fn2; // nam_wn_reg_jit, nam_wn_reg_jit2 (two stages)
   };
   static std::vector<Entry> cache;
   static std::mutex mu;
@@ -419,17 +419,19 @@ int wr_jit_function(const std::string& path, int device, void** fn)
   for (const Entry& e : cache)
     if (e.device == device && e.path == path)
     {
-      *fn = reinterpret_cast<void*>(e.fn);
+      *fn = reinterpret_cast<void*>(stages == 2 ? e.fn2 : e.fn);
       return NAM_HIP_OK;
     }
-  Entry e{path, device, nullptr, nullptr};
+  Entry e{path, device, nullptr, nullptr, nullptr};
   NAM_HIP_CHECK(hipModuleLoad(&e.module, path.c_str()));
   NAM_HIP_CHECK(hipModuleGetFunction(&e.fn, e.module, "nam_wn_reg_jit"));
+  NAM_HIP_CHECK(hipModuleGetFunction(&e.fn2, e.module, "nam_wn_reg_jit2"));
   // more than the default 64 KB of dynamic LDS per workgroup (long dilations: up to 156 KB of rings)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn2), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
   (void)hipGetLastError();
   cache.push_back(e);
-  *fn = reinterpret_cast<void*>(e.fn);
+  *fn = reinterpret_cast<void*>(stages == 2 ? e.fn2 : e.fn);
   return NAM_HIP_OK;
 }
 
@@ -441,7 +443,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   WrArgs a;
   std::memset(&a, 0, sizeof(a));
   int total = 0, lds_bytes = 0;
-  bool layers = false, runs = false, rt_layers = false;
+  bool layers = false, runs = false, rt_layers = false, can_split = true;
   for (int k = 0; k < n_groups; k++)
   {
     WidthGroup& g = *groups[k];
@@ -470,8 +472,23 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
     G.tab_ring = w.tab_ring;
     G.tab_ops = w.tab_ops;
     G.first = total;
+    G.split_op = w.split_op;
+    can_split = can_split && w.split_op >= 1 && w.split_op < (int)w.ops.size();
     total += counts[k];
     lds_bytes = std::max(lds_bytes, w.lds_bytes);
+  }
+  // Two wavefronts per stream (the program cut in two, consecutive buffers in flight: kernel_wn_reg.hip, NST = 2) when the
+  // launch holds more than one buffer and the chip has the SIMDs for it — config 4's 512 streams become 1,024 wavefronts
+  int stages = 1;
+  {
+    const int cus = std::max(b->n_cus, 1);
+    const int per_cu = (total + cus - 1) / cus;
+    if (can_split && !b->no_pipe && (b->ps_launching || n_frames > kBlock) && 2 * total <= 4 * cus
+        && (lds_bytes + kWrQueueBytes) <= kWrMaxLdsBytes && per_cu * (lds_bytes + kWrQueueBytes + 512) <= 160 * 1024)
+    {
+      stages = 2;
+      lds_bytes += kWrQueueBytes;
+    }
   }
   a.n_groups = n_groups;
   a.in = d_in;
@@ -489,13 +506,13 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   if (!module.empty())
   {
     void* fn = nullptr;
-    const int rc = wr_jit_function(module, b->device, &fn);
+    const int rc = wr_jit_function(module, b->device, stages, &fn);
     if (rc != NAM_HIP_OK)
       return rc;
-    NAM_HIP_CHECK(launch_wn_reg_jit(fn, a, total, lds_bytes, s));
+    NAM_HIP_CHECK(launch_wn_reg_jit(fn, a, total, lds_bytes, stages, s));
     return NAM_HIP_OK;
   }
-  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, layers, runs, rt_layers, s));
+  NAM_HIP_CHECK(launch_wn_reg(a, total, lds_bytes, layers, runs, rt_layers, stages, s));
   return NAM_HIP_OK;
 }
 

@@ -1810,6 +1810,41 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
       }
     }
     std::memcpy(&wr.blob[(size_t)wr.tab_ops], wr.ops.data(), wr.ops.size() * sizeof(WrOp));
+    {
+      // Two-stage launches (kernel_wn_reg.hip, NST = 2) cut the program where the work balances; an op's weights are a
+      // fair measure of its arithmetic (every weight is one multiply-add per frame): op i owns the blob from its offset to
+      // the next larger one.
+      std::vector<int> ws;
+      for (const auto& op : wr.ops)
+        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K)
+          ws.push_back(op.w);
+      ws.push_back(wr.tab_rows); // (the first table: the end of the weights)
+      std::sort(ws.begin(), ws.end());
+      std::vector<long> cost(wr.ops.size(), 8);
+      long total = 0;
+      for (size_t i = 0; i < wr.ops.size(); i++)
+      {
+        const auto& op = wr.ops[i];
+        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K)
+        {
+          const auto nx = std::upper_bound(ws.begin(), ws.end(), op.w);
+          cost[i] += nx != ws.end() ? *nx - op.w : 0;
+        }
+        total += cost[i];
+      }
+      long acc = 0, best = -1;
+      wr.split_op = 0;
+      for (size_t m = 1; m < wr.ops.size(); m++)
+      {
+        acc += cost[m - 1];
+        const long d = std::labs(2 * acc - total);
+        if (best < 0 || d < best)
+        {
+          best = d;
+          wr.split_op = (int)m;
+        }
+      }
+    }
     wr.hist_floats = b.hist;
     wr.state_floats = (kWrPosInts + b.hist + 63) / 64 * 64;
     wr.lds_bytes = (hist_base + wr.hist_floats) * 4;

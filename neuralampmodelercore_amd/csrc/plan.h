@@ -426,6 +426,7 @@ static_assert(sizeof(WrOp) == 64, "WrOp must stay 64 bytes");
 
 constexpr int kWrPosInts = 64; // write positions per stream (one per layer): the header of the state, a table in LDS
 constexpr int kWrRegs = 8; // width of the register files (x, condition, head accumulator, head output)
+constexpr int kWrQueueBytes = 5 * kWrRegs * 64 * 4 + 64; // two-stage launches: the registers in flight between the two waves + token / flag words
 constexpr int kWrActFloats = 20; // per activation: p0..p3, then the PReLU slope of each of (up to) 16 rows
 constexpr int kWrMaxLdsBytes = 156 * 1024; // a workgroup of nam_wn_reg_kernel may take (nearly) a whole CU's 160 KB of LDS
 constexpr int kWrMaxGroups = 8; // width groups one launch of nam_wn_reg_kernel can serve (kernels.h: WrArgs)
@@ -446,6 +447,7 @@ struct WrPlan
   int tab_pf = 0, n_pf = 0; // ... of the one-block prefetch windows
   int tab_ring = 0; // ... of R per slot (n_layers ints, padded to 4)
   int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
+  int split_op = 0; // two-stage launches: wave 0 runs ops [0, split_op), wave 1 the rest (0: the program cannot be cut)
   // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
   // object compiled for it ("" until nam_hip_api.cpp has prepared it — the plan is not runnable before)
   bool jit = false;
