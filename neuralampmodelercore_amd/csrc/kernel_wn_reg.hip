@@ -698,19 +698,19 @@ __device__ __forceinline__ void wr_array_end_k(WrRegs& r, const WrOpS& op, char*
 // SET: which layer code the instantiation carries — 0: the fully described WR_LAYER shapes only (wavenet_a2_max: 344
 // registers, no spills), 1: WR_RUN shapes only (plain stacks: 278 registers, a short dispatch), 2: everything (the
 // run-time-flag layer shapes spill).
-// NST = 2: the op program cut in two (WrGroup::split_op, balanced on weights by the planner); wave 0 runs ops [0, split) on
-// buffer k while wave 1 runs [split, n_ops) on buffer k - 1 — the pipeline of wave sets of kernel_a1_p4.hip for this
-// kernel. A launch of S streams then keeps 2 S wavefronts busy instead of S: config 4's 512 streams fill the chip's
-// 1,024 SIMDs. Every ring belongs to the wave that runs its layer; the registers (WrRegs: 40 floats per lane) travel
-// through a one-slot LDS queue with single-writer "produced" / "consumed" words polled from inline asm. Only launches
-// that hold more than one buffer (sessions, renders, prewarm) are started this way.
+// NST = 2 / 4: the op program cut into NST parts (WrGroup::split_op, balanced on weights by the planner); wave s runs its
+// part on buffer k - s while wave 0 works on buffer k — the pipeline of wave sets of kernel_a1_p4.hip for this kernel. A
+// launch of N streams then keeps NST x N wavefronts busy instead of N: config 4's 512 streams fill the chip's 1,024
+// SIMDs with two waves each, 256 streams with four. Every ring belongs to the wave that runs its layer; the registers
+// (WrRegs: 40 floats per lane) travel through one-slot LDS queues with single-writer "produced" / "consumed" words
+// polled from inline asm. Only launches that hold more than one buffer (sessions, renders, prewarm) are started this way.
 template <int SET, int NST = 1>
 __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
 {
   extern __shared__ __attribute__((aligned(16))) char lds_wr[];
   char* const lds = lds_wr;
   const int lane = (int)threadIdx.x & 63;
-  const int S = NST == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0; // stage (wave) of this thread
+  const int S = NST > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0; // stage (wave) of this thread
   // the width group of this workgroup (wavefront-uniform: everything below stays in scalar registers)
   int gi = 0;
 #pragma unroll
@@ -728,10 +728,11 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
   int* const sti = reinterpret_cast<int*>(st);
   float* const st_ring = st + kWrPosInts;
   const int blob_floats = G.blob_floats, hist_floats = G.hist_floats;
-  const unsigned ring_b = (unsigned)blob_floats * 4u; // LDS: [blob][rings][queue (NST = 2)]
-  const unsigned queue_b = ring_b + (unsigned)hist_floats * 4u;
-  int* const qwords = reinterpret_cast<int*>(lds + queue_b + 5u * kWrRegs * 64u * 4u); // token [0..3] | produced [4] | consumed [5] | ready, first count [6, 7]
-  unsigned done = 0; // NST = 2, wave 1: commands finished
+  const unsigned ring_b = (unsigned)blob_floats * 4u; // LDS: [blob][rings][queues (NST > 1): queue q = stage q -> q + 1]
+  const unsigned queue0_b = ring_b + (unsigned)hist_floats * 4u;
+  constexpr unsigned kQRegsB = 5u * kWrRegs * 64u * 4u; // a queue: the registers | token [0..3] | produced [4] | consumed [5] | (queue 0) ready, first count [6, 7]
+  int* const q0words = reinterpret_cast<int*>(lds + queue0_b + kQRegsB);
+  unsigned done = 0; // NST > 1, last wave: commands finished
   if constexpr (NST == 1)
   {
     if (pers && !pw.begin(a.ps, (int)blockIdx.x, cmd_off))
@@ -746,16 +747,20 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     if (S == 0)
     {
       const bool ready = !pers || pw.begin(a.ps, (int)blockIdx.x, cmd_off);
+      if (lane < NST - 1) // (the queues' counters)
+      {
+        int* const qw = reinterpret_cast<int*>(lds + queue0_b + (unsigned)lane * (unsigned)kWrQueueBytes + kQRegsB);
+        qw[4] = qw[5] = 0;
+      }
       if (lane == 0)
       {
-        qwords[4] = qwords[5] = 0;
-        qwords[6] = ready ? 1 : 0;
-        qwords[7] = (int)pw.seq;
+        q0words[6] = ready ? 1 : 0;
+        q0words[7] = (int)pw.seq;
       }
     }
     __syncthreads();
-    const bool ready = __builtin_amdgcn_readfirstlane(qwords[6]) != 0;
-    done = (unsigned)__builtin_amdgcn_readfirstlane(qwords[7]);
+    const bool ready = __builtin_amdgcn_readfirstlane(q0words[6]) != 0;
+    done = (unsigned)__builtin_amdgcn_readfirstlane(q0words[7]);
     if (!ready)
     {
       if (S == 0)
@@ -791,38 +796,39 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     for (int u = 0; u < kWin; u++)
       window(min(u, n_pf - 1), win[u], win_off[u]);
   }
-  for (int base = 0; base < (NST == 2 && S == 1 ? 0 : blob_floats); base += 8 * 256) // (NST = 2: wave 0 the blob, wave 1 the rings)
+  const int t4 = (S * 64 + lane) * 4; // (NST > 1: every wave copies its share)
+  for (int base = 0; base < blob_floats; base += 8 * 256 * NST)
   {
     f4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; u++)
     {
-      const int i = base + u * 256 + lane * 4;
+      const int i = base + u * 256 * NST + t4;
       v[u] = i < blob_floats ? *reinterpret_cast<const f4*>(G.blob + i) : f4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
     {
-      const int i = base + u * 256 + lane * 4;
+      const int i = base + u * 256 * NST + t4;
       if (i < blob_floats)
         lds_st4(lds, (unsigned)i * 4u, v[u]);
     }
   }
   if (whole)
   {
-    for (int base = 0; base < (NST == 2 && S == 0 ? 0 : hist_floats); base += 8 * 256)
+    for (int base = 0; base < hist_floats; base += 8 * 256 * NST)
     {
       f4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++)
       {
-        const int i = base + u * 256 + lane * 4;
+        const int i = base + u * 256 * NST + t4;
         v[u] = i < hist_floats ? *reinterpret_cast<const f4*>(st_ring + i) : f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 8; u++)
       {
-        const int i = base + u * 256 + lane * 4;
+        const int i = base + u * 256 * NST + t4;
         if (i < hist_floats)
           lds_st4(lds, ring_b + (unsigned)i * 4u, v[u]);
       }
@@ -876,9 +882,22 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
         dst[c] = pers ? persist_in(in + (long)c * a.io_stride + off + lane) : in[(long)c * a.io_stride + off + lane];
     }
   };
-  // NST = 2: this wave's share of the program, and the queue between the two (kernel_a1_p4.hip: wait_word, queue_put / take)
-  const int split = NST == 2 ? max(1, min(G.split_op, n_ops - 1)) : 0;
-  const int oi0 = NST == 2 && S == 1 ? split : 0, oi1 = NST == 2 && S == 0 ? split : n_ops;
+  // NST > 1: this wave's share of the program (cuts at a quarter, a half, three quarters of the weights; two stages use the
+  // middle one), and the queues between the waves (kernel_a1_p4.hip: wait_word, queue_put / take)
+  int oi0 = 0, oi1 = n_ops;
+  if constexpr (NST == 2)
+  {
+    const int c = max(1, min(G.split_op[1], n_ops - 1));
+    oi0 = S == 1 ? c : 0;
+    oi1 = S == 0 ? c : n_ops;
+  }
+  else if constexpr (NST == 4)
+  {
+    const int c0 = max(1, min(G.split_op[0], n_ops - 3)), c1 = max(c0 + 1, min(G.split_op[1], n_ops - 2)),
+              c2 = max(c1 + 1, min(G.split_op[2], n_ops - 1));
+    oi0 = S == 0 ? 0 : S == 1 ? c0 : S == 2 ? c1 : c2;
+    oi1 = S == 0 ? c0 : S == 1 ? c1 : S == 2 ? c2 : n_ops;
+  }
   auto wait_word = [&](unsigned byte_addr, int want) { // until the LDS word has reached `want`
     int tmp;
     asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_sub_u32 %0, %0, %2\n\tv_cmp_gt_i32 vcc, 0, %0\n\t"
@@ -887,8 +906,9 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
                  : "v"(byte_addr), "v"(want)
                  : "vcc");
   };
-  const unsigned qw_b = queue_b + 5u * kWrRegs * 64u * 4u;
-  auto queue_put = [&](int k, const WrRegs& q, int f0_, int n_, bool is_exit) {
+  auto queue_put = [&](int qi, int k, const WrRegs& q, int f0_, int n_, bool is_exit) {
+    const unsigned queue_b = queue0_b + (unsigned)qi * (unsigned)kWrQueueBytes, qw_b = queue_b + kQRegsB;
+    int* const qwords = reinterpret_cast<int*>(lds + qw_b);
     wait_word(qw_b + 20u, k); // the slot is free once buffer k - 1 has been taken out of it
     asm volatile("" ::: "memory");
     if (!is_exit)
@@ -914,7 +934,9 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
       __hip_atomic_store(qwords + 4, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
   };
-  auto queue_take = [&](int k, WrRegs& q, int& f0_, int& n_, bool& is_exit) {
+  auto queue_take = [&](int qi, int k, WrRegs& q, int& f0_, int& n_, bool& is_exit) {
+    const unsigned queue_b = queue0_b + (unsigned)qi * (unsigned)kWrQueueBytes, qw_b = queue_b + kQRegsB;
+    int* const qwords = reinterpret_cast<int*>(lds + qw_b);
     wait_word(qw_b + 16u, k + 1);
     asm volatile("" ::: "memory");
     f0_ = __builtin_amdgcn_readfirstlane(qwords[0]);
@@ -936,10 +958,10 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
       __hip_atomic_store(qwords + 5, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
   };
-  if constexpr (NST == 2)
-    __syncthreads(); // the blob (wave 0) and the rings (wave 1) are in LDS
+  if constexpr (NST > 1)
+    __syncthreads(); // the blob and the rings are in LDS (every wave copied its share)
   const int pf_at = (oi0 + oi1) >> 1;
-  int kbuf = 0; // NST = 2: buffers this wave has handed over / taken
+  int kbuf = 0; // NST > 1: buffers this wave has handed over / taken
   for (int f0 = pers ? (int)cmd_off : 0;;)
   {
     WrRegs r;
@@ -967,10 +989,13 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     else
     {
       bool is_exit = false;
-      queue_take(kbuf, r, f0, n, is_exit);
-      kbuf++;
+      queue_take(S - 1, kbuf, r, f0, n, is_exit);
       if (is_exit)
+      {
+        if (S + 1 < NST)
+          queue_put(S, kbuf, r, 0, 0, true); // pass the EXIT on
         break;
+      }
     }
     WrOpS cur = wr_fetch(lds, ops_b, oi0);
     for (int oi = oi0; oi < oi1; oi++)
@@ -1083,15 +1108,16 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     // every ring moves on by the block's n frames (lane = slot; lanes without a slot stay at 0)
     posv += ring_len > 0 ? n : 0;
     posv -= posv >= ring_len ? ring_len : 0;
-    if constexpr (NST == 2)
+    if constexpr (NST > 1)
     {
-      if (S == 1)
+      if (S + 1 < NST)
+        queue_put(S, kbuf, r, f0, n, false);
+      kbuf++;
+      if (S > 0)
       {
         done++; // (the next buffer comes out of the queue)
         continue;
       }
-      queue_put(kbuf, r, f0, n, false);
-      kbuf++;
     }
     bool more;
     if (pers)
@@ -1106,17 +1132,16 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
     }
     if (!more)
     {
-      if constexpr (NST == 2)
-        queue_put(kbuf, r, 0, 0, true); // EXIT: wave 1 finishes what is in front of it and leaves
+      if constexpr (NST > 1)
+        queue_put(0, kbuf, r, 0, 0, true); // EXIT: the later waves finish what is in front of them and leave
       break;
     }
   }
-  if constexpr (NST == 2)
-    __syncthreads(); // both waves are done with their rings
+  if constexpr (NST > 1)
+    __syncthreads(); // every wave is done with its rings
   // the state goes back: everything, or the frames this launch's single block appended
   if (whole)
   {
-    const int t4 = (S * 64 + lane) * 4; // (NST = 2: both waves copy)
     for (int base = 0; base < hist_floats; base += 4 * 256 * NST)
     {
 #pragma unroll
@@ -1161,14 +1186,14 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
   }
   else
   {
-    if (S == 1)
+    if (S == NST - 1)
       sti[lane] = posv;
     if (pers)
     {
-      // results visible, then the consumed-command count (PersistWave::leave): wave 1 knows it; wave 0's ring copy is
-      // ordered in front of the fence by the barrier below
+      // results visible, then the consumed-command count (PersistWave::leave): the last wave knows it; the other waves'
+      // ring copies are ordered in front of the fence by the barrier below
       __syncthreads();
-      if (S == 1)
+      if (S == NST - 1)
       {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (lane == 0)
@@ -1192,6 +1217,10 @@ extern "C" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(
 {
   wn_reg_body<2, 2>(a); // two stages (two wavefronts per stream)
 }
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_jit4(const WrArgs a)
+{
+  wn_reg_body<2, 4>(a); // four stages
+}
 #else
 template <int SET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_kernel(const WrArgs a)
@@ -1202,6 +1231,11 @@ template <int SET>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg2_kernel(const WrArgs a)
 {
   wn_reg_body<SET, 2>(a); // two stages (two wavefronts per stream)
+}
+template <int SET>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg4_kernel(const WrArgs a)
+{
+  wn_reg_body<SET, 4>(a); // four stages
 }
 
 // a kernel compiled for one model's shapes (`fn`: hipFunction_t of nam_wn_reg_jit / nam_wn_reg_jit2 in that model's code object)
@@ -1221,9 +1255,9 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
 {
   if (n_workgroups <= 0 || a.n_frames <= 0)
     return hipSuccess;
-  if (stages == 2)
+  if (stages > 1)
   {
-    static DynamicLdsLimit lds_limit2[3];
+    static DynamicLdsLimit lds_limit2[6];
     auto launch2 = [&](auto kernel, int set) -> hipError_t {
       if (lds_bytes > 64 * 1024)
       {
@@ -1231,14 +1265,13 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
         if (e != hipSuccess)
           return e;
       }
-      hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(128), lds_bytes, stream, a);
+      hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(64 * stages), lds_bytes, stream, a);
       return hipGetLastError();
     };
-    if ((layers && runs) || rt_layers)
-      return launch2(nam_wn_reg2_kernel<2>, 2);
-    if (runs)
-      return launch2(nam_wn_reg2_kernel<1>, 1);
-    return launch2(nam_wn_reg2_kernel<0>, 0);
+    const int set = ((layers && runs) || rt_layers) ? 2 : runs ? 1 : 0;
+    if (stages == 4)
+      return set == 2 ? launch2(nam_wn_reg4_kernel<2>, 5) : set == 1 ? launch2(nam_wn_reg4_kernel<1>, 4) : launch2(nam_wn_reg4_kernel<0>, 3);
+    return set == 2 ? launch2(nam_wn_reg2_kernel<2>, 2) : set == 1 ? launch2(nam_wn_reg2_kernel<1>, 1) : launch2(nam_wn_reg2_kernel<0>, 0);
   }
   // more than the default 64 KB of dynamic LDS per workgroup (long dilations at 4+ channels: the official nano size
   // keeps 68 KB of rings): raised once per instantiation

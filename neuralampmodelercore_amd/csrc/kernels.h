@@ -144,7 +144,7 @@ struct WrGroup
   int n_slots; // layers (write positions)
   int tab_rows, n_rows, tab_pf, n_pf, tab_ring, tab_ops; // blob float offsets / entry counts of the tables
   int first; // first workgroup of the group
-  int split_op; // two-stage launches (nam_wn_reg2_kernel): wave 0 runs ops [0, split_op), wave 1 the rest
+  int split_op[3]; // pipelined launches: the program's cuts at 1/4, 1/2, 3/4 of its weights (two stages: [1]; four: all three)
 };
 struct WrArgs
 {
@@ -158,7 +158,8 @@ struct WrArgs
   PersistArgs ps;
 };
 
-// stages = 2: two wavefronts per stream (the op program cut at WrGroup::split_op), lds_bytes including kWrQueueBytes
+// stages = 2 / 4: that many wavefronts per stream (the op program cut at WrGroup::split_op), lds_bytes including the
+// (stages - 1) queues of kWrQueueBytes
 hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool layers, bool runs, bool rt_layers, int stages,
                          hipStream_t stream);
 // the same kernel compiled for one model's own layer shapes (wr_jit.cpp); fn = hipFunction_t of the model's code object

@@ -190,6 +190,7 @@ struct nam_hip_batch
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
+  int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
   bool ps_launching = false; // launch_group is starting the session's resident launch
@@ -411,7 +412,7 @@ int wr_jit_function(const std::string& path, int device, int stages, void** fn)
     std::string path;
     int device;
     hipModule_t module;
-    hipFunction_t fn, fn2; // nam_wn_reg_jit, nam_wn_reg_jit2 (two stages)
+    hipFunction_t fn, fn2, fn4; // nam_wn_reg_jit, nam_wn_reg_jit2 (two stages), nam_wn_reg_jit4
   };
   static std::vector<Entry> cache;
   static std::mutex mu;
@@ -419,19 +420,21 @@ int wr_jit_function(const std::string& path, int device, int stages, void** fn)
   for (const Entry& e : cache)
     if (e.device == device && e.path == path)
     {
-      *fn = reinterpret_cast<void*>(stages == 2 ? e.fn2 : e.fn);
+      *fn = reinterpret_cast<void*>(stages == 4 ? e.fn4 : stages == 2 ? e.fn2 : e.fn);
       return NAM_HIP_OK;
     }
-  Entry e{path, device, nullptr, nullptr, nullptr};
+  Entry e{path, device, nullptr, nullptr, nullptr, nullptr};
   NAM_HIP_CHECK(hipModuleLoad(&e.module, path.c_str()));
   NAM_HIP_CHECK(hipModuleGetFunction(&e.fn, e.module, "nam_wn_reg_jit"));
   NAM_HIP_CHECK(hipModuleGetFunction(&e.fn2, e.module, "nam_wn_reg_jit2"));
+  NAM_HIP_CHECK(hipModuleGetFunction(&e.fn4, e.module, "nam_wn_reg_jit4"));
   // more than the default 64 KB of dynamic LDS per workgroup (long dilations: up to 156 KB of rings)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn2), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn4), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
   (void)hipGetLastError();
   cache.push_back(e);
-  *fn = reinterpret_cast<void*>(stages == 2 ? e.fn2 : e.fn);
+  *fn = reinterpret_cast<void*>(stages == 4 ? e.fn4 : stages == 2 ? e.fn2 : e.fn);
   return NAM_HIP_OK;
 }
 
@@ -443,7 +446,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   WrArgs a;
   std::memset(&a, 0, sizeof(a));
   int total = 0, lds_bytes = 0;
-  bool layers = false, runs = false, rt_layers = false, can_split = true;
+  bool layers = false, runs = false, rt_layers = false, can_split = true, can_split4 = true;
   for (int k = 0; k < n_groups; k++)
   {
     WidthGroup& g = *groups[k];
@@ -472,23 +475,31 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
     G.tab_ring = w.tab_ring;
     G.tab_ops = w.tab_ops;
     G.first = total;
-    G.split_op = w.split_op;
-    can_split = can_split && w.split_op >= 1 && w.split_op < (int)w.ops.size();
+    for (int q = 0; q < 3; q++)
+      G.split_op[q] = w.split_op[q];
+    can_split = can_split && w.split_op[1] >= 1 && w.split_op[1] < (int)w.ops.size();
+    can_split4 = can_split4 && w.split_op[0] >= 1 && w.split_op[0] < w.split_op[1] && w.split_op[1] < w.split_op[2]
+                 && w.split_op[2] < (int)w.ops.size();
     total += counts[k];
     lds_bytes = std::max(lds_bytes, w.lds_bytes);
   }
-  // Two wavefronts per stream (the program cut in two, consecutive buffers in flight: kernel_wn_reg.hip, NST = 2) when the
-  // launch holds more than one buffer and the chip has the SIMDs for it — config 4's 512 streams become 1,024 wavefronts
+  // Two or four wavefronts per stream (the program cut up, consecutive buffers in flight: kernel_wn_reg.hip, NST) when the
+  // launch holds more than one buffer and the chip has the SIMDs for it — config 4's 512 streams become 1,024
+  // wavefronts, 256 streams too
   int stages = 1;
+  if (!b->no_pipe && (b->ps_launching || n_frames > kBlock))
   {
     const int cus = std::max(b->n_cus, 1);
     const int per_cu = (total + cus - 1) / cus;
-    if (can_split && !b->no_pipe && (b->ps_launching || n_frames > kBlock) && 2 * total <= 4 * cus
-        && (lds_bytes + kWrQueueBytes) <= kWrMaxLdsBytes && per_cu * (lds_bytes + kWrQueueBytes + 512) <= 160 * 1024)
-    {
+    auto fits = [&](int nst) {
+      const int lds = lds_bytes + (nst - 1) * kWrQueueBytes;
+      return nst * total <= 4 * cus && lds <= kWrMaxLdsBytes && per_cu * (lds + 512) <= 160 * 1024;
+    };
+    if (can_split && can_split4 && b->wr_max_stages >= 4 && fits(4))
+      stages = 4;
+    else if (can_split && b->wr_max_stages >= 2 && fits(2))
       stages = 2;
-      lds_bytes += kWrQueueBytes;
-    }
+    lds_bytes += (stages - 1) * kWrQueueBytes;
   }
   a.n_groups = n_groups;
   a.in = d_in;
@@ -1746,6 +1757,8 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   {
     const char* e = std::getenv("NAM_HIP_IL_GENERIC");
     b->il_generic = e && e[0] == '1';
+    if (const char* e4 = std::getenv("NAM_HIP_WR_STAGES"))
+      b->wr_max_stages = std::max(1, std::atoi(e4));
     const char* e3 = std::getenv("NAM_HIP_NO_PIPE");
     b->no_pipe = e3 && e3[0] == '1';
   }

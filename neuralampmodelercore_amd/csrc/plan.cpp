@@ -1832,16 +1832,19 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
         }
         total += cost[i];
       }
-      long acc = 0, best = -1;
-      wr.split_op = 0;
-      for (size_t m = 1; m < wr.ops.size(); m++)
+      for (int q = 0; q < 3; q++) // the cut closest to (q + 1) / 4 of the work
       {
-        acc += cost[m - 1];
-        const long d = std::labs(2 * acc - total);
-        if (best < 0 || d < best)
+        long acc = 0, best = -1;
+        wr.split_op[q] = 0;
+        for (size_t m = 1; m < wr.ops.size(); m++)
         {
-          best = d;
-          wr.split_op = (int)m;
+          acc += cost[m - 1];
+          const long d = std::labs(4 * acc - (q + 1) * total);
+          if (best < 0 || d < best)
+          {
+            best = d;
+            wr.split_op[q] = (int)m;
+          }
         }
       }
     }

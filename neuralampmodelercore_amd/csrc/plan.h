@@ -447,7 +447,7 @@ struct WrPlan
   int tab_pf = 0, n_pf = 0; // ... of the one-block prefetch windows
   int tab_ring = 0; // ... of R per slot (n_layers ints, padded to 4)
   int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
-  int split_op = 0; // two-stage launches: wave 0 runs ops [0, split_op), wave 1 the rest (0: the program cannot be cut)
+  int split_op[3] = {0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its weights (kernel_wn_reg.hip, NST)
   // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
   // object compiled for it ("" until nam_hip_api.cpp has prepared it — the plan is not runnable before)
   bool jit = false;
