@@ -1,7 +1,8 @@
 """Loads every fixture and every seeded feature-rich test model once on this machine (no GPU needed): models whose layer
 shapes are outside nam_wn_reg_kernel's ahead-of-time tables get the kernel compiled for them here, and the code objects
 land in neuralampmodelercore_amd/lib/jit/ — next to the library, so they travel with it (the GPU box then finds them by
-hash instead of compiling). Run by __graft_entry__.build()."""
+hash instead of compiling). Run by __graft_entry__.build(). --prune: delete cache files no load of this run asked for
+(code objects of older kernel sources)."""
 import glob, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -26,7 +27,7 @@ def main():
             acc += bool(m.info.has_a1_kernel & 16)
             n += 1
     pruned = 0
-    for f in glob.glob(os.path.join(cache, "*")):  # (a hit refreshes the file's time stamp, wr_jit.cpp)
+    for f in glob.glob(os.path.join(cache, "*")) if "--prune" in sys.argv else []:  # (a hit refreshes the file's time stamp, wr_jit.cpp)
         if os.path.getmtime(f) < stamp:
             os.remove(f)
             pruned += 1
