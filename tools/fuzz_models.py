@@ -5,7 +5,8 @@ the register-resident kernel's LDS rings, plain-layer runs and run-time-flag lay
 (make_synthetic_models.random_featured: per-layer gating / blending, FiLM subsets with and without shift, grouped input /
 mixin / 1x1 / head1x1, bottleneck != channels, a nested condition_dsp, PReLU / LeakyHardtanh / Hardswish secondaries —
 alternately with free dimensions (op interpreter) and with the dimensions nam_wn_reg_kernel instantiates).
-Usage: python tools/fuzz_models.py [n] [seed]"""
+Every kernel runs 64-frame launches, one multi-block launch (the pipelined forms) and — where the batch is eligible — a
+persistent session. Usage: python tools/fuzz_models.py [n] [seed] [--load-only]"""
 import json, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,6 +84,7 @@ def random_featured(rng, tmp, idx):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    load_only = "--load-only" in sys.argv  # no GPU: just load every model (compiles the per-model kernels into the cache)
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(n):
@@ -90,6 +92,10 @@ def main():
             ft = bool(rng.integers(2))
             model = nam.get_dsp(path, fast_tanh=ft)
             bits = model.info.has_a1_kernel
+            if load_only:
+                rng.integers(3, 7); rng.integers(0, 64)  # (keep the random sequence of a full run)
+                print("loaded", os.path.basename(path), "bits", bits, flush=True)
+                continue
             n_streams, block = 3, 64
             T = 64 * int(rng.integers(3, 7)) + int(rng.integers(0, 64))
             x = stream_bank(n_streams, T, seed=i)
@@ -102,9 +108,12 @@ def main():
             errs = {}
             kernels = [("generic", nam.KERNEL_GENERIC)] + ([("valu", nam.KERNEL_A1)] if bits & 1 else []) + ([("mfma", nam.KERNEL_A1_MFMA)] if bits & 2 else []) + ([("wn_reg", nam.KERNEL_WN_REG)] if bits & 16 else [])
             for kname, k in kernels:
-                for mode, mf in (("blocks", block), ("one", 512)):
+                for mode, mf in (("blocks", block), ("one", 512), ("session", block)):
                     b = model.batch(n_streams, mf)
                     b.set_kernel(k)
+                    if mode == "session" and not b.set_persistent(True):  # 64-frame buffers as commands of a persistent session
+                        b.close()
+                        continue
                     b.Reset(prewarm=True)
                     if mode == "one":
                         ref2 = nam_oracle.get_dsp(path, fast_tanh=ft); ref2.Reset(48000.0, mf); rr = ref2.process_stream(x[1], mf)
