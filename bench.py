@@ -231,6 +231,20 @@ def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: f
                                                             "note": "oracle/_ref/libnam_ref.so, -O2, scalar Eigen stand-in"}
     except Exception as e:  # the checker library is optional
         out["reference_sources_on_eigen_stand_in"] = {"error": str(e)[:200]}
+    # A2.nam: what the reference itself runs for this shape is its fused wavenet/a2_fast.cpp path (fixed-size matrices: the
+    # scalar Eigen stand-in costs it little) — timed too where the checker library travelled
+    try:
+        import nam_ref
+        if os.path.basename(model_path) == "A2.nam" and os.path.exists(getattr(nam_ref, "LIB_A2FAST", "")):
+            r = nam_ref.get_dsp(model_path, fast_tanh, a2_fast=True)
+            r.Reset(SR, block)
+            xr = two_tone(int(min(secs_audio, 20.0) * SR))
+            t0 = time.perf_counter()
+            r.process_stream(xr, block)
+            out["reference_a2_fast_path"] = {"value": round(len(xr) / SR / (time.perf_counter() - t0), 3), "cores": 1,
+                                             "note": "oracle/_ref/libnam_ref_a2fast.so = the reference's wavenet/a2_fast.cpp, unmodified, -O2"}
+    except Exception as e:
+        out["reference_a2_fast_path"] = {"error": str(e)[:200]}
     return out
 
 
