@@ -190,6 +190,7 @@ struct nam_hip_batch
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
+  bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
   int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
@@ -487,7 +488,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   // launch holds more than one buffer and the chip has the SIMDs for it — config 4's 512 streams become 1,024
   // wavefronts, 256 streams too
   int stages = 1;
-  if (!b->no_pipe && (b->ps_launching || n_frames > kBlock))
+  if (!b->no_pipe && !b->one_buffer_call && (b->ps_launching || n_frames > kBlock))
   {
     const int cus = std::max(b->n_cus, 1);
     const int per_cu = (total + cus - 1) / cus;
@@ -1454,10 +1455,15 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
 #else
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
 #endif
+  b->one_buffer_call = n_frames == kBlock; // (one command, then the caller waits: the stages of a pipeline would only queue up)
   const int rc = persist_submit(b, b->in_bar, b->d_out_map, n_frames, stride, b->stream);
   if (rc != NAM_HIP_OK)
+  {
+    b->one_buffer_call = false;
     return rc < 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: the host-mapped buffer was refused");
+  }
   const int rw = persist_flush(b, b->stream);
+  b->one_buffer_call = false;
   if (rw != NAM_HIP_OK)
     return rw;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
