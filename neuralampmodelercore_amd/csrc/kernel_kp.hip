@@ -526,7 +526,7 @@ __global__ __launch_bounds__(NST * 256) void nam_kp_kernel(const float* __restri
               // the early look missed: look again; while the later stages still work, for a few microseconds (bounded:
               // the launch never waits for a command)
               v = ring_load(tag - 1u);
-              const long long t_end = (long long)wall_clock64() + 300; // 3 us of the 100 MHz clock
+              const long long t_end = (long long)wall_clock64() + 100; // 1 us of the 100 MHz clock
               while ((unsigned)(v >> 32) != tag && (long long)wall_clock64() < t_end)
               {
                 __builtin_amdgcn_s_sleep(16);
