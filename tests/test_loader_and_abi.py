@@ -60,6 +60,19 @@ def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
     assert nam_lib.get_dsp(model_path(name)).info.has_a1_kernel == bits
 
 
+def test_the_a2_pipeline_kernel_is_offered_to_the_a2_topology_only(nam_lib):
+    """nam_kp_kernel is compiled for ONE topology (csrc/kp_table.h: the A2 stack of the reference's fused path,
+    wavenet/a2_fast.cpp): plan.cpp: build_a1_kp checks a model against the table layer by layer — kernel sizes, dilations,
+    ring geometry, chunk and tile offsets — and only A2.nam's 8-channel submodel passes; other K-tap models keep the
+    descriptor-driven kernel (kt_mfma=1, kp=0); A2-Lite (3 channels) runs on nam_wn_reg_kernel."""
+    d = nam_lib.get_dsp(model_path("A2")).describe()
+    lite, full = d.split(" | plan 1:")
+    assert " kt_mfma=1 kp=1 " in full and " kp=0 " in lite and " wn_reg=1" in lite
+    for other in ("synth_kt_c8", "synth_kt_c16", "wavenet_a1_standard"):
+        assert " kp=0 " in nam_lib.get_dsp(model_path(other)).describe(), other
+    assert " kt_mfma=1 " in nam_lib.get_dsp(model_path("synth_kt_c8")).describe()
+
+
 def test_missing_file_is_validation_error(nam_lib):
     with pytest.raises(nam_lib.NamFileValidationError):
         nam_lib.get_dsp(os.path.join(MODELS, "does_not_exist.nam"))
