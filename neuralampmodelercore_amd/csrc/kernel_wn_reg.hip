@@ -693,6 +693,47 @@ __device__ __forceinline__ void wr_array_end_k(WrRegs& r, const WrOpS& op, char*
   wr_unpack<HS>(r.hout, o);
 }
 
+// one layer of the post-stack head (detail::Head::process, model.cpp:86-103; built :21-44): the activation on the input — the last
+// array's head output times head_scale for the first layer (:854-866), the previous layer's output after that —, then a
+// Conv1D(kernel KH, dilation 1, bias) whose history is of the ACTIVATED input (the reference activates in place before
+// Conv1D::Process). W^T = [KH * HI][pad4(HS)] | bias | activation parameters.
+template <int HI, int HS, int KH, int ACT>
+__device__ __forceinline__ void wr_post_head(WrRegs& r, const WrOpS& op, char* lds, int lane, int posv)
+{
+  WrMat<HS, KH * HI> m;
+  const unsigned wb = (unsigned)op.w * 4u, bb = wb + (unsigned)(KH * HI * wr_pad4(HS)) * 4u;
+  wr_ld(m, lds, wb, true, bb);
+  WrActP<HI> ap;
+  wr_ld(ap, lds, bb + (unsigned)wr_pad4(HS) * 4u);
+  const float sc = op.scale();
+  float v[kWrRegs];
+#pragma unroll
+  for (int i = 0; i < HI; i++)
+    v[i] = wr_act1<ACT>(sc * r.hout[i], ap.p[0], ap.p[1], ap.p[2], ap.p[3], ap.slope[i >> 2][i & 3]);
+  float taps[KH * HI];
+  if constexpr (KH > 1)
+  {
+    const int R = op.ring;
+    int widx = __builtin_amdgcn_readlane(posv, op.slot) + lane;
+    widx -= widx >= R ? R : 0;
+    const unsigned hb = (unsigned)op.hist * 4u;
+    wr_ring_put<HI>(lds, hb, widx, R, v);
+#pragma unroll
+    for (int k = 0; k + 1 < KH; k++)
+    {
+      int idx = widx - (KH - 1 - k);
+      idx += idx < 0 ? R : 0;
+      wr_ring_get<HI>(lds, hb, idx, R, taps + k * HI);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < HI; i++)
+    taps[(KH - 1) * HI + i] = v[i];
+  f2 o[wr_pairs(HS)];
+  wr_mv(o, taps, m);
+  wr_unpack<HS>(r.hout, o);
+}
+
 } // namespace
 
 // SET: which layer code the instantiation carries — 0: the fully described WR_LAYER shapes only (wavenet_a2_max: 344
@@ -1083,6 +1124,16 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
 #define X(ID, IN, OUT, KH) \
   case ID: wr_array_end_k<IN, OUT, KH>(r, cur, lds, lane, posv); break;
             WR_HEADK_SHAPES(X)
+#undef X
+            default: __builtin_trap();
+          }
+          break;
+        case WR_POST_HEAD:
+          switch (cur.shape)
+          {
+#define X(ID, IN, OUT, KH, ACT) \
+  case ID: wr_post_head<IN, OUT, KH, ACT>(r, cur, lds, lane, posv); break;
+            WR_POSTHEAD_SHAPES(X)
 #undef X
             default: __builtin_trap();
           }

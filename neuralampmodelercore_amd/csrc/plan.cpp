@@ -1420,8 +1420,8 @@ struct WrBuilder
 
   void net(const WaveNetSpec& wn, bool nested)
   {
-    if (wn.with_head)
-      throw Unsupported("a post-stack head");
+    if (wn.with_head && (policy != JIT || !dyn || nested))
+      throw Unsupported("a post-stack head (no ahead-of-time shapes: it needs the per-model compile)");
     if (wn.in_channels > kWrRegs || wn.out_channels() > kWrRegs)
       throw Unsupported("more than 8 input / output channels");
     if ((long)wn.weights.size() != wn.expected_weight_count())
@@ -1615,14 +1615,57 @@ struct WrBuilder
         wr.n_layers++; // (a slot: one write position per ring)
       }
     }
+    // the post-stack head (model.cpp:21-103, applied :854-866): activation + Conv1D per entry of kernel_sizes, on the
+    // last array's head output times head_scale; head_scale itself follows the head's weights in the stream
+    size_t first_post = 0;
+    if (wn.with_head)
+    {
+      const PostHeadSpec& H = wn.head;
+      if (H.in_channels != wn.arrays.back().head_size || H.kernel_sizes.empty())
+        throw Unsupported("a post-stack head whose input is not the last array's head output");
+      first_post = wr.ops.size();
+      int cin = H.in_channels;
+      for (size_t i = 0; i < H.kernel_sizes.size(); i++)
+      {
+        const int cout = (i + 1 == H.kernel_sizes.size()) ? H.out_channels : H.channels;
+        const int K = H.kernel_sizes[i];
+        if (cin > kWrRegs || cout > kWrRegs || K * cin > 64 || K * cin * wr_pad4(cout) > 320)
+          throw Unsupported("a post-stack head layer of more than 8 channels / 64 tap inputs / 320 weights");
+        if (H.activation.type == ACT_LUT)
+          throw Unsupported("a lookup-table activation in the post-stack head");
+        const int off = reserve(K * cin * wr_pad4(cout) + wr_pad4(cout) + kWrActFloats);
+        dense(&wr.blob[(size_t)off], w, cin, cout, K, 1);
+        for (int o = 0; o < cout; o++) // Conv1D bias (always: set_size_(cin, cout, k, true, 1, 1))
+          wr.blob[(size_t)off + (size_t)K * cin * wr_pad4(cout) + o] = *(w++);
+        act_block(&wr.blob[(size_t)off + (size_t)K * cin * wr_pad4(cout) + wr_pad4(cout)], H.activation, cin);
+        WrOp& op = push(WR_POST_HEAD);
+        op.n_in = cin;
+        op.n_out = cout;
+        op.shape = dyn->post(cin, cout, K, H.activation.type);
+        op.w = off;
+        op.act = H.activation.type;
+        op.scale = 1.0f;
+        op.dil = 1;
+        if (K > 1)
+        {
+          op.slot = (int)ring_of_slot.size();
+          op.hist = ring_area(cin, K, 1); // + the ring area's base, below
+          op.ring = (K - 1) + kBlock;
+          wr.n_layers++;
+        }
+        cin = cout;
+      }
+    }
     const float head_scale = *(w++);
     if (w != wn.weights.data() + wn.weights.size())
       throw std::runtime_error("plan: internal error, weight stream not fully consumed (register-resident plan)");
+    if (wn.with_head)
+      wr.ops[first_post].scale = head_scale;
     if (!nested)
     {
       WrOp& op = push(WR_OUTPUT);
       op.n_out = wn.out_channels();
-      op.scale = head_scale;
+      op.scale = wn.with_head ? 1.0f : head_scale;
     }
   }
 };
@@ -1692,6 +1735,14 @@ int WrShapeSet::run(int C, int act)
   runs.push_back({C, act});
   return (int)runs.size() - 1;
 }
+int WrShapeSet::post(int n_in, int n_out, int K, int act)
+{
+  for (size_t i = 0; i < posts.size(); i++)
+    if (posts[i].n_in == n_in && posts[i].n_out == n_out && posts[i].K == K && posts[i].act == act)
+      return (int)i;
+  posts.push_back({n_in, n_out, K, act});
+  return (int)posts.size() - 1;
+}
 int WrShapeSet::head(int n_in, int n_out, int K)
 {
   for (size_t i = 0; i < heads.size(); i++)
@@ -1729,6 +1780,9 @@ std::string WrShapeSet::header_text() const
   ss << "\n#define WR_HEADK_SHAPES(X)";
   for (size_t i = 0; i < heads.size(); i++)
     ss << " X(" << i << ", " << heads[i].n_in << ", " << heads[i].n_out << ", " << heads[i].K << ")";
+  ss << "\n#define WR_POSTHEAD_SHAPES(X)";
+  for (size_t i = 0; i < posts.size(); i++)
+    ss << " X(" << i << ", " << posts[i].n_in << ", " << posts[i].n_out << ", " << posts[i].K << ", " << posts[i].act << ")";
   ss << "\n";
   return ss.str();
 }
@@ -1797,7 +1851,7 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
     wr.tab_ops = b.reserve((int)wr.ops.size() * 16); // the macro-ops themselves: fetched from LDS, one op ahead
     const int hist_base = (int)wr.blob.size(); // LDS: weights, tables, program | rings
     for (auto& op : wr.ops)
-      if (op.type == WR_LAYER || op.type == WR_ARRAY_END_K)
+      if (op.type == WR_LAYER || op.type == WR_ARRAY_END_K || (op.type == WR_POST_HEAD && op.ring > 0))
         op.hist += hist_base;
     for (const auto& run : runs)
     {
@@ -1816,7 +1870,7 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
       // the next larger one.
       std::vector<int> ws;
       for (const auto& op : wr.ops)
-        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K)
+        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K || op.type == WR_POST_HEAD)
           ws.push_back(op.w);
       ws.push_back(wr.tab_rows); // (the first table: the end of the weights)
       std::sort(ws.begin(), ws.end());
@@ -1825,7 +1879,7 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
       for (size_t i = 0; i < wr.ops.size(); i++)
       {
         const auto& op = wr.ops[i];
-        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K)
+        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K || op.type == WR_POST_HEAD)
         {
           const auto nx = std::upper_bound(ws.begin(), ws.end(), op.w);
           cost[i] += nx != ws.end() ? *nx - op.w : 0;

@@ -401,7 +401,8 @@ enum WrOpType : int32_t
   WR_RUN = 5,
   // head rechannel WITH TAPS (model.cpp:399-400, 547-548: a Conv1D of kernel size K_h over the head accumulator): the
   // head accumulator has a ring of its own (`hist`, `ring`, `dil`, `slot` as in WR_LAYER). Per-model compile only.
-  WR_ARRAY_END_K = 6
+  WR_ARRAY_END_K = 6,
+  WR_POST_HEAD = 7 // one layer of the post-stack head: activation, Conv1D (per-model compiled shapes only)
 };
 
 struct WrOp // 16 x int32 = 64 bytes
@@ -498,6 +499,8 @@ struct WrPlan
   X(11, 8, 1) X(12, 8, 4) X(13, 4, 2) X(14, 2, 2) X(15, 3, 3) X(16, 8, 8) X(17, 2, 4) X(18, 3, 2) X(19, 6, 1) X(20, 1, 1) X(21, 2, 3) X(22, 4, 3) X(23, 3, 8) X(24, 2, 8)
 // head rechannels with taps: (id, head accumulator rows, head size, kernel size) — none ahead of time
 #define WR_HEADK_SHAPES(X)
+// post-stack head layers (id, inputs, outputs, kernel size, activation): per-model compiled shapes only
+#define WR_POSTHEAD_SHAPES(X)
 #endif
 // The shapes of one model (or of all the sub-models of a slimmable one), collected while it is planned, for the
 // per-model compile: ids are positions in these lists.
@@ -524,10 +527,16 @@ struct WrShapeSet
   std::vector<Pair> pairs;
   std::vector<HeadK> heads; // head rechannels with kernel size > 1
   int head(int n_in, int n_out, int K);
+  struct PostHead
+  {
+    int n_in, n_out, K, act;
+  };
+  std::vector<PostHead> posts; // post-stack head layers
+  int post(int n_in, int n_out, int K, int act);
   int layer(int cond, int C, int B, bool G, int K, int HO, int flags, int act, int act2, bool l1);
   int run(int C, int act);
   int pair(int n_in, int n_out);
-  bool empty() const { return layers.empty() && runs.empty() && pairs.empty() && heads.empty(); }
+  bool empty() const { return layers.empty() && runs.empty() && pairs.empty() && heads.empty() && posts.empty(); }
   std::string header_text() const; // the generated tables: "#define NAM_WR_JIT_SHAPES 1 / #define WR_LAYER_SHAPES(X) ..."
 };
 // id of a shape in the ahead-of-time tables, -1 = not instantiated

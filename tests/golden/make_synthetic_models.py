@@ -373,8 +373,32 @@ def random_featured(rng, wr_shapes=False, allow_condition_dsp=True, in_channels=
                 sample_rate=48000)
 
 
-def write_featured(path, seed, wr_shapes=False):
-    """Seeded feature-rich model -> `path`; returns the model dict."""
+POST_HEAD_ACTS = ["ReLU", "Tanh", "SiLU", "Hardtanh", "Sigmoid", "Softsign", dict(type="LeakyReLU", negative_slope=0.05)]
+
+
+def add_post_head(m, rng):
+    """A post-stack head (model.cpp:21-103: activation -> Conv1D(kernel_sizes[i], bias) per entry, `channels` wide inside)
+    behind the last array of model dict `m`: its weights go between the arrays' and head_scale (:661-683)."""
+    cfg = m["config"]
+    last = cfg["layers"][-1]
+    cin = last["head"]["out_channels"] if "head" in last else last["head_size"]
+    ks = [int(rng.choice([1, 2, 3, 5])) for _ in range(int(rng.integers(1, 4)))]
+    head = dict(channels=int(rng.integers(1, 7)), out_channels=int(rng.choice([1, 1, 2, 3])), kernel_sizes=ks,
+                activation=POST_HEAD_ACTS[int(rng.integers(len(POST_HEAD_ACTS)))])
+    w = []
+    for i, k in enumerate(ks):
+        cout = head["out_channels"] if i + 1 == len(ks) else head["channels"]
+        w += (rng.standard_normal(cout * cin * k).astype(np.float32) * np.float32(0.6 / np.sqrt(cin * k))).tolist()
+        w += (rng.standard_normal(cout).astype(np.float32) * np.float32(0.1)).tolist()
+        cin = cout
+    m["weights"] = m["weights"][:-1] + w + m["weights"][-1:]
+    cfg["head"] = head
+    return m
+
+
+def write_featured(path, seed, wr_shapes=False, post_head=False):
+    """Seeded feature-rich model -> `path`; returns the model dict. post_head: with a random post-stack head (drawn from
+    a generator of its own: the arrays of a seed are the same with and without it)."""
     rng = np.random.default_rng(seed)
     while True:
         try:
@@ -382,6 +406,8 @@ def write_featured(path, seed, wr_shapes=False):
             break
         except ValueError:
             continue
+    if post_head:
+        add_post_head(m, np.random.default_rng(seed + 50_000))
     with open(path, "w") as f:
         json.dump(m, f)
     return m

@@ -51,7 +51,7 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
     # FiLMs / gating / nested condition_dsp / multi-channel: the register-resident kernel (bit 4) where every layer is
     # one of its instantiated shapes, else the op interpreter alone (a post-stack head)
     ("wavenet_a2_max", 16), ("wavenet_condition_dsp", 16), ("synth_multich", 16), ("synth_leakyhardtanh", 16),
-    ("synth_posthead", 0), ("wavenet", 17),
+    ("synth_posthead", 16), ("wavenet", 17),
     ("lstm", 0)])
 def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
     """has_a1_kernel: bit 0 = the VALU A1 kernel, bit 1 = one of the MFMA kernels (plan.cpp: build_a1 / build_a1_ws /

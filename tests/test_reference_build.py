@@ -140,7 +140,7 @@ def test_reference_error_messages_match_the_loader(nam_lib, tmp_path):
         assert str(ref_err.value) in str(our_err.value), (tag, str(ref_err.value), str(our_err.value))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(50))
 def test_featured_models_oracle_bit_exact_with_the_reference(oracle, nam_lib, tmp_path, seed):
     """The seeded feature-rich models of tests/test_gpu_breadth.py (per-layer gating / blending, FiLM subsets, grouped
     convs, head1x1, bottlenecks, nested condition_dsp — the cases of the reference's own feature tests,
@@ -150,7 +150,7 @@ def test_featured_models_oracle_bit_exact_with_the_reference(oracle, nam_lib, tm
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_synthetic_models as msm
     path = str(tmp_path / f"featured_{seed}.nam")
-    msm.write_featured(path, 7000 + seed, wr_shapes=bool(seed % 2))
+    msm.write_featured(path, 7000 + seed, wr_shapes=bool(seed % 2), post_head=seed >= 40)
     model = nam_lib.get_dsp(path)
     for fast_tanh in (False, True):
         ref = nam_ref.get_dsp(path, fast_tanh)

@@ -20,9 +20,9 @@ def main():
             nam.get_dsp(p, fast_tanh=ft)
             n += 1
     with tempfile.TemporaryDirectory() as tmp:
-        for seed in range(40):  # tests/test_gpu_breadth.py: FEATURED_SEEDS
+        for seed in range(50):  # tests/test_gpu_breadth.py: FEATURED_SEEDS (40 ..: with a post-stack head)
             p = os.path.join(tmp, f"featured_{seed}.nam")
-            msm.write_featured(p, 7000 + seed, wr_shapes=bool(seed % 2))
+            msm.write_featured(p, 7000 + seed, wr_shapes=bool(seed % 2), post_head=seed >= 40)
             m = nam.get_dsp(p, fast_tanh=seed % 3 == 0)
             acc += bool(m.info.has_a1_kernel & 16)
             n += 1
@@ -31,7 +31,7 @@ def main():
         if os.path.getmtime(f) < stamp:
             os.remove(f)
             pruned += 1
-    print(f"warm_jit_cache: {n} loads in {time.time() - t0:.1f} s, {acc} / 40 feature-rich models on nam_wn_reg_kernel, "
+    print(f"warm_jit_cache: {n} loads in {time.time() - t0:.1f} s, {acc} / 50 feature-rich models on nam_wn_reg_kernel, "
           f"{len(glob.glob(os.path.join(cache, '*.hsaco')))} code objects in {cache} ({pruned} stale files pruned)")
 
 
