@@ -77,8 +77,9 @@ def random_featured(rng, tmp, idx):
     os.makedirs(os.path.join(tmp, "models"), exist_ok=True)
     path = os.path.join(tmp, "models", f"fuzz_ft_{idx}.nam")
     wr = bool((idx // 4) % 2)
-    msm.write_featured(path, int(rng.integers(1 << 30)), wr_shapes=wr)
-    return path, dict(featured=True, wr_shapes=wr)
+    post = (idx // 8) % 2 == 1  # every other pair of feature-rich models: + a random post-stack head
+    msm.write_featured(path, int(rng.integers(1 << 30)), wr_shapes=wr, post_head=post)
+    return path, dict(featured=True, wr_shapes=wr, post_head=post)
 
 
 def main():
