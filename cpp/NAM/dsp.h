@@ -281,6 +281,16 @@ public:
     detail::check(nam_hip_batch_set_slimmable_size(mBatch.get(), stream_ids, n, ratio));
   }
   bool IsSlimmable() const { return mInfo.is_slimmable != 0; }
+  // Device-resident audio (a server that keeps its streams' buffers in HBM): planar float32 DEVICE pointers
+  // [stream][channel][frame_stride]; enqueue-only. In the persistent block mode (on since Reset) a call of a multiple of 64
+  // frames is num_frames / 64 commands of the session and costs the host ~1.5 us; flush() returns when every submitted
+  // buffer is rendered and visible. `hip_stream`: the hipStream_t the input was produced on (nullptr = the batch's own).
+  void process_device(const float* d_in, float* d_out, const int num_frames, const int64_t frame_stride, void* hip_stream = nullptr)
+  {
+    detail::check(nam_hip_batch_process_device(mBatch.get(), d_in, d_out, num_frames, frame_stride, hip_stream));
+  }
+  void flush(void* hip_stream = nullptr) { detail::check(nam_hip_batch_flush(mBatch.get(), hip_stream)); }
+  void synchronize() { detail::check(nam_hip_batch_synchronize(mBatch.get())); }
   // Offline re-amp of one whole signal per stream (lengths may differ); planar float32 host buffers.
   void render(const float* const* in, float* const* out, const int64_t* n_frames)
   {

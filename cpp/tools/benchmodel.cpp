@@ -82,7 +82,7 @@ int main(int argc, char* argv[])
 {
   if (argc < 2)
   {
-    std::cerr << "Usage: benchmodel <model_path> [--slim <0..1>] [--no-fast-tanh] [--streams N] [--count-allocs]\n";
+    std::cerr << "Usage: benchmodel <model_path> [--slim <0..1>] [--no-fast-tanh] [--streams N [--resident]] [--buffer N] [--count-allocs]\n";
     return 1;
   }
   const char* modelPath = argv[1];
@@ -90,7 +90,7 @@ int main(int argc, char* argv[])
   bool fast_tanh = true;
   int streams = 1;
   int bufferSize = AUDIO_BUFFER_SIZE;
-  bool count_allocs = false;
+  bool count_allocs = false, resident = false;
   for (int i = 2; i < argc; i++)
   {
     if (!std::strcmp(argv[i], "--count-allocs"))
@@ -103,6 +103,8 @@ int main(int argc, char* argv[])
       streams = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--buffer") && i + 1 < argc) // frames per process() call (the reference's tool: 64)
       bufferSize = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--resident")) // with --streams: the audio stays in device memory (BatchDSP::process_device)
+      resident = true;
   }
   if (fast_tanh)
     nam::activations::Activation::enable_fast_tanh();
@@ -150,6 +152,58 @@ int main(int argc, char* argv[])
       std::shared_ptr<nam_hip_model> m(raw, nam::detail::ModelDeleter());
       nam::BatchDSP batch(m, streams);
       batch.Reset(48000.0, bufferSize);
+      if (resident)
+      {
+        // The server shape: the streams' audio lives in device memory (a window of 64 buffers per stream, walked round
+        // and round), every buffer is one enqueue-only call, the host waits once per window. Device memory comes from the
+        // HIP runtime libnam_hip.so already brought into the process (this tool is plain C++: no HIP headers).
+        using malloc_fn = int (*)(void**, size_t);
+        using memset_fn = int (*)(void*, int, size_t);
+        using free_fn = int (*)(void*);
+        void* hip = nullptr;
+        for (const char* name : {"libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"}) // the copy that is already loaded
+          if (!hip)
+            hip = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (!hip)
+          hip = dlopen("libamdhip64.so", RTLD_NOW);
+        auto hipMalloc_ = hip ? reinterpret_cast<malloc_fn>(dlsym(hip, "hipMalloc")) : nullptr;
+        auto hipMemset_ = hip ? reinterpret_cast<memset_fn>(dlsym(hip, "hipMemset")) : nullptr;
+        auto hipFree_ = hip ? reinterpret_cast<free_fn>(dlsym(hip, "hipFree")) : nullptr;
+        if (!hipMalloc_ || !hipMemset_ || !hipFree_)
+          throw std::runtime_error("--resident: the HIP runtime's hipMalloc / hipMemset / hipFree were not found");
+        const int kWindow = 64;
+        const int64_t stride = (int64_t)kWindow * bufferSize;
+        const size_t in_bytes = (size_t)streams * batch.NumInputChannels() * stride * sizeof(float),
+                     out_bytes = (size_t)streams * batch.NumOutputChannels() * stride * sizeof(float);
+        float *d_in = nullptr, *d_out = nullptr;
+        if (hipMalloc_(reinterpret_cast<void**>(&d_in), in_bytes) != 0 || hipMalloc_(reinterpret_cast<void**>(&d_out), out_bytes) != 0)
+          throw std::runtime_error("--resident: hipMalloc failed");
+        hipMemset_(d_in, 0, in_bytes);
+        hipMemset_(d_out, 0, out_bytes);
+        batch.synchronize();
+        std::cout << "Running benchmark (" << streams << " streams, device-resident buffers)\n";
+        auto pass = [&](size_t n) {
+          for (size_t i = 0; i < n; i++)
+          {
+            const int64_t off = (int64_t)(i % kWindow) * bufferSize;
+            batch.process_device(d_in + off, d_out + off, bufferSize, stride);
+            if ((i + 1) % kWindow == 0)
+              batch.flush();
+          }
+          batch.flush();
+          batch.synchronize();
+        };
+        pass(4 * kWindow); // warm-up (clocks, session start)
+        auto t1 = high_resolution_clock::now();
+        pass(numBuffers);
+        auto t2 = high_resolution_clock::now();
+        duration<double, std::milli> ms = t2 - t1;
+        std::cout << ms.count() << "ms for 2 s x " << streams << " streams = " << 2000.0 * streams / ms.count() << " x real time ("
+                  << ms.count() * 1e3 / (double)numBuffers << " us per buffer, one flush per " << kWindow << " buffers)\n";
+        hipFree_(d_in);
+        hipFree_(d_out);
+        return 0;
+      }
       std::vector<float> in((size_t)streams * batch.NumInputChannels() * bufferSize, 0.0f),
         out((size_t)streams * batch.NumOutputChannels() * bufferSize, 0.0f);
       std::cout << "Running benchmark (" << streams << " streams, host buffers)\n";

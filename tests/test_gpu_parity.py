@@ -328,7 +328,9 @@ def test_cpp_adapter_benchmodel_runs(nam_lib):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "cpp")])
     for args in ([model_path("wavenet")], [model_path("lstm")], [model_path("slimmable_wavenet"), "--slim", "0.5"],
-                 [model_path("wavenet_a1_standard"), "--streams", "64"], [model_path("A2")], [model_path("A2"), "--slim", "0.2"]):
+                 [model_path("wavenet_a1_standard"), "--streams", "64"], [model_path("A2")], [model_path("A2"), "--slim", "0.2"],
+                 # device-resident buffers through BatchDSP::process_device / flush (sessions; 300 streams: more than CUs)
+                 [model_path("wavenet_a1_standard"), "--streams", "300", "--resident"], [model_path("wavenet_a2_max"), "--streams", "40", "--resident"]):
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         assert "ms" in out.stdout
