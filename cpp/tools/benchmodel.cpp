@@ -91,6 +91,7 @@ int main(int argc, char* argv[])
   int streams = 1;
   int bufferSize = AUDIO_BUFFER_SIZE;
   bool count_allocs = false, resident = false;
+  const char* kernelName = "auto";
   for (int i = 2; i < argc; i++)
   {
     if (!std::strcmp(argv[i], "--count-allocs"))
@@ -105,6 +106,8 @@ int main(int argc, char* argv[])
       bufferSize = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--resident")) // with --streams: the audio stays in device memory (BatchDSP::process_device)
       resident = true;
+    else if (!std::strcmp(argv[i], "--kernel") && i + 1 < argc) // with --streams: auto | generic | a1 | a1_mfma | a1_il | wn_reg (A/B runs)
+      kernelName = argv[++i];
   }
   if (fast_tanh)
     nam::activations::Activation::enable_fast_tanh();
@@ -152,6 +155,19 @@ int main(int argc, char* argv[])
       std::shared_ptr<nam_hip_model> m(raw, nam::detail::ModelDeleter());
       nam::BatchDSP batch(m, streams);
       batch.Reset(48000.0, bufferSize);
+      if (std::strcmp(kernelName, "auto"))
+      {
+        const int k = !std::strcmp(kernelName, "generic") ? NAM_HIP_KERNEL_GENERIC
+                      : !std::strcmp(kernelName, "a1")    ? NAM_HIP_KERNEL_A1
+                      : !std::strcmp(kernelName, "a1_mfma") ? NAM_HIP_KERNEL_A1_MFMA
+                      : !std::strcmp(kernelName, "a1_il") ? NAM_HIP_KERNEL_A1_IL
+                                                          : NAM_HIP_KERNEL_WN_REG;
+        nam::detail::check(nam_hip_batch_set_kernel(batch.GetBatchHandle(), k));
+        batch.Reset(48000.0, bufferSize);
+      }
+      if (slim >= 0.0) // (every stream at that size)
+        batch.SetSlimmableSize(nullptr, 0, slim);
+      std::cout << "kernel: " << nam_hip_batch_kernel_name_for(batch.GetBatchHandle(), bufferSize) << "\n";
       if (resident)
       {
         // The server shape: the streams' audio lives in device memory (a window of 64 buffers per stream, walked round

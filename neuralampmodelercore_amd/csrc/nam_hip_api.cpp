@@ -311,7 +311,20 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
       // narrow models (1 .. 8 channels in the instantiated layer shapes) keep their whole dilation history in LDS on
       // nam_wn_reg_kernel; the VALU kernel fetches it from the HBM rings layer by layer
       if (!mfma)
+      {
+        // ... as long as the batch fits the chip that way (LDS image x streams per CU): beyond it no session can hold the
+        // batch and every buffer is a launch that moves the image's windows in and out — a plain model then runs its
+        // HBM rings on the VALU kernel (A2-Lite, 105 KB of rings per stream: 8.1 k xRT at any stream count this way
+        // against 13.2 k / 21.7 k / 40.5 k at 512 / 1,024 / 2,048 streams on the VALU kernel; 48.6 k in a session at 256).
+        // Decided on the batch's stream count, which never changes: the two kernels keep different state layouts.
+        if (wr && a1)
+        {
+          const int per_cu = std::min(4, (160 * 1024) / (g.plan->wr.lds_bytes + 512));
+          if (b->n_streams > std::max(per_cu, 1) * std::max(b->n_cus, 1))
+            return NAM_HIP_KERNEL_A1;
+        }
         return wr ? NAM_HIP_KERNEL_WN_REG : fallback;
+      }
       // The K-tap kernel (A2 shapes) spreads a stream over four wavefronts: 2.3x the VALU kernel while the chip has
       // idle SIMDs, level with it at ~1,000 streams per GPU, behind it beyond (it issues more instructions per tap).
       if (!g.plan->a1.ws_ok && g.streams.size() > kKtAutoMaxStreams)
