@@ -227,7 +227,7 @@ NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* cons
  * Outputs are NOT ordered on the caller's stream: call nam_hip_batch_flush (or nam_hip_batch_synchronize, or use the
  * blocking *_f32 / *_f64 entry points, which do it) before consuming them.
  * Eligible: one width group on nam_a1_p4_kernel / nam_kp_kernel up to 8 streams per CU (beyond one per CU the workgroups
- * take turns on the chip); every group on nam_wn_reg_kernel up to min(4, 160 KB / LDS image) streams per CU; small LSTMs.
+ * take turns on the chip); every group on nam_wn_reg_kernel up to 8 x min(4, 160 KB / LDS image) streams per CU (in turns too); small LSTMs.
  * Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual). */
 NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);
 /* Blocks until every buffer submitted so far has been rendered and is visible (hip_stream: the stream the process

@@ -291,6 +291,7 @@ int refresh_map(nam_hip_batch* b, WidthGroup& g)
 // Which kernel a WaveNet group runs: explicit choice if possible, otherwise the fastest available.
 constexpr size_t kKtAutoMaxStreams = 1024;
 
+constexpr int kPersistTurns = 8; // sessions whose workgroups cannot all be on the chip at once: up to this many turns (they consume the same commands one after the other)
 int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 {
   const bool a1 = g.plan->a1.valid && g.d_a1;
@@ -313,14 +314,15 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
       if (!mfma)
       {
         // ... as long as the batch fits the chip that way (LDS image x streams per CU): beyond it no session can hold the
-        // batch and every buffer is a launch that moves the image's windows in and out — a plain model then runs its
-        // HBM rings on the VALU kernel (A2-Lite, 105 KB of rings per stream: 8.1 k xRT at any stream count this way
-        // against 13.2 k / 21.7 k / 40.5 k at 512 / 1,024 / 2,048 streams on the VALU kernel; 48.6 k in a session at 256).
+        // batch (its workgroups may take turns on the chip: kPersistTurns) and every buffer is a launch that moves the
+        // image's windows in and out — a plain model then runs its HBM rings on the VALU kernel (A2-Lite, 105 KB of rings
+        // per stream: 8.1 k xRT at any stream count with a launch per buffer, 13.2 k / 21.7 k / 40.5 k at 512 / 1,024 / 2,048
+        // streams on the VALU kernel; 48.6 k in a session at 256).
         // Decided on the batch's stream count, which never changes: the two kernels keep different state layouts.
         if (wr && a1)
         {
           const int per_cu = std::min(4, (160 * 1024) / (g.plan->wr.lds_bytes + 512));
-          if (b->n_streams > std::max(per_cu, 1) * std::max(b->n_cus, 1))
+          if (b->n_streams > kPersistTurns * std::max(per_cu, 1) * std::max(b->n_cus, 1)) // (a session's workgroups may take turns)
             return NAM_HIP_KERNEL_A1;
         }
         return wr ? NAM_HIP_KERNEL_WN_REG : fallback;
@@ -503,16 +505,26 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   int stages = 1;
   if (!b->no_pipe && !b->one_buffer_call && (b->ps_launching || n_frames > kBlock))
   {
+    // the launch's relative duration with nst waves per stream: a workgroup is nst waves at one wave per SIMD plus its LDS
+    // image (and the queues), the workgroups beyond what the chip holds run in later turns (persist_kind), and a stream's
+    // buffer takes 1, 1/1.75, 1/3.1 of the one-wave time (measured: DESIGN 4.5)
     const int cus = std::max(b->n_cus, 1);
-    const int per_cu = (total + cus - 1) / cus;
-    auto fits = [&](int nst) {
+    auto duration = [&](int nst) {
       const int lds = lds_bytes + (nst - 1) * kWrQueueBytes;
-      return nst * total <= 4 * cus && lds <= kWrMaxLdsBytes && per_cu * (lds + 512) <= 160 * 1024;
+      if (lds > kWrMaxLdsBytes)
+        return 1e9;
+      const int on_chip = cus * std::min(4 / nst, (160 * 1024) / (lds + 512));
+      const double speed = nst == 4 ? 3.1 : nst == 2 ? 1.75 : 1.0;
+      return double((total + on_chip - 1) / on_chip) / speed;
     };
-    if (can_split && can_split4 && b->wr_max_stages >= 4 && fits(4))
-      stages = 4;
-    else if (can_split && b->wr_max_stages >= 2 && fits(2))
+    double best = duration(1);
+    if (can_split && b->wr_max_stages >= 2 && duration(2) < best)
+    {
       stages = 2;
+      best = duration(2);
+    }
+    if (can_split && can_split4 && b->wr_max_stages >= 4 && duration(4) < best)
+      stages = 4;
     lds_bytes += (stages - 1) * kWrQueueBytes;
   }
   a.n_groups = n_groups;
@@ -893,7 +905,6 @@ int reset_streams(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, bool
 
 // ---- persistent block mode -------------------------------------------------------------------------------------
 constexpr int kGraceUs = 40; // how long a fresh launch looks for the doorbell it was started for
-constexpr int kPersistTurns = 8; // one-workgroup-per-stream sessions: at most this many streams per CU (they take turns on the chip)
 constexpr int kPersistMaxFrames = 2048; // buffers up to this long go through the session as n_frames / 64 commands
 // the state layout the session's kernel keeps (WaveNets only)
 int persist_family(const nam_hip_batch* b, const WidthGroup& g)
@@ -920,7 +931,9 @@ int persist_kind(const nam_hip_batch* b)
       for (int k = 0; k < gs.n; k++)
         lds = std::max(lds, gs.g[k]->plan->wr.lds_bytes);
       const int per_cu = std::min(4, (160 * 1024) / (lds + 512));
-      return b->n_streams <= per_cu * cus ? PERSIST_WN_REG : PERSIST_NONE;
+      // (more workgroups than the chip holds at once take turns, as below: each turn moves its streams' LDS images in and
+      // out once and consumes every command that is there)
+      return b->n_streams <= kPersistTurns * per_cu * cus ? PERSIST_WN_REG : PERSIST_NONE;
     }
   }
   if ((int)g.streams.size() != b->n_streams || g.d_map != nullptr)
