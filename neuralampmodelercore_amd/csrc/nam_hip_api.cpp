@@ -515,15 +515,16 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
         return 1e9;
       const int on_chip = cus * std::min(4 / nst, (160 * 1024) / (lds + 512));
       const double speed = nst == 4 ? 3.1 : nst == 2 ? 1.75 : 1.0;
-      return double((total + on_chip - 1) / on_chip) / speed;
+      const int turns = (total + on_chip - 1) / on_chip;
+      return turns * (1.0 + 0.15 * (turns - 1)) / speed; // a turn's last workgroups leave SIMDs idle; images move in and out
     };
     double best = duration(1);
-    if (can_split && b->wr_max_stages >= 2 && duration(2) < best)
+    if (can_split && b->wr_max_stages >= 2 && duration(2) < 0.9 * best)
     {
       stages = 2;
       best = duration(2);
     }
-    if (can_split && can_split4 && b->wr_max_stages >= 4 && duration(4) < best)
+    if (can_split && can_split4 && b->wr_max_stages >= 4 && duration(4) < 0.9 * best)
       stages = 4;
     lds_bytes += (stages - 1) * kWrQueueBytes;
   }
