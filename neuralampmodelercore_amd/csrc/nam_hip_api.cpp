@@ -23,10 +23,16 @@
 #include "plan.h"
 #include "wr_jit.h"
 
+namespace namhip
+{
+hipError_t launch_kq(const A1Args& a, int n_blocks, int act, hipStream_t stream); // kernel_kq.hip (developer switch NAM_HIP_KQ)
+bool kq_takes(int act, float act_p0);
+}
 using namespace namhip;
 
 namespace
 {
+
 thread_local std::string g_last_error;
 
 int fail(int code, const std::string& msg)
@@ -191,6 +197,7 @@ struct nam_hip_batch
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
+  bool use_kq = false; // developer switch (NAM_HIP_KQ=1): the A2 topology's pipeline on nam_kq_kernel (kernel_kq.hip) instead of nam_kp_kernel
   int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
@@ -722,7 +729,13 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        NAM_HIP_CHECK(launch_kp(a, n, p.a1.arr[0].act, s));
+        if (b->use_kq && kq_takes(p.a1.arr[0].act, a.act_p0))
+        {
+          a.tiles_off = p.a1.kp_pad[0];
+          NAM_HIP_CHECK(launch_kq(a, n, p.a1.arr[0].act, s));
+        }
+        else
+          NAM_HIP_CHECK(launch_kp(a, n, p.a1.arr[0].act, s));
       }
       else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok)
         // single-array models with other kernel sizes than 3 (A2): the K-tap MFMA kernel
@@ -1792,6 +1805,8 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
     b->il_generic = e && e[0] == '1';
     if (const char* e4 = std::getenv("NAM_HIP_WR_STAGES"))
       b->wr_max_stages = std::max(1, std::atoi(e4));
+    const char* e5 = std::getenv("NAM_HIP_KQ");
+    b->use_kq = e5 && e5[0] == '1';
     const char* e3 = std::getenv("NAM_HIP_NO_PIPE");
     b->no_pipe = e3 && e3[0] == '1';
   }

@@ -1165,6 +1165,61 @@ void build_a1_kp(Plan& plan)
         || D.consts_off != kp::kLayers * 512 + j * 192 || (j < kp::kLayers && D.w1_off != j * 512))
       return;
   }
+  // nam_kq_kernel's weight block (kernel_kq.hip): v_mfma_f32_4x4x1_16b operands for a lane-per-frame layout. One 256-byte
+  // tile per tap, [lane class i = lane % 4][h][c] = W[out = 4 h + i][in = c]; every job's taps in order, then the layers'
+  // 1x1; constants per job bias[8] | mixin[8] | 1x1 bias[8]; the rechannel column [8]. The head rechannel has one output:
+  // class 0, half 0 only.
+  {
+    const int C = kp::kC;
+    while (plan.blob.size() % 64)
+      plan.blob.push_back(0.0f);
+    const size_t w0 = plan.blob.size();
+    int n_taps = 0;
+    for (int j = 0; j < kp::kJobs; j++)
+      n_taps += kp::kKs[j];
+    const size_t c_0 = w0 + (size_t)(n_taps + kp::kLayers) * 64, rech0 = c_0 + (size_t)kp::kJobs * 24;
+    plan.blob.resize(rech0 + 16, 0.0f);
+    float* const blob = plan.blob.data();
+    const A1Array& AA = a1.arr[0]; // (the vector may have moved: take the array again)
+    const float* const base = blob + AA.w_base;
+    auto fill_tile = [&](size_t off, auto at) { // at(co, ci)
+      for (int i = 0; i < 4; i++)
+        for (int h = 0; h < 2; h++)
+          for (int c = 0; c < C; c++)
+            blob[off + (size_t)i * 16 + h * 8 + c] = at(4 * h + i, c);
+    };
+    size_t tile = w0;
+    const size_t w1_0 = w0 + (size_t)n_taps * 64;
+    for (int l = 0; l < kp::kLayers; l++)
+    {
+      const int K = AA.ksize[l];
+      const float* cw = base + AA.layer_off[l];
+      const float* cb = cw + (size_t)K * C * C;
+      const float* mx = cb + C;
+      const float* w1 = mx + C;
+      const float* b1 = w1 + (size_t)C * C;
+      for (int k = 0; k < K; k++, tile += 64)
+        fill_tile(tile, [&](int co, int ci) { return cw[((size_t)k * C + ci) * C + co]; });
+      fill_tile(w1_0 + (size_t)l * 64, [&](int co, int ci) { return w1[(size_t)ci * C + co]; });
+      for (int c = 0; c < C; c++)
+      {
+        blob[c_0 + (size_t)l * 24 + c] = cb[c];
+        blob[c_0 + (size_t)l * 24 + 8 + c] = mx[c];
+        blob[c_0 + (size_t)l * 24 + 16 + c] = b1[c];
+      }
+    }
+    {
+      const int K = AA.head_k;
+      const float* hw = base + AA.head_off;
+      const float* hb = hw + (size_t)K * C;
+      for (int k = 0; k < K; k++, tile += 64)
+        fill_tile(tile, [&](int co, int ci) { return co == 0 ? hw[(size_t)k * C + ci] : 0.0f; });
+      blob[c_0 + (size_t)kp::kLayers * 24] = hb[0];
+    }
+    for (int c = 0; c < C; c++)
+      blob[rech0 + c] = base[c]; // rechannel [ci = 0][co]
+    a1.kp_pad[0] = (int)w0; // nam_kq_kernel: A1Args::tiles_off
+  }
   a1.kp_ok = 1;
 }
 
