@@ -174,6 +174,10 @@ hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, 
 // nam_kp_kernel (kernel_kp.hip): the A2 topology (kp_table.h) as a pipeline of wave sets; a.tiles_off / consts_off / r1_off =
 // blob offsets of the K-tap kernel's tap tiles, LDS block and rechannel column
 hipError_t launch_kp(const A1Args& a, int n_blocks, int act, hipStream_t stream);
+// nam_kq_kernel (kernel_kq.hip): the same topology, state and session protocol with one lane per frame; a.tiles_off = the
+// plan's kq weight block (A1Plan::kq_w_off); kq_takes: the activations it is compiled for
+bool kq_takes(int act, float act_p0);
+hipError_t launch_kq(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,
                           hipStream_t stream);
 hipError_t launch_lstm(const LSTMArgs& a, hipStream_t stream);

@@ -23,11 +23,6 @@
 #include "plan.h"
 #include "wr_jit.h"
 
-namespace namhip
-{
-hipError_t launch_kq(const A1Args& a, int n_blocks, int act, hipStream_t stream); // kernel_kq.hip (developer switch NAM_HIP_KQ)
-bool kq_takes(int act, float act_p0);
-}
 using namespace namhip;
 
 namespace
@@ -197,7 +192,9 @@ struct nam_hip_batch
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
-  bool use_kq = false; // developer switch (NAM_HIP_KQ=1): the A2 topology's pipeline on nam_kq_kernel (kernel_kq.hip) instead of nam_kp_kernel
+  bool use_kq = false; // developer switch (NAM_HIP_KQ=1): the A2 topology's pipeline on nam_kq_kernel (kernel_kq.hip) instead of
+                       // nam_kp_kernel — 1.7x faster, parity green, but a session whose launch leaves and restarts can come back wrong
+                       // (DESIGN 4.2d): not the default until that is found
   int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
@@ -369,6 +366,13 @@ inline bool use_pipeline(const nam_hip_batch* b, int n_frames)
   return !b->no_pipe && (b->ps_launching || n_frames > kBlock);
 }
 
+// the A2 topology's pipeline: nam_kq_kernel (one lane per frame, 4x4x1 matrix instructions) for the activation it is
+// compiled for, nam_kp_kernel otherwise
+inline bool kq_runs(const nam_hip_batch* b, const Plan& p)
+{
+  return b->use_kq && kq_takes(p.a1.arr[0].act, p.a1.arr[0].act_p0);
+}
+
 // `n_frames`: the launch length the question is about (under AUTO a launch of four or more blocks runs another kernel
 // of the family than a one-block launch); 64 in persistent mode means "a command of the session"
 const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n_frames)
@@ -378,7 +382,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
     switch (persist_kind(b)) // persistent block mode
     {
       case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : "nam_a1_p4_kernel";
-      case PERSIST_KP: return "nam_kp_kernel";
+      case PERSIST_KP: return kq_runs(b, p) ? "nam_kq_kernel" : "nam_kp_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
       case PERSIST_LSTM_WIDE: return "nam_lstm_wide_kernel";
@@ -394,7 +398,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
       case NAM_HIP_KERNEL_A1_IL:
         return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_pipe && n_frames > kBlock) ? "nam_a1_p4_kernel" : "nam_a1_p2_kernel") : "nam_a1_il_kernel";
       default:
-        return p.a1.ws_ok ? "nam_a1_mfma_kernel" : (p.a1.kp_ok && !b->no_pipe && n_frames > kBlock) ? "nam_kp_kernel" : "nam_kt_mfma_kernel";
+        return p.a1.ws_ok ? "nam_a1_mfma_kernel" : (p.a1.kp_ok && !b->no_pipe && n_frames > kBlock) ? (kq_runs(b, p) ? "nam_kq_kernel" : "nam_kp_kernel") : "nam_kt_mfma_kernel";
     }
   }
   const LSTMPlan& L = p.lstm;
@@ -729,9 +733,9 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (b->use_kq && kq_takes(p.a1.arr[0].act, a.act_p0))
+        if (kq_runs(b, p))
         {
-          a.tiles_off = p.a1.kp_pad[0];
+          a.tiles_off = p.a1.kq_w_off;
           NAM_HIP_CHECK(launch_kq(a, n, p.a1.arr[0].act, s));
         }
         else

@@ -1218,7 +1218,7 @@ void build_a1_kp(Plan& plan)
     }
     for (int c = 0; c < C; c++)
       blob[rech0 + c] = base[c]; // rechannel [ci = 0][co]
-    a1.kp_pad[0] = (int)w0; // nam_kq_kernel: A1Args::tiles_off
+    a1.kq_w_off = (int)w0;
   }
   a1.kp_ok = 1;
 }

@@ -360,7 +360,8 @@ struct A1Plan
   int32_t kt_lds_src_off = 0, kt_lds_floats = 0; // blob region copied to LDS at kernel start: 1x1 tiles | constants
   KtDesc kt_desc[kKtChunkMax];
   int32_t kp_ok = 0; // nam_kp_kernel can run this model too: it IS the topology of kp_table.h (plan.cpp: build_a1_kp)
-  int32_t kp_pad[3] = {0, 0, 0};
+  int32_t kq_w_off = 0; // blob float offset of nam_kq_kernel's weight block (tiles | constants | rechannel column; kernel_kq.hip)
+  int32_t kp_pad[2] = {0, 0};
 };
 
 // ---- register-resident WaveNet (nam_wn_reg_kernel) ----------------------------------------------------------------

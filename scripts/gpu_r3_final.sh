@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, last check of the tree as shipped: the whole GPU suite twice, the soak of every pipelined kernel, smoke, the driver's bench command
+# round 3, last check of the tree as shipped: the whole GPU suite (SUITE_REPS times, default once), the soak of every pipelined kernel, smoke, the driver's bench command
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export NAM_HIP_PERSIST_TIMEOUT_MS=8000
-for i in 1 2; do
+for i in $(seq 1 ${SUITE_REPS:-1}); do
   timeout 1500 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider > gpurun_out/r3_final_tests_$i.log 2>&1
   echo "suite run $i rc=$? $(tail -1 gpurun_out/r3_final_tests_$i.log)"
 done

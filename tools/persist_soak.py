@@ -43,6 +43,11 @@ for rep in range(reps):
     err = float((yd - yr).abs().max())
     bad = int(((yd - yr).abs() > 1e-4).any(dim=2).sum())
     worst = max(worst, err)
+    if bad:
+        d = (yd - yr).abs()[:, 0, :] > 1e-4
+        ids = torch.nonzero(d.any(dim=1))[:, 0].cpu().numpy()
+        first = [int(torch.nonzero(d[i])[0, 0]) for i in ids[:12]]
+        print(f"      bad streams {ids[:12].tolist()} ... {ids[-4:].tolist()}; first bad frame of each: {first} (buffer {[f // block for f in first]})", flush=True)
     print(f"   soak rep {rep}: {b.kernel_name()} {nb} buffers in {dt * 1e3:.1f} ms ({dt / nb * 1e6:.2f} us/buffer), max |session - one launch| = {err:.3e}, bad streams {bad}", flush=True)
     b.close()
 print("   SOAK", "OK" if worst < 1e-4 else "FAILED")
