@@ -432,7 +432,10 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
     // persistent session, stage 0: look at the next ring slot in job 0 and, when the command is already there, request
     // the next buffer's input sample from it in job 1 (unconditional load, out-of-range offset on a miss)
     if constexpr (PERSIST && JI == 0)
-      spec_cmd = ring_load(na + 1);
+    {
+      const unsigned long long v = ring_load(na + 1); // (lane 0's view for the whole wave, as at the end of the buffer)
+      spec_cmd = ((unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)v);
+    }
     if constexpr (PERSIST && JI == 1)
     {
       const bool hit = (unsigned)(spec_cmd >> 32) == na + 2;
@@ -620,8 +623,11 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
               v = ring_load(tag - 1u);
             }
           }
-          have = (unsigned)(v >> 32) == tag;
-          const unsigned next_off = (unsigned)v * 4u;
+          // ONE view of the ring slot for the whole wave (lane 0's): the lanes' loads are separate memory requests, and a
+          // command that lands between them would split the wave — some lanes leaving, some starting the next buffer
+          const unsigned v_tag = (unsigned)uni((int)(unsigned)(v >> 32)), v_off = (unsigned)uni((int)(unsigned)v);
+          have = v_tag == tag;
+          const unsigned next_off = v_off * 4u;
           na++;
           if (have)
           {

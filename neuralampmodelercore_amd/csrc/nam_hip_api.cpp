@@ -192,9 +192,7 @@ struct nam_hip_batch
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
-  bool use_kq = false; // developer switch (NAM_HIP_KQ=1): the A2 topology's pipeline on nam_kq_kernel (kernel_kq.hip) instead of
-                       // nam_kp_kernel — 1.7x faster, parity green, but a session whose launch leaves and restarts can come back wrong
-                       // (DESIGN 4.2d): not the default until that is found
+  bool use_kq = true; // the A2 topology's pipeline runs nam_kq_kernel (kernel_kq.hip) where it applies; NAM_HIP_KQ=0: nam_kp_kernel everywhere
   int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
@@ -1810,7 +1808,7 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
     if (const char* e4 = std::getenv("NAM_HIP_WR_STAGES"))
       b->wr_max_stages = std::max(1, std::atoi(e4));
     const char* e5 = std::getenv("NAM_HIP_KQ");
-    b->use_kq = e5 && e5[0] == '1';
+    b->use_kq = !(e5 && e5[0] == '0');
     const char* e3 = std::getenv("NAM_HIP_NO_PIPE");
     b->no_pipe = e3 && e3[0] == '1';
   }
