@@ -212,7 +212,7 @@ NAM_HIP_API int nam_hip_batch_process_device(nam_hip_batch* batch, const float* 
 NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float* const* out,
                                          const int64_t* n_frames);
 
-/* Persistent block mode (opt-in; nam_a1_p4_kernel, nam_kp_kernel, nam_wn_reg_kernel — mixed slimmable widths included — and
+/* Persistent block mode (opt-in; nam_a1_p4_kernel, nam_kq_kernel / nam_kp_kernel, nam_wn_reg_kernel — mixed slimmable widths included — and
  * the small LSTM kernels): instead of one kernel launch per nam_hip_batch_process_device call, a SESSION launch consumes
  * every call of a multiple of 64 frames (up to 2,048; n_frames / 64 commands) — a command is a 64-bit word in a
  * device-memory ring, stored by the host itself when the call's stream is idle, else by hipStreamWriteValue64 on that
@@ -226,7 +226,7 @@ NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* cons
  * transparently. The blocking *_f32 / *_f64 entry points stay inside the session (host-mapped staging).
  * Outputs are NOT ordered on the caller's stream: call nam_hip_batch_flush (or nam_hip_batch_synchronize, or use the
  * blocking *_f32 / *_f64 entry points, which do it) before consuming them.
- * Eligible: one width group on nam_a1_p4_kernel / nam_kp_kernel up to 8 streams per CU (beyond one per CU the workgroups
+ * Eligible: one width group on nam_a1_p4_kernel / nam_kq_kernel (nam_kp_kernel) up to 8 streams per CU (beyond one per CU the workgroups
  * take turns on the chip); every group on nam_wn_reg_kernel up to 8 x min(4, 160 KB / LDS image) streams per CU (in turns too); small LSTMs.
  * Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual). */
 NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);

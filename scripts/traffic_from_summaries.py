@@ -73,6 +73,7 @@ for rnd, tag, kernel, model, streams, launch in RUNS:
 # The persistent block mode's session launch runs the same loop body per command.
 RESIDENT = [("r03", "counters_c2_p4_resident.json", "nam_a1_p4_kernel", "wavenet_a1_standard", 256, 300),
             ("r03", "counters_a2_kp_resident.json", "nam_kp_kernel", "A2", 256, 300),
+            ("r03", "counters_a2_kq_resident.json", "nam_kq_kernel", "A2", 256, 300),
             # nam_wn_reg_kernel as the sessions run it (two wavefronts per stream for config 4): the history never leaves LDS
             ("r03", "counters_c4_wn_reg2_resident.json", "nam_wn_reg_kernel", "wavenet_a2_max", 512, 300),
             ("r03", "counters_c5_wn_reg_resident.json", "nam_wn_reg_kernel", "slimmable_wavenet", 768, 300)]
