@@ -18,7 +18,7 @@ trap 'cp variants/libnam_hip_shipped.so $LIB; rm -rf variants/libnam_hip_shipped
 cp variants/libnam_hip_asan.so $LIB
 rm -f variants/asan_log.*
 export LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:log_path=$PWD/variants/asan_log UBSAN_OPTIONS=print_stacktrace=1:log_path=$PWD/variants/asan_log
-python -m pytest tests/ -x -q -m "not gpu" -p no:cacheprovider | tail -1
+python -m pytest tests/ -x -q -m "not gpu" -p no:cacheprovider | tail -15
 python tools/fuzz_models.py 160 12 --load-only | tail -1
 unset LD_PRELOAD
 if ls variants/asan_log.* > /dev/null 2>&1; then echo "sanitizer reports:"; cat variants/asan_log.* | head -60; exit 1; fi

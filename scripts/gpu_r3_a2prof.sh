@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: counters of nam_kp_kernel (A2-Full, 256 streams) and, for comparison, nam_a1_p4_kernel: one resident launch of 300 steps
+# round 3: counters of the A2 pipeline kernel (nam_kq_kernel; KP_NAME=nam_kp_kernel with NAM_HIP_KQ=0 for the four-waves-per-stage form; A2-Full, 256 streams) and, for comparison, nam_a1_p4_kernel: one resident launch of 300 steps
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
@@ -13,7 +13,7 @@ for T in ${PROF_SET:-a2 c2}; do
   rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $D -o pmc_sq -- $BENCH > /dev/null 2>> gpurun_out/prof_kp_$T.err
   rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA --output-format csv -d $D -o pmc_inst -- $BENCH > /dev/null 2>> gpurun_out/prof_kp_$T.err
   rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $D -o pmc_inst2 -- $BENCH > /dev/null 2>> gpurun_out/prof_kp_$T.err
-  K=$([ $T = a2 ] && echo ${KP_NAME:-nam_kp_kernel} || echo nam_a1_p4_kernel)
+  K=$([ $T = a2 ] && echo ${KP_NAME:-nam_kq_kernel} || echo nam_a1_p4_kernel)
   python scripts/resident_counters.py $D $K gpurun_out/counters_${T}_resident.json > /dev/null 2>&1
   python - $D $K <<'PY'
 import collections, csv, glob, os, sys
