@@ -1,0 +1,106 @@
+// aq_table.h — the job / stage / LDS tables of nam_a1_q_kernel (kernel_a1_q.hip), shared with the planner (plan.cpp:
+// build_a1_q packs the weight block these offsets describe and checks the model against this topology).
+//
+// Topology: the official A1 "standard" WaveNet — two layer arrays of ten layers, kernel size 3, dilations 1 .. 512,
+// 16 and 8 channels (NAM/wavenet/model.cpp:183-393, 463-549; example_models/wavenet_a1_standard.nam). 22 jobs per buffer:
+//   0 .. 9   array 0's layers ("big": 16 channels; v_mfma_f32_16x16x4_f32, four groups of 16 frames per wavefront)
+//   10       the transition: array 1's rechannel 16 -> 8 and array 0's head rechannel 16 -> 8 (one lane per frame, 4x4x1)
+//   11 .. 20 array 1's layers ("small": 8 channels; one lane per frame, v_mfma_f32_4x4x1_16b_f32)
+//   21       array 1's head rechannel 8 -> 1, head_scale, the output sample
+// Ring r of the stream state (r = 0 .. 19) is the conv input of layer r: [R = 2 d + 64 frames][C channels], frame-major
+// (the layout every A1 kernel shares: plan.h, namespace p2).
+#pragma once
+
+namespace namhip
+{
+namespace aq
+{
+constexpr int kC0 = 16, kC1 = 8;
+constexpr int kBlockF = 64; // frames per buffer
+constexpr int kLayers = 10; // per array
+constexpr int kJobT = 10, kJobM0 = 11, kJobHead = 21, kJobs = 22;
+constexpr int kRings = 20;
+constexpr int kTable = 64; // write-position words in front of a stream's rings
+constexpr int kNst = 12;
+// stage s = jobs [kFirst[s], kFirst[s + 1]); wave i of the workgroup runs stage kStageOfWave[i]; waves i, i + 4, i + 8 share
+// a SIMD. Estimated issue cycles per buffer (matrix + vector): a big layer 2.65 k, a small layer 0.8 k, the transition
+// 0.55 k -> per SIMD {L0-1, L2, T} 8.5 k | {L3-4, L5, M0} 8.75 k | {L6-7, L8, M1} 8.75 k | {L9, M2-5, M6-9 + head} 9.05 k
+constexpr int kFirst[kNst + 1] = {0, 2, 3, 5, 6, 8, 9, 10, 11, 12, 13, 17, 22};
+constexpr int kStageOfWave[kNst] = {0, 2, 4, 6, 1, 3, 5, 10, 7, 8, 9, 11};
+static_assert(kFirst[kNst] == kJobs, "aq stage table");
+
+constexpr bool is_big(int job) { return job < kLayers; }
+constexpr bool is_small(int job) { return job >= kJobM0 && job < kJobHead; }
+constexpr bool has_ring(int job) { return is_big(job) || is_small(job); }
+constexpr int ring_id(int job) { return is_big(job) ? job : job - kJobM0 + kLayers; }
+constexpr int dil(int job) { return has_ring(job) ? 1 << (is_big(job) ? job : job - kJobM0) : 0; }
+constexpr int chans(int job) { return job <= kJobT ? kC0 : kC1; } // channels of the job's INPUT rows
+constexpr int ring_len(int job) { return 2 * dil(job) + kBlockF; }
+constexpr int ring_off(int job) // float offset of the job's ring in the stream state
+{
+  int o = kTable;
+  for (int r = 0; r < ring_id(job); r++)
+    o += (r < kLayers ? kC0 : kC1) * (2 * (1 << (r % kLayers)) + kBlockF);
+  return o;
+}
+// LDS-resident rings: the whole ring lives in LDS while the launch runs (loaded from the state when it starts, written
+// back when it leaves); the others keep their ring in HBM (appended every buffer, their taps — all at least two buffers
+// old — requested one buffer ahead)
+constexpr bool res(int job) { return is_big(job) ? dil(job) <= 64 : is_small(job) ? dil(job) <= 128 : false; }
+constexpr int stage_of(int job)
+{
+  int s = 0;
+  for (int k = 1; k < kNst; k++)
+    if (job >= kFirst[k])
+      s = k;
+  return s;
+}
+constexpr bool starts_stage(int job) { return kFirst[stage_of(job)] == job; }
+// a job's input area in LDS: planes of 16-byte rows, [C / 4 planes][rows]. Resident ring: R rows (plane pitch rounded up
+// to 256 bytes: the four lane groups of a b128 access then never share a bank). A stage's FIRST job whose ring is in HBM
+// (or that has none: the transition) takes its input through a 64-row area.
+constexpr int in_rows(int job) { return res(job) ? ring_len(job) : (job > 0 && job < kJobHead && starts_stage(job)) ? kBlockF : 0; }
+constexpr int plane_b(int job) { return (in_rows(job) * 16 + 255) / 256 * 256; }
+constexpr int in_bytes(int job) { return plane_b(job) * (chans(job) / 4); }
+
+// ---- weight block in the blob (floats), copied to LDS as it lies (plan.cpp: build_a1_q) ----
+// 4x4x1 tiles [lane class i = lane % 4][h][c] = W[out = 4 h + i][in = c]
+constexpr int kTileT = 4 * 2 * 16; // 16 -> 8: 128 floats
+constexpr int kTileM = 4 * 2 * 8; // 8 -> 8 (and the head's 8 -> 1: class 0, half 0 only): 64 floats
+constexpr int kWrOff = 0; // array 1's rechannel
+constexpr int kWhOff = kWrOff + kTileT; // array 0's head rechannel
+constexpr int kMTiles = kWhOff + kTileT; // per small layer: tap 0 (oldest), 1, 2, 1x1
+constexpr int kHeadTile = kMTiles + kLayers * 4 * kTileM;
+constexpr int kMConsts = kHeadTile + kTileM; // per small layer: bias[8] | mixin[8] | 1x1 bias[8]
+constexpr int kTConsts = kMConsts + kLayers * 24; // array 0's head-rechannel bias[8] | array 1's head bias, 0, 0, 0 | pad
+constexpr int kBigConsts = kTConsts + 16; // per big layer: bias[16] | mixin[16] | 1x1 bias[16] | (job 0: rechannel column[16])
+constexpr int kBlockFloats = kBigConsts + kLayers * 64;
+static_assert(kBlockFloats % 4 == 0, "aq weight block");
+
+// ---- LDS layout (bytes) ----
+constexpr int kWB = 0;
+constexpr int kFlagB = kWB + kBlockFloats * 4; // 256 bytes of single-writer words
+constexpr int kSlotB0 = kFlagB + 256;
+// boundary b = stage b -> b + 1: a slot with the head accumulator (planes of 16-byte rows), the input sample, a token
+constexpr int kBigSlot = 4 * 1024 + 256 + 16, kSmallSlot = 2 * 1024 + 256 + 16;
+constexpr bool big_slot(int b) { return kFirst[b + 1] <= kJobT; } // the consumer's first job reads 16 channels
+constexpr int slot_b(int b)
+{
+  int o = kSlotB0;
+  for (int i = 0; i < b; i++)
+    o += big_slot(i) ? kBigSlot : kSmallSlot;
+  return o;
+}
+constexpr int kInB0 = (slot_b(kNst - 1) + 255) / 256 * 256;
+constexpr int in_b(int job)
+{
+  int o = kInB0;
+  for (int i = 0; i < job; i++)
+    o += in_bytes(i);
+  return o;
+}
+constexpr int kLdsBytes = in_b(kJobs);
+static_assert(kLdsBytes <= 160 * 1024, "aq LDS layout");
+static_assert(kFlagB % 16 == 0 && kSlotB0 % 16 == 0 && kBigSlot % 16 == 0 && kSmallSlot % 16 == 0, "aq LDS alignment");
+} // namespace aq
+} // namespace namhip

@@ -1,0 +1,937 @@
+// kernel_a1_q.hip — nam_a1_q_kernel: the official A1 "standard" topology (aq_table.h) as a pipeline of TWELVE ONE-WAVE STAGES
+// whose hand-over medium is the next layer's history ring itself, most rings resident in LDS for the whole launch.
+#include "device_common.h"
+#include "il_common.h"
+#include "aq_table.h"
+
+namespace namhip
+{
+
+// ================================================================================================
+// What nam_a1_p4_kernel (kernel_a1_p4.hip; read its header first) leaves on the table, from its counters
+// (profiles/r03/counters_c2_p4_resident.json): the 8-channel array pays for 16 x 16 x 4 tiles that are half padding and
+// computes its activation on duplicated rows (7.9 k matrix + 5.7 k vector cycles per SIMD and buffer, and an fp32 MFMA
+// never overlaps a vector instruction on this chip); every layer's ring row goes to HBM and comes back (33 MB per step at
+// 256 streams: 5.3 us at the achievable HBM rate — the floor under ANY instruction tuning); every wave reads every weight
+// tile from LDS for its 16 frames. This kernel changes the shape of the work (model.cpp:183-393 / 463-549 unchanged):
+//   * one WAVE per stage and 64 frames per wave. Array 0 (16 channels) stays on v_mfma_f32_16x16x4_f32 — no padding there —
+//     as FOUR frame groups per wave: lane (g = lane / 16, n = lane % 16) holds channels 4 g .. 4 g + 3 of frames 16 F + n,
+//     F = 0 .. 3; D layout = B layout (kernel_a1_p2.hip's trick), four independent accumulator chains per product, and the
+//     A operands — 4 registers per 16 x 16 matrix — stay IN REGISTERS for the whole launch (16 per layer): no weight
+//     traffic at all. Array 1 (8 channels), the transition and the head run one lane per frame on
+//     v_mfma_f32_4x4x1_16b_f32 (kernel_kq.hip): no padded rows, half the activations;
+//   * stage -> stage: the producer writes its output rows STRAIGHT INTO THE CONSUMER'S FIRST RING (planes of 16-byte rows
+//     in LDS) and the head accumulator / input sample / token into a one-slot queue; "produced" / "consumed" words with one
+//     writer each. The consumer signals "consumed" right behind the LDS reads of its first job's taps (LDS runs a wave's
+//     accesses in order: the producer's next rows cannot overtake them);
+//   * rings with (K - 1) d + 64 rows up to 12 KB (array 0: d <= 64, array 1: d <= 128) live in LDS from the first buffer
+//     of a launch to its last: loaded from the stream state when the launch starts, written back (same R, same write
+//     position: the state stays the one every A1 kernel shares) when it leaves. Five rings stay in HBM (array 0: d = 128,
+//     256, 512; array 1: d = 256, 512): appended every buffer, their taps — all at least two buffers old — requested one
+//     buffer ahead into registers. HBM traffic per stream and buffer: 48 KB instead of 114.
+// Sums: one chain per product seeded with bias + mixin * input, taps oldest first (as nam_a1_p4_kernel / nam_kq_kernel).
+// ================================================================================================
+using aq_i4 = __attribute__((ext_vector_type(4))) int;
+__device__ mf::f4 aq_sb_load4(aq_i4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
+__device__ void aq_sb_store4(mf::f4 v, aq_i4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.store.v4f32");
+
+namespace aq
+{
+constexpr int kNoRow = 1 << 26; // a ring row index no descriptor holds: the access is dropped / returns 0
+constexpr int kRowsMax = 1 << 20; // num_records of the ring descriptors (rows)
+constexpr int far_jobs_before(int s, int job) // HBM-ring jobs of stage s in front of `job`
+{
+  int c = 0;
+  for (int i = kFirst[s]; i < job; i++)
+    c += (has_ring(i) && !res(i)) ? 1 : 0;
+  return c;
+}
+constexpr int max_far_small()
+{
+  int m = 0;
+  for (int s = 0; s < kNst; s++)
+    if (is_small(kFirst[s]))
+      m = far_jobs_before(s, kFirst[s + 1]) > m ? far_jobs_before(s, kFirst[s + 1]) : m;
+  return m;
+}
+} // namespace aq
+
+template <int ACT_T, bool WT, bool PERSIST>
+__global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __restrict__ blob, const A1Args a)
+{
+  using namespace mf;
+  using il::kOob;
+  using i4 = aq_i4;
+  constexpr int NST = aq::kNst;
+  extern __shared__ __attribute__((aligned(16))) float lds_aq[];
+  char* const lds = reinterpret_cast<char*>(lds_aq);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wall = uni(tid >> 6);
+  int S = 0; // this wave's stage
+#pragma unroll
+  for (int i = 0; i < NST; i++)
+    S = wall == i ? aq::kStageOfWave[i] : S;
+  const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
+  float* st = a.state + (size_t)stream * a.state_stride;
+  const int n_blocks = PERSIST ? (1 << 30) : (a.n_frames + kBlock - 1) / kBlock;
+
+  const int frame = lane; // one lane per frame (stage 0's input sample, the small stages)
+  const int g = lane >> 4, n = lane & 15; // the big stages: channel quad g of frames 16 F + n
+  const unsigned g16 = (unsigned)g * 16u;
+  const unsigned frame16 = (unsigned)frame * 16u;
+  const unsigned cls64 = (unsigned)(lane & 3) * 64u; // the lane's record inside an 8 x 8 tile (64 bytes per class)
+  const unsigned cls128 = (unsigned)(lane & 3) * 128u; // ... inside a 16 -> 8 tile
+  const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
+  float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
+  const float head_scale = a.head_scale;
+  const float act_p0 = a.act_p0;
+  const int act = a.act; // (only read by the run-time-dispatch instantiation)
+  const int io_bytes = PERSIST ? 0x7ffffff0 : a.n_frames * 4;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(in ? in : st), 0, in ? io_bytes : 0, 0x00020000);
+  const auto rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out ? out : st), 0, out ? io_bytes : 0, 0x00020000);
+  const unsigned long long in_addr = (unsigned long long)(in ? in : st);
+  const i4 in_desc = {uni((int)(unsigned)in_addr), uni((int)(unsigned)(in_addr >> 32) & 0xffff), in ? io_bytes : 0, 0x00020000};
+  int* wpos_tbl = reinterpret_cast<int*>(st);
+  const int wposv = lane < aq::kRings ? wpos_tbl[lane] : 0; // lane r = write position of ring r at launch
+  int* const flags = reinterpret_cast<int*>(lds + aq::kFlagB);
+
+  // ---- the small stages' tiles and every constant -> LDS, once per launch, by every wave ----
+  constexpr int NT = NST * 64;
+  {
+    constexpr int kSrc4 = aq::kBlockFloats / 4; // 16-byte records
+    const f4* __restrict__ src = reinterpret_cast<const f4*>(blob + a.tiles_off);
+#pragma unroll 1
+    for (int i0 = 0; i0 < kSrc4; i0 += 2 * NT)
+    {
+      const f4 t0 = src[min(i0 + tid, kSrc4 - 1)], t1 = src[min(i0 + NT + tid, kSrc4 - 1)];
+      if (i0 + tid < kSrc4)
+        lds_st4(lds, (unsigned)aq::kWB + (unsigned)(i0 + tid) * 16u, t0);
+      if (i0 + NT + tid < kSrc4)
+        lds_st4(lds, (unsigned)aq::kWB + (unsigned)(i0 + NT + tid) * 16u, t1);
+    }
+  }
+
+  // The stream's rings through two descriptors with the row pitch as the stride (64 / 32 bytes): an access names its row by
+  // index and its ring by the scalar offset; kNoRow drops it.
+  const unsigned long long st_addr = (unsigned long long)st;
+  auto ring_desc = [&](int row_b) {
+    return i4{uni((int)(unsigned)st_addr), uni((int)((unsigned)(st_addr >> 32) & 0xffffu) | (row_b << 16)), aq::kRowsMax, 0x00020000};
+  };
+  const i4 rs16 = ring_desc(aq::kC0 * 4), rs8 = ring_desc(aq::kC1 * 4);
+  // row (sb + off) mod R for a wave-uniform sb in [0, R) and a lane offset below 64 <= R
+  auto wrap_row = [](int sb, unsigned off, unsigned R) {
+    const unsigned v = (unsigned)sb + off;
+    return min(v, v - R);
+  };
+  auto wrap_s = [](int v, int R) { // wave-uniform, v in (-R, R)
+    v += v < 0 ? R : 0;
+    return v;
+  };
+
+  constexpr bool kOutHost = PERSIST && WT; // (kernel_a1_p4.hip: a session whose results go to host memory)
+  constexpr int kInAux = PERSIST ? 17 : 0; // session inputs bypass the caches (the caller may rewrite the buffer between commands)
+  constexpr int kAppAux = WT && !PERSIST ? 17 : 0; // ring appends of a short launch are written through
+  auto ring_load = [&](unsigned s_) {
+    return __hip_atomic_load(a.p_ring + (s_ & (unsigned)a.p_ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  // ---- single-writer words in LDS (kernel_a1_p4.hip): [16 + 2 b] buffers handed over across boundary b, [16 + 2 b + 1]
+  // buffers whose LDS reads the consumer has issued; [48], [49] stage 0's first-command decision ----
+  const unsigned flag_b = (unsigned)aq::kFlagB;
+  auto wait_word = [&](unsigned byte_addr, int want) { // until the word has reached `want`
+    int tmp;
+    asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_sub_u32 %0, %0, %2\n\tv_cmp_gt_i32 vcc, 0, %0\n\t"
+                 "s_cbranch_vccz 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 : "=&v"(tmp)
+                 : "v"(byte_addr), "v"(want)
+                 : "vcc");
+  };
+  auto set_word = [&](unsigned byte_addr, int v) {
+    asm volatile("" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_store(reinterpret_cast<int*>(lds + byte_addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto prod_b = [&](int b) { return flag_b + (unsigned)(16 + 2 * b) * 4u; };
+  auto cons_b = [&](int b) { return flag_b + (unsigned)(16 + 2 * b + 1) * 4u; };
+
+  // a resident ring: stream state <-> LDS planes. 16-channel rings: lane (g, n) moves the quad g of row r0 + n; 8-channel
+  // rings: lane (h = lane & 1, r = lane >> 1) the quad h of row r0 + r
+  auto ring_to_lds = [&](int R, int ring_off_f, unsigned lds_b, unsigned plane_b, bool wide) {
+    const int per = wide ? 16 : 32;
+    const int rl = wide ? n : (lane >> 1);
+    const unsigned pl = wide ? (unsigned)g : (unsigned)(lane & 1);
+#pragma unroll 2
+    for (int r0 = 0; r0 < R; r0 += per)
+    {
+      const int row = r0 + rl;
+      const f4 v = aq_sb_load4(wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
+      if (row < R)
+        lds_st4(lds, lds_b + pl * plane_b + (unsigned)row * 16u, v);
+    }
+  };
+  auto lds_to_ring = [&](int R, int ring_off_f, unsigned lds_b, unsigned plane_b, bool wide) {
+    const int per = wide ? 16 : 32;
+    const int rl = wide ? n : (lane >> 1);
+    const unsigned pl = wide ? (unsigned)g : (unsigned)(lane & 1);
+#pragma unroll 2
+    for (int r0 = 0; r0 < R; r0 += per)
+    {
+      const int row = r0 + rl;
+      const f4 v = lds_ld4(lds, lds_b + pl * plane_b + (unsigned)min(row, R - 1) * 16u);
+      aq_sb_store4(v, wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
+    }
+  };
+
+  unsigned na = 0; // PERSIST, stage 0: commands finished by this stage (its current command carries tag na + 1)
+  unsigned done = 0; // PERSIST: commands consumed before this launch (+ finished by the last stage during it)
+  unsigned boff0 = 0; // stage 0: byte offset of its first buffer
+  if (tid < 64)
+    flags[tid] = 0;
+  if constexpr (PERSIST)
+  {
+    const bool by_value = a.p_seq0 >= 0;
+    done = na = by_value ? (unsigned)a.p_seq0 : a.p_cons[blockIdx.x];
+    bool ready = true;
+    unsigned lo = (unsigned)a.p_cmd0;
+    if (!by_value)
+    {
+      lds_barrier(); // (the counters are zero)
+      if (wall == 0)
+      {
+        // started right behind a stream-ordered doorbell on another hardware queue: look for it for a bounded time
+        unsigned long long v = ring_load(na);
+        if ((unsigned)(v >> 32) != na + 1 && a.p_grace > 0)
+        {
+          const long long t_end = (long long)wall_clock64() + a.p_grace;
+          do
+          {
+            __builtin_amdgcn_s_sleep(8);
+            v = ring_load(na);
+          } while ((unsigned)(v >> 32) != na + 1 && (long long)wall_clock64() < t_end);
+        }
+        if (lane == 0)
+        {
+          flags[48] = (int)(unsigned)v;
+          flags[49] = (unsigned)(v >> 32) == na + 1 ? 1 : 0;
+        }
+      }
+      lds_barrier();
+      ready = uni(flags[49]) != 0;
+      lo = (unsigned)uni(flags[48]);
+      lds_barrier();
+    }
+    if (!ready)
+    {
+      // nothing to do (the doorbell this launch was started for has been consumed by its predecessor)
+      if (wall == 0 && lane == 0)
+      {
+        a.p_cons[blockIdx.x] = done;
+        __hip_atomic_store(a.p_done + blockIdx.x, done | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    boff0 = lo * 4u;
+  }
+
+  int nvalid = kBlock; // frames of the buffer this wave's stage is working on
+  bool more = false; // this stage has another buffer behind the current one
+  unsigned boff = 0; // byte offset of the current buffer in the stream's row
+  // write positions go back into the state: lane r = ring r, for the rings [r0, r0 + nr) whose positions are wpv[0 .. nr)
+  auto store_positions = [&](int r0, int nr, const int* wpv) {
+    int v = 0;
+#pragma unroll
+    for (int u = 0; u < 5; u++)
+      v = (u < nr && lane == r0 + u) ? wpv[u < nr ? u : 0] : v;
+    if (lane >= r0 && lane < r0 + nr)
+      wpos_tbl[lane] = v;
+  };
+
+  // ==============================================================================================
+  // BIG stages (array 0): jobs J0 .. J0 + NJS - 1 are layers of 16 channels
+  // ==============================================================================================
+  auto run_big = [&](auto s_tag) {
+    constexpr int SS = decltype(s_tag)::value;
+    constexpr int J0 = aq::kFirst[SS], NJS = aq::kFirst[SS + 1] - J0, JN = aq::kFirst[SS + 1];
+    constexpr bool FIRST = SS == 0;
+    constexpr int QIN = SS - 1, QOUT = SS;
+    constexpr int NFAR = aq::far_jobs_before(SS, JN);
+    // ---- this stage's weights: registers for the whole launch. Tile q of job j (plan.cpp: build_a1_ws, FULL layout):
+    // lane (g, i) holds W[out = i][in = 4 g + s], s = 0 .. 3 — the A operand of k-step s ----
+    f4 W[NJS][4];
+    {
+      const f4* __restrict__ tsrc = reinterpret_cast<const f4*>(blob + a.consts_off); // (the p2 tiles: A1Args::consts_off, see launch_a1_q)
+#pragma unroll
+      for (int u = 0; u < NJS; u++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          W[u][q] = tsrc[(J0 + u) * 256 + q * 64 + lane];
+    }
+    int wp[NJS];
+#pragma unroll
+    for (int u = 0; u < NJS; u++)
+      wp[u] = __builtin_amdgcn_readlane(wposv, aq::ring_id(J0 + u));
+    int wpo = aq::res(JN) ? __builtin_amdgcn_readlane(wposv, aq::ring_id(aq::res(JN) ? JN : 0)) : 0; // the next stage's first ring
+    // lane part of an LDS row address per ring of this stage (+ the next stage's input area)
+    unsigned gb[NJS];
+#pragma unroll
+    for (int u = 0; u < NJS; u++)
+      gb[u] = (unsigned)aq::in_b(J0 + u) + (unsigned)g * (unsigned)aq::plane_b(J0 + u);
+    const unsigned gbn = (unsigned)aq::in_b(JN) + (unsigned)g * (unsigned)aq::plane_b(JN);
+    // resident rings of this stage: state -> LDS
+    il::for_each_index(
+      [&](auto u_tag) {
+        constexpr int TJ = J0 + decltype(u_tag)::value;
+        if constexpr (aq::res(TJ))
+          ring_to_lds(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), true);
+      },
+      std::make_integer_sequence<int, NJS>{});
+    // HBM rings: the far taps' rows of the first buffer
+    f4 far[NFAR > 0 ? NFAR : 1][2][4];
+    auto fetch_far = [&](auto tj_tag, int wpj) { // rows (wpj + 16 F + n - L) mod R of ring TJ, L = 2 d, d
+      constexpr int TJ = decltype(tj_tag)::value;
+      constexpr int R = aq::ring_len(TJ), D = aq::dil(TJ), FI = aq::far_jobs_before(SS, TJ);
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+        {
+          const int sb = wrap_s(wpj - (2 - j) * D, R);
+          far[FI][j][F] = aq_sb_load4(rs16, (int)wrap_row(sb, (unsigned)(16 * F + n), R), (int)g16, aq::ring_off(TJ) * 4, 0);
+        }
+    };
+    // (an HBM-ring job that is not the stage's first asks for its rows inside the job in front of it: the registers are then
+    // not live while that job's taps are)
+    if constexpr (!aq::res(J0))
+      fetch_far(std::integral_constant<int, J0>{}, wp[0]);
+    float inp = 0.0f; // stage 0: the next buffer's input sample of frame `lane`
+    if constexpr (FIRST)
+      inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, frame * 4, uni((int)boff0), kInAux));
+    lds_barrier(); // weights, constants, rings and flags are in place
+
+    f4 xs[4], hd[4];
+    float cnd[4];
+    unsigned long long spec_cmd = 0; // PERSIST, stage 0: the early look at the next command ...
+    float inp_spec = 0.0f; // ... and the input sample requested on a hit
+    int k = 0;
+
+    // One layer: z = act(conv(x) + mixin(cond)); head += z; x += layer1x1(z)   (model.cpp:183-393)
+    auto job = [&](auto j_tag) {
+      constexpr int JI = decltype(j_tag)::value;
+      constexpr int U = JI - J0;
+      constexpr int R = aq::ring_len(JI), D = aq::dil(JI);
+      constexpr bool RES = aq::res(JI);
+      constexpr bool TAKES = U == 0 && SS > 0; // the input rows come from the previous stage (LDS)
+      constexpr int FI = aq::far_jobs_before(SS, JI);
+      __builtin_amdgcn_sched_barrier(0);
+      const int wpj = wp[U];
+      // (a) the job's input rows
+      if constexpr (TAKES)
+      {
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+        {
+          const unsigned row = RES ? wrap_row(wpj, (unsigned)(16 * F + n), R) : (unsigned)(16 * F + n);
+          xs[F] = lds_ld4(lds, gb[U] + row * 16u);
+        }
+      }
+      else if constexpr (RES)
+      {
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+          lds_st4(lds, gb[U] + wrap_row(wpj, (unsigned)(16 * F + n), R) * 16u, xs[F]);
+        asm volatile("" ::: "memory"); // the taps read OTHER lanes' rows: not above these stores
+      }
+      if constexpr (!RES)
+      {
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+        {
+          const unsigned row = wrap_row(wpj, (unsigned)(16 * F + n), R);
+          aq_sb_store4(xs[F], rs16, 16 * F + n < nvalid ? (int)row : aq::kNoRow, (int)g16, aq::ring_off(JI) * 4, kAppAux);
+        }
+      }
+      int wpn = wpj + nvalid; // the ring's position for the next buffer (scalar unit)
+      wpn -= wpn >= R ? R : 0;
+      // (b) the taps' rows: LDS ring, or the registers requested a buffer ago
+      f4 bt[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+        {
+          if constexpr (RES)
+            bt[j][F] = lds_ld4(lds, gb[U] + wrap_row(wrap_s(wpj - (2 - j) * D, R), (unsigned)(16 * F + n), R) * 16u);
+          else
+            bt[j][F] = far[FI][j][F];
+        }
+      if constexpr (TAKES)
+        set_word(cons_b(QIN), k + 1); // every LDS read of what the previous stage may overwrite next is issued
+      // persistent session, stage 0: look at the next ring slot in job 0 and, when the command is already there, request the
+      // next buffer's input sample from it in job 1 (kernel_kq.hip)
+      if constexpr (PERSIST && JI == 0)
+      {
+        const unsigned long long v = ring_load(na + 1);
+        spec_cmd = ((unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)v);
+      }
+      if constexpr (PERSIST && JI == 1)
+      {
+        const bool hit = (unsigned)(spec_cmd >> 32) == na + 2;
+        const int soff = uni(hit ? (int)((unsigned)spec_cmd * 4u) : 0);
+        inp_spec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, hit ? frame * 4 : (int)kOob, soff, kInAux));
+      }
+      // (c) conv + mixin: one chain per frame group, seeded with bias + mixin * input
+      constexpr unsigned cb = (unsigned)(aq::kWB + (aq::kBigConsts + JI * 64) * 4);
+      const f4 bv = lds_ld4(lds, cb + g16), mv = lds_ld4(lds, cb + 64u + g16);
+      f4 acc[4];
+#pragma unroll
+      for (int F = 0; F < 4; F++)
+        acc[F] = __builtin_elementwise_fma(mv, f4{cnd[F], cnd[F], cnd[F], cnd[F]}, bv);
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+          for (int F = 0; F < 4; F++)
+            acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][j][s], bt[j][F][s], acc[F], 0, 0, 0);
+      // the far taps' rows of the NEXT buffer, into the registers just consumed (the stage's first job); the rows of the
+      // stage's next job, an HBM ring's, for THIS buffer (all of them at least two buffers old)
+      if constexpr (!RES && U == 0)
+        fetch_far(j_tag, wpn);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+          acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][s], xs[F][s], acc[F], 0, 0, 0);
+      if constexpr (U + 1 < NJS && !aq::res(JI + 1 < aq::kJobs ? JI + 1 : 0))
+        fetch_far(std::integral_constant<int, (U + 1 < NJS ? JI + 1 : JI)>{}, wp[U + 1 < NJS ? U + 1 : U]);
+      // (d) activation, head accumulator, layer 1x1 + residual
+      const f4 b1v = lds_ld4(lds, cb + 128u + g16);
+#pragma unroll
+      for (int F = 0; F < 4; F++)
+      {
+        const f4 z = act4<ACT_T>(act, acc[F], act_p0);
+        hd[F] += z;
+        acc[F] = z;
+        xs[F] += b1v;
+        __builtin_amdgcn_sched_barrier(0); // one frame group's activation at a time: sixteen interleaved chains spill
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+          xs[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][3][s], acc[F][s], xs[F], 0, 0, 0);
+      wp[U] = wpn;
+    };
+
+    boff = boff0;
+    bool have = !FIRST || n_blocks > 0;
+#pragma unroll 1
+    for (;; k++)
+    {
+      bool exit_tok = false;
+      float cond = 0.0f;
+      if constexpr (FIRST)
+      {
+        exit_tok = !have;
+        nvalid = PERSIST ? kBlock : min(kBlock, a.n_frames - k * kBlock);
+        more = PERSIST || k + 1 < n_blocks;
+      }
+      else
+      {
+        // the token, the head accumulator and the input sample of buffer k (its rows: job 0)
+        constexpr unsigned slot = (unsigned)aq::slot_b(QIN < 0 ? 0 : QIN);
+        wait_word(prod_b(QIN), k + 1);
+        asm volatile("" ::: "memory");
+        const i4 tok = *reinterpret_cast<const i4*>(lds + slot + 4352u);
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+        {
+          hd[F] = lds_ld4(lds, slot + g16 * 64u + (unsigned)(16 * F + n) * 16u);
+          cnd[F] = *reinterpret_cast<const float*>(lds + slot + 4096u + (unsigned)(16 * F + n) * 4u);
+        }
+        boff = (unsigned)uni(tok[0]);
+        nvalid = uni(tok[1]);
+        exit_tok = uni(tok[2]) != 0;
+        more = PERSIST || uni(tok[3]) != 0;
+      }
+      // hand-over to the next stage: the rows into its first ring (or 64-row area), the rest into the slot
+      auto hand_over = [&](bool is_exit) {
+        constexpr unsigned slot = (unsigned)aq::slot_b(QOUT);
+        wait_word(cons_b(QOUT), k); // the consumer has issued every LDS read of buffer k - 1
+        asm volatile("" ::: "memory");
+        if (!is_exit)
+        {
+#pragma unroll
+          for (int F = 0; F < 4; F++)
+          {
+            const unsigned row = aq::res(JN) ? wrap_row(wpo, (unsigned)(16 * F + n), aq::ring_len(JN)) : (unsigned)(16 * F + n);
+            lds_st4(lds, gbn + row * 16u, xs[F]);
+            lds_st4(lds, slot + g16 * 64u + (unsigned)(16 * F + n) * 16u, hd[F]);
+            if (g == 0)
+              *reinterpret_cast<float*>(lds + slot + 4096u + (unsigned)(16 * F + n) * 4u) = cnd[F];
+          }
+        }
+        if (lane == 0)
+          *reinterpret_cast<i4*>(lds + slot + 4352u) = i4{(int)boff, nvalid, is_exit ? 1 : 0, more ? 1 : 0};
+        set_word(prod_b(QOUT), k + 1);
+        if constexpr (aq::res(JN))
+        {
+          wpo += is_exit ? 0 : nvalid;
+          wpo -= wpo >= aq::ring_len(JN) ? aq::ring_len(JN) : 0;
+        }
+      };
+      if (exit_tok)
+      {
+        hand_over(true);
+        break;
+      }
+      if constexpr (FIRST)
+      {
+        cond = inp; // this buffer's input sample (requested a buffer ago)
+        if constexpr (!PERSIST) // next block's (offset beyond the launch's frames -> 0)
+          inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, frame * 4, uni((k + 1) * (kBlock * 4)), 0));
+        // array 0's rechannel (1 -> 16, model.cpp:488-490): x = column * input
+        const f4 rech = lds_ld4(lds, (unsigned)(aq::kWB + aq::kBigConsts * 4) + 192u + g16);
+#pragma unroll
+        for (int F = 0; F < 4; F++)
+        {
+          cnd[F] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 * F + n) * 4, __builtin_bit_cast(int, cond)));
+          xs[F] = rech * cnd[F];
+          hd[F] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      il::for_each_index([&](auto u_tag) { job(std::integral_constant<int, J0 + decltype(u_tag)::value>{}); },
+                         std::make_integer_sequence<int, NJS>{});
+      hand_over(false);
+      if constexpr (FIRST)
+      {
+        // the next buffer of this stage (kernel_kq.hip)
+        if constexpr (PERSIST)
+        {
+          const unsigned tag = na + 2u; // the command behind the one just finished
+          unsigned long long v = spec_cmd;
+          if ((unsigned)(v >> 32) != tag)
+          {
+            v = ring_load(tag - 1u);
+            const long long t_end = (long long)wall_clock64() + 100; // 1 us of the 100 MHz clock
+            while ((unsigned)(v >> 32) != tag && (long long)wall_clock64() < t_end)
+            {
+              __builtin_amdgcn_s_sleep(16);
+              v = ring_load(tag - 1u);
+            }
+          }
+          // ONE view of the ring slot for the whole wave (lane 0's)
+          const unsigned v_tag = (unsigned)uni((int)(unsigned)(v >> 32)), v_off = (unsigned)uni((int)(unsigned)v);
+          have = v_tag == tag;
+          const unsigned next_off = v_off * 4u;
+          na++;
+          if (have)
+          {
+            boff = next_off;
+            const bool mine = (unsigned)(spec_cmd >> 32) == na + 1u && (unsigned)spec_cmd * 4u == next_off;
+            inp = inp_spec;
+            if (!mine)
+            {
+              const int voff = frame * 4, soff = uni((int)next_off);
+              const i4 rsd = in_desc;
+              asm volatile("buffer_load_dword %0, %1, %2, %3 offen sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                           : "=v"(inp)
+                           : "v"(voff), "s"(rsd), "s"(soff)
+                           : "memory");
+            }
+          }
+        }
+        else
+        {
+          have = k + 1 < n_blocks;
+          boff = (unsigned)(k + 1) * (kBlock * 4u);
+        }
+      }
+    }
+    // the launch leaves: resident rings and write positions go back into the state
+    asm volatile("" ::: "memory");
+    il::for_each_index(
+      [&](auto u_tag) {
+        constexpr int TJ = J0 + decltype(u_tag)::value;
+        if constexpr (aq::res(TJ))
+          lds_to_ring(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), true);
+      },
+      std::make_integer_sequence<int, NJS>{});
+    store_positions(aq::ring_id(J0), NJS, wp);
+  };
+
+  // ==============================================================================================
+  // the TRANSITION stage (job 10): array 1's rechannel and array 0's head rechannel, 16 -> 8 each, one lane per frame
+  // (model.cpp:476-490: array 1's head accumulator starts as array 0's head output; its layers run on rechannel(x))
+  // ==============================================================================================
+  auto run_t = [&](auto s_tag) {
+    constexpr int SS = decltype(s_tag)::value;
+    constexpr int QIN = SS - 1, QOUT = SS, JN = aq::kFirst[SS + 1];
+    static_assert(aq::kFirst[SS] == aq::kJobT && JN == aq::kJobM0 && aq::res(JN), "aq: the transition is a stage of its own");
+    int wpo = __builtin_amdgcn_readlane(wposv, aq::ring_id(JN));
+    lds_barrier();
+#pragma unroll 1
+    for (int k = 0;; k++)
+    {
+      constexpr unsigned slot = (unsigned)aq::slot_b(QIN), xin = (unsigned)aq::in_b(aq::kJobT);
+      wait_word(prod_b(QIN), k + 1);
+      asm volatile("" ::: "memory");
+      const i4 tok = *reinterpret_cast<const i4*>(lds + slot + 4352u);
+      const bool exit_tok = uni(tok[2]) != 0;
+      f4 x16[4], h16[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+      {
+        x16[p] = lds_ld4(lds, xin + (unsigned)p * 1024u + frame16);
+        h16[p] = lds_ld4(lds, slot + (unsigned)p * 1024u + frame16);
+      }
+      const float cond = *reinterpret_cast<const float*>(lds + slot + 4096u + (unsigned)lane * 4u);
+      set_word(cons_b(QIN), k + 1);
+      nvalid = uni(tok[1]);
+      constexpr unsigned oslot = (unsigned)aq::slot_b(QOUT);
+      if (exit_tok)
+      {
+        wait_word(cons_b(QOUT), k);
+        asm volatile("" ::: "memory");
+        if (lane == 0)
+          *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
+        set_word(prod_b(QOUT), k + 1);
+        break;
+      }
+      // x8 = Wr x16; h8 = bias + Wh h16: per output half one chain, input channels in order
+      constexpr unsigned wr = (unsigned)(aq::kWB + aq::kWrOff * 4), wh = (unsigned)(aq::kWB + aq::kWhOff * 4), tc = (unsigned)(aq::kWB + aq::kTConsts * 4);
+      f4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
+      f4 ha = lds_ld4(lds, tc), hb = lds_ld4(lds, tc + 16u);
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+      {
+        const f4 w0 = lds_ld4(lds, wr + cls128 + (unsigned)p * 16u), w1 = lds_ld4(lds, wr + cls128 + 64u + (unsigned)p * 16u);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          xa = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[c], x16[p][c], xa, 0, 0, 0);
+          xb = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[c], x16[p][c], xb, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+      {
+        const f4 w0 = lds_ld4(lds, wh + cls128 + (unsigned)p * 16u), w1 = lds_ld4(lds, wh + cls128 + 64u + (unsigned)p * 16u);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          ha = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[c], h16[p][c], ha, 0, 0, 0);
+          hb = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[c], h16[p][c], hb, 0, 0, 0);
+        }
+      }
+      wait_word(cons_b(QOUT), k);
+      asm volatile("" ::: "memory");
+      {
+        constexpr int RN = aq::ring_len(JN);
+        const unsigned row = wrap_row(wpo, (unsigned)frame, RN) * 16u;
+        lds_st4(lds, (unsigned)aq::in_b(JN) + row, xa);
+        lds_st4(lds, (unsigned)(aq::in_b(JN) + aq::plane_b(JN)) + row, xb);
+        lds_st4(lds, oslot + frame16, ha);
+        lds_st4(lds, oslot + 1024u + frame16, hb);
+        *reinterpret_cast<float*>(lds + oslot + 2048u + (unsigned)lane * 4u) = cond;
+        if (lane == 0)
+          *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
+        wpo += nvalid;
+        wpo -= wpo >= RN ? RN : 0;
+      }
+      set_word(prod_b(QOUT), k + 1);
+    }
+  };
+
+  // ==============================================================================================
+  // SMALL stages (array 1, 8 channels; the last one also the head): one lane per frame (kernel_kq.hip's job on rings)
+  // ==============================================================================================
+  auto run_small = [&](auto s_tag) {
+    constexpr int SS = decltype(s_tag)::value;
+    constexpr int J0 = aq::kFirst[SS], JE = aq::kFirst[SS + 1], LAST = SS == NST - 1;
+    constexpr int NL = (LAST ? JE - 1 : JE) - J0; // layers (the last stage's final job is the head)
+    constexpr int JN = LAST ? 0 : JE;
+    constexpr int QIN = SS - 1, QOUT = SS;
+    constexpr int NFAR = aq::far_jobs_before(SS, J0 + NL);
+    static_assert(LAST || aq::res(JN), "aq: a small stage hands its rows to a resident ring");
+    int wp[NL];
+#pragma unroll
+    for (int u = 0; u < NL; u++)
+      wp[u] = __builtin_amdgcn_readlane(wposv, aq::ring_id(J0 + u));
+    int wpo = LAST ? 0 : __builtin_amdgcn_readlane(wposv, aq::ring_id(JN));
+    il::for_each_index(
+      [&](auto u_tag) {
+        constexpr int TJ = J0 + decltype(u_tag)::value;
+        if constexpr (aq::res(TJ))
+          ring_to_lds(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), false);
+      },
+      std::make_integer_sequence<int, NL>{});
+    struct Row
+    {
+      f4 q0, q1;
+    };
+    Row far[NFAR > 0 ? NFAR : 1][2];
+    auto fetch_far = [&](auto tj_tag, int wpj) {
+      constexpr int TJ = decltype(tj_tag)::value;
+      constexpr int R = aq::ring_len(TJ), D = aq::dil(TJ), FI = aq::far_jobs_before(SS, TJ);
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+      {
+        const int idx = (int)wrap_row(wrap_s(wpj - (2 - j) * D, R), (unsigned)frame, R);
+        far[FI][j].q0 = aq_sb_load4(rs8, idx, 0, aq::ring_off(TJ) * 4, 0);
+        far[FI][j].q1 = aq_sb_load4(rs8, idx, 16, aq::ring_off(TJ) * 4, 0);
+      }
+    };
+    il::for_each_index(
+      [&](auto u_tag) {
+        constexpr int TJ = J0 + decltype(u_tag)::value;
+        if constexpr (!aq::res(TJ))
+          fetch_far(std::integral_constant<int, TJ>{}, wp[TJ - J0]);
+      },
+      std::make_integer_sequence<int, NL>{});
+    lds_barrier();
+
+    f4 x0, x1, head0, head1;
+    float cond = 0.0f;
+    int k = 0;
+    auto job = [&](auto j_tag) {
+      constexpr int JI = decltype(j_tag)::value;
+      constexpr int U = JI - J0, LI = JI - aq::kJobM0;
+      constexpr int R = aq::ring_len(JI), D = aq::dil(JI);
+      constexpr bool RES = aq::res(JI), TAKES = U == 0;
+      constexpr int FI = aq::far_jobs_before(SS, JI);
+      constexpr unsigned rb0 = (unsigned)aq::in_b(JI), rb1 = rb0 + (unsigned)aq::plane_b(JI);
+      __builtin_amdgcn_sched_barrier(0);
+      const int wpj = wp[U];
+      const unsigned row0 = wrap_row(wpj, (unsigned)frame, R);
+      if constexpr (TAKES)
+      {
+        x0 = lds_ld4(lds, rb0 + row0 * 16u);
+        x1 = lds_ld4(lds, rb1 + row0 * 16u);
+      }
+      else if constexpr (RES)
+      {
+        lds_st4(lds, rb0 + row0 * 16u, x0);
+        lds_st4(lds, rb1 + row0 * 16u, x1);
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (!RES)
+      {
+        const int widx = frame < nvalid ? (int)row0 : aq::kNoRow;
+        aq_sb_store4(x0, rs8, widx, 0, aq::ring_off(JI) * 4, kAppAux);
+        aq_sb_store4(x1, rs8, widx, 16, aq::ring_off(JI) * 4, kAppAux);
+      }
+      int wpn = wpj + nvalid;
+      wpn -= wpn >= R ? R : 0;
+      f4 b0[2], b1[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+      {
+        if constexpr (RES)
+        {
+          const unsigned row = wrap_row(wrap_s(wpj - (2 - j) * D, R), (unsigned)frame, R) * 16u;
+          b0[j] = lds_ld4(lds, rb0 + row);
+          b1[j] = lds_ld4(lds, rb1 + row);
+        }
+        else
+          b0[j] = far[FI][j].q0, b1[j] = far[FI][j].q1;
+      }
+      if constexpr (TAKES)
+        set_word(cons_b(QIN), k + 1);
+      constexpr unsigned cb = (unsigned)(aq::kWB + (aq::kMConsts + LI * 24) * 4);
+      f4 acc0 = lds_ld4(lds, cb), acc1 = lds_ld4(lds, cb + 16u);
+      {
+        const f4 m0 = lds_ld4(lds, cb + 32u), m1 = lds_ld4(lds, cb + 48u);
+        const f4 c4 = {cond, cond, cond, cond};
+        acc0 = __builtin_elementwise_fma(m0, c4, acc0);
+        acc1 = __builtin_elementwise_fma(m1, c4, acc1);
+      }
+      auto tap = [&](unsigned tb, const f4& v0, const f4& v1, f4& o0, f4& o1) {
+        const f4 wa = lds_ld4(lds, tb + cls64), wb = lds_ld4(lds, tb + 16u + cls64);
+        const f4 wc = lds_ld4(lds, tb + 32u + cls64), wd = lds_ld4(lds, tb + 48u + cls64);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[c], v0[c], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[c], v0[c], o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[c], v1[c], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[c], v1[c], o1, 0, 0, 0);
+        }
+      };
+      constexpr unsigned t0 = (unsigned)(aq::kWB + (aq::kMTiles + LI * 4 * aq::kTileM) * 4);
+      tap(t0, b0[0], b1[0], acc0, acc1);
+      tap(t0 + 256u, b0[1], b1[1], acc0, acc1);
+      if constexpr (!RES)
+        fetch_far(j_tag, wpn);
+      tap(t0 + 512u, x0, x1, acc0, acc1);
+      const f4 b1v0 = lds_ld4(lds, cb + 64u), b1v1 = lds_ld4(lds, cb + 80u);
+      const f4 z0 = act4<ACT_T>(act, acc0, act_p0), z1 = act4<ACT_T>(act, acc1, act_p0);
+      head0 += z0;
+      head1 += z1;
+      f4 y0 = x0 + b1v0, y1 = x1 + b1v1;
+      tap(t0 + 768u, z0, z1, y0, y1);
+      x0 = y0;
+      x1 = y1;
+      wp[U] = wpn;
+    };
+
+#pragma unroll 1
+    for (;; k++)
+    {
+      constexpr unsigned slot = (unsigned)aq::slot_b(QIN);
+      wait_word(prod_b(QIN), k + 1);
+      asm volatile("" ::: "memory");
+      const i4 tok = *reinterpret_cast<const i4*>(lds + slot + 2304u);
+      head0 = lds_ld4(lds, slot + frame16);
+      head1 = lds_ld4(lds, slot + 1024u + frame16);
+      cond = *reinterpret_cast<const float*>(lds + slot + 2048u + (unsigned)lane * 4u);
+      boff = (unsigned)uni(tok[0]);
+      nvalid = uni(tok[1]);
+      const bool exit_tok = uni(tok[2]) != 0;
+      if (exit_tok)
+      {
+        set_word(cons_b(QIN), k + 1);
+        if constexpr (!LAST)
+        {
+          constexpr unsigned oslot = (unsigned)aq::slot_b(LAST ? 0 : QOUT);
+          wait_word(cons_b(QOUT), k);
+          asm volatile("" ::: "memory");
+          if (lane == 0)
+            *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
+          set_word(prod_b(QOUT), k + 1);
+        }
+        break;
+      }
+      il::for_each_index([&](auto u_tag) { job(std::integral_constant<int, J0 + decltype(u_tag)::value>{}); },
+                         std::make_integer_sequence<int, NL>{});
+      if constexpr (!LAST)
+      {
+        constexpr unsigned oslot = (unsigned)aq::slot_b(LAST ? 0 : QOUT);
+        constexpr int RN = aq::ring_len(JN);
+        wait_word(cons_b(QOUT), k);
+        asm volatile("" ::: "memory");
+        const unsigned row = wrap_row(wpo, (unsigned)frame, RN) * 16u;
+        lds_st4(lds, (unsigned)aq::in_b(JN) + row, x0);
+        lds_st4(lds, (unsigned)(aq::in_b(JN) + aq::plane_b(JN)) + row, x1);
+        lds_st4(lds, oslot + frame16, head0);
+        lds_st4(lds, oslot + 1024u + frame16, head1);
+        *reinterpret_cast<float*>(lds + oslot + 2048u + (unsigned)lane * 4u) = cond;
+        if (lane == 0)
+          *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
+        wpo += nvalid;
+        wpo -= wpo >= RN ? RN : 0;
+        set_word(prod_b(QOUT), k + 1);
+      }
+      else
+      {
+        // array 1's head rechannel (8 -> 1, bias), head_scale (model.cpp:547-549, 886-910)
+        constexpr unsigned tb = (unsigned)(aq::kWB + aq::kHeadTile * 4);
+        const f4 wa = lds_ld4(lds, tb + cls64), wb = lds_ld4(lds, tb + 16u + cls64);
+        f4 acc = lds_ld4(lds, (unsigned)(aq::kWB + aq::kTConsts * 4) + 32u);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[c], head0[c], acc, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[c], head1[c], acc, 0, 0, 0);
+        const float yout = head_scale * acc[0];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, frame < nvalid ? frame * 4 : (int)kOob, uni((int)boff),
+                                              PERSIST && !kOutHost ? 17 : 0);
+        if constexpr (PERSIST)
+        {
+          done++;
+          if (lane == 0 && (done & 15u) == 0u) // progress for the host's ring bookkeeping (not a completion signal)
+            __hip_atomic_store(a.p_prog + blockIdx.x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    il::for_each_index(
+      [&](auto u_tag) {
+        constexpr int TJ = J0 + decltype(u_tag)::value;
+        if constexpr (aq::res(TJ))
+          lds_to_ring(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), false);
+      },
+      std::make_integer_sequence<int, NL>{});
+    store_positions(aq::ring_id(J0), NL, wp);
+  };
+
+  il::for_each_index(
+    [&](auto s_tag) {
+      constexpr int SS = decltype(s_tag)::value;
+      if (S == SS)
+      {
+        if constexpr (aq::is_big(aq::kFirst[SS]))
+          run_big(s_tag);
+        else if constexpr (aq::kFirst[SS] == aq::kJobT)
+          run_t(s_tag);
+        else
+          run_small(s_tag);
+      }
+    },
+    std::make_integer_sequence<int, NST>{});
+
+  if constexpr (PERSIST)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if constexpr (kOutHost)
+    {
+      if (S == NST - 1) // one wave per workgroup asks for the write-back (kernel_a1_p4.hip)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    }
+    if (S == NST - 1 && lane == 0)
+    {
+      a.p_cons[blockIdx.x] = done;
+      __hip_atomic_store(a.p_done + blockIdx.x, done | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+#ifdef NAM_AQ_PROBE // developer builds (tools/isa_regions.py): one instantiation only
+template __global__ void nam_a1_q_kernel<ACT_FASTTANH, false, true>(const float* __restrict__, const A1Args);
+#else
+namespace
+{
+template <int ACT_T, bool WT, bool PERSIST = false>
+hipError_t launch_q_inst(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  static DynamicLdsLimit lds_limit; // per instantiation, tracked per device (kernels.h)
+  const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_q_kernel<ACT_T, WT, PERSIST>), aq::kLdsBytes);
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL((nam_a1_q_kernel<ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(aq::kNst * 64), aq::kLdsBytes, stream, a.blob, a);
+  return hipGetLastError();
+}
+template <int ACT_T>
+hipError_t launch_q_act(const A1Args& a, int n_blocks, hipStream_t stream)
+{
+  if (a.p_ring) // persistent session (kernel_a1_p4.hip: launch_p4_shape)
+    return a.p_out_host != 0 ? launch_q_inst<ACT_T, true, true>(a, n_blocks, stream) : launch_q_inst<ACT_T, false, true>(a, n_blocks, stream);
+  const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through
+  return wt ? launch_q_inst<ACT_T, true>(a, n_blocks, stream) : launch_q_inst<ACT_T, false>(a, n_blocks, stream);
+}
+} // namespace
+
+// a.tiles_off: blob offset (floats) of the kernel's own weight block (plan.cpp: build_a1_q; aq_table.h), a.consts_off: of the
+// big layers' register tiles = the A1 kernels' tile area (A1Plan::ws_tiles_off, FULL layout)
+bool a1_q_takes(int act)
+{
+  return act == ACT_FASTTANH || act == ACT_TANH;
+}
+hipError_t launch_a1_q(const A1Args& a, int n_blocks, int act, hipStream_t stream)
+{
+  if (act == ACT_FASTTANH)
+    return launch_q_act<ACT_FASTTANH>(a, n_blocks, stream);
+  if (act == ACT_TANH)
+    return launch_q_act<ACT_TANH>(a, n_blocks, stream);
+  return hipErrorInvalidValue; // (other activations keep nam_a1_p4_kernel: a1_q_takes)
+}
+#endif
+
+} // namespace namhip

@@ -171,6 +171,10 @@ hipError_t launch_a1_il(const A1Args& a, int n_blocks, int act, hipStream_t stre
 hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
 // nam_a1_p4_kernel: the same models as a pipeline of wave sets decoupled through LDS (kernel_a1_p4.hip)
 hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
+// nam_a1_q_kernel (kernel_a1_q.hip): the 16 / 8 official topology (aq_table.h) as twelve one-wave stages with LDS-resident
+// rings; a.tiles_off = the plan's q weight block (A1Plan::q_w_off), a.consts_off = the FULL-layout tile area (ws_tiles_off)
+bool a1_q_takes(int act); // the activations it is compiled for (Fasttanh, Tanh)
+hipError_t launch_a1_q(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 // nam_kp_kernel (kernel_kp.hip): the A2 topology (kp_table.h) as a pipeline of wave sets; a.tiles_off / consts_off / r1_off =
 // blob offsets of the K-tap kernel's tap tiles, LDS block and rechannel column
 hipError_t launch_kp(const A1Args& a, int n_blocks, int act, hipStream_t stream);

@@ -192,6 +192,7 @@ struct nam_hip_batch
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
+  bool use_q = true; // the official 16 / 8 topology's pipeline runs nam_a1_q_kernel (kernel_a1_q.hip); NAM_HIP_A1Q=0: nam_a1_p4_kernel (A/B runs)
   bool use_kq = true; // the A2 topology's pipeline runs nam_kq_kernel (kernel_kq.hip) where it applies; NAM_HIP_KQ=0: nam_kp_kernel everywhere
   int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
@@ -364,6 +365,12 @@ inline bool use_pipeline(const nam_hip_batch* b, int n_frames)
   return !b->no_pipe && (b->ps_launching || n_frames > kBlock);
 }
 
+// the official 16 / 8 topology's pipeline: nam_a1_q_kernel (one-wave stages, LDS-resident rings) unless switched off
+inline bool q_runs(const nam_hip_batch* b, const Plan& p)
+{
+  return b->use_q && p.a1.q_ok && !b->il_generic && a1_q_takes(p.a1.arr[0].act);
+}
+
 // the A2 topology's pipeline: nam_kq_kernel (one lane per frame, 4x4x1 matrix instructions) for the activation it is
 // compiled for, nam_kp_kernel otherwise
 inline bool kq_runs(const nam_hip_batch* b, const Plan& p)
@@ -379,7 +386,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
   if (b->ps.enabled && n_frames == kBlock)
     switch (persist_kind(b)) // persistent block mode
     {
-      case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : "nam_a1_p4_kernel";
+      case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : q_runs(b, p) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel";
       case PERSIST_KP: return kq_runs(b, p) ? "nam_kq_kernel" : "nam_kp_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
@@ -394,7 +401,8 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
       case NAM_HIP_KERNEL_WN_REG: return "nam_wn_reg_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
       case NAM_HIP_KERNEL_A1_IL:
-        return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_pipe && n_frames > kBlock) ? "nam_a1_p4_kernel" : "nam_a1_p2_kernel") : "nam_a1_il_kernel";
+        return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_pipe && n_frames > kBlock) ? (q_runs(b, p) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel") : "nam_a1_p2_kernel")
+                                               : "nam_a1_il_kernel";
       default:
         return p.a1.ws_ok ? "nam_a1_mfma_kernel" : (p.a1.kp_ok && !b->no_pipe && n_frames > kBlock) ? (kq_runs(b, p) ? "nam_kq_kernel" : "nam_kp_kernel") : "nam_kt_mfma_kernel";
     }
@@ -699,7 +707,15 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames))
+        if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames) && q_runs(b, p))
+        {
+          // the 16 / 8 topology as twelve one-wave stages, most rings resident in LDS (kernel_a1_q.hip): its own weight block
+          // + the FULL-layout tiles of array 0 (kept in registers)
+          a.consts_off = p.a1.ws_tiles_off;
+          a.tiles_off = p.a1.q_w_off;
+          NAM_HIP_CHECK(launch_a1_q(a, n, act, s));
+        }
+        else if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames))
           // ... as a pipeline of wave sets (three wavefronts per SIMD) across consecutive buffers
           NAM_HIP_CHECK(launch_a1_p4(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
         else if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
@@ -1807,6 +1823,8 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
     b->il_generic = e && e[0] == '1';
     if (const char* e4 = std::getenv("NAM_HIP_WR_STAGES"))
       b->wr_max_stages = std::max(1, std::atoi(e4));
+    const char* e6 = std::getenv("NAM_HIP_A1Q");
+    b->use_q = !(e6 && e6[0] == '0');
     const char* e5 = std::getenv("NAM_HIP_KQ");
     b->use_kq = !(e5 && e5[0] == '0');
     const char* e3 = std::getenv("NAM_HIP_NO_PIPE");

@@ -9,6 +9,7 @@
 // (model.cpp:152-181, 563-569, 661-683; Conv1D conv1d.cpp:40-55; Conv1x1 dsp.cpp:384-397).
 #include "plan.h"
 #include "kp_table.h"
+#include "aq_table.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1223,6 +1224,96 @@ void build_a1_kp(Plan& plan)
   a1.kp_ok = 1;
 }
 
+// nam_a1_q_kernel (kernel_a1_q.hip) runs this model if it IS the topology of aq_table.h: the official two-array stack with
+// 16 and 8 channels. Its weight block (aq_table.h: kWrOff .. kBlockFloats) holds the lane-per-frame (4x4x1) tiles of the
+// transition, of array 1 and of the head, every constant, and array 0's constants in channel order; array 0's matrices
+// are the FULL-layout tiles build_a1_ws has already packed (ws_tiles_off), which the kernel keeps in registers.
+void build_a1_q(Plan& plan)
+{
+  A1Plan& a1 = plan.a1;
+  a1.q_ok = 0;
+  a1.q_w_off = 0;
+  if (!a1.valid || !a1.p2_ok || a1.p2_c0 != aq::kC0 || a1.p2_c1 != aq::kC1 || a1.n_arrays != 2 || a1.n_rings != aq::kRings)
+    return;
+  for (int ai = 0; ai < 2; ai++)
+  {
+    const A1Array& A = a1.arr[ai];
+    if (A.channels != (ai == 0 ? aq::kC0 : aq::kC1) || A.n_layers != aq::kLayers || A.head_k != 1
+        || A.in_size != (ai == 0 ? 1 : aq::kC0) || A.head_size != (ai == 0 ? aq::kC1 : 1))
+      return;
+    for (int l = 0; l < aq::kLayers; l++)
+    {
+      const int job = ai == 0 ? l : aq::kJobM0 + l;
+      if (A.ksize[l] != 3 || A.dil[l] != aq::dil(job) || A.ring_id[l] != aq::ring_id(job) || A.ring_len[l] != aq::ring_len(job)
+          || A.ring_off[l] != aq::ring_off(job))
+        return;
+    }
+  }
+  while (plan.blob.size() % 64)
+    plan.blob.push_back(0.0f);
+  const size_t w0 = plan.blob.size();
+  plan.blob.resize(w0 + (size_t)aq::kBlockFloats, 0.0f);
+  float* const q = plan.blob.data() + w0;
+  const A1Array& A0 = a1.arr[0];
+  const A1Array& A1 = a1.arr[1];
+  const float* const base0 = plan.blob.data() + A0.w_base;
+  const float* const base1 = plan.blob.data() + A1.w_base;
+  // 4x4x1 tile: [lane class i][h][c] = W[out = 4 h + i][in = c]
+  auto fill_tile = [&](float* t, int n_half, int n_in, auto at) {
+    for (int i = 0; i < 4; i++)
+      for (int h = 0; h < n_half; h++)
+        for (int c = 0; c < n_in; c++)
+          t[(i * n_half + h) * n_in + c] = at(4 * h + i, c);
+  };
+  const int C0 = aq::kC0, C1 = aq::kC1;
+  // array 1's rechannel: packed [ci][co]; array 0's head rechannel: packed [k = 0][c][h], bias[h] behind it
+  fill_tile(q + aq::kWrOff, 2, C0, [&](int co, int ci) { return base1[(size_t)ci * C1 + co]; });
+  const float* hw0 = base0 + A0.head_off;
+  fill_tile(q + aq::kWhOff, 2, C0, [&](int co, int ci) { return hw0[(size_t)ci * C1 + co]; });
+  for (int h = 0; h < C1; h++)
+    q[aq::kTConsts + h] = hw0[(size_t)C0 * C1 + h];
+  for (int l = 0; l < aq::kLayers; l++)
+  {
+    const float* cw = base1 + A1.layer_off[l];
+    const float* cb = cw + (size_t)3 * C1 * C1;
+    const float* mx = cb + C1;
+    const float* w1 = mx + C1;
+    const float* b1 = w1 + (size_t)C1 * C1;
+    for (int k = 0; k < 3; k++)
+      fill_tile(q + aq::kMTiles + (l * 4 + k) * aq::kTileM, 2, C1, [&](int co, int ci) { return cw[((size_t)k * C1 + ci) * C1 + co]; });
+    fill_tile(q + aq::kMTiles + (l * 4 + 3) * aq::kTileM, 2, C1, [&](int co, int ci) { return w1[(size_t)ci * C1 + co]; });
+    for (int c = 0; c < C1; c++)
+    {
+      q[aq::kMConsts + l * 24 + c] = cb[c];
+      q[aq::kMConsts + l * 24 + 8 + c] = mx[c];
+      q[aq::kMConsts + l * 24 + 16 + c] = b1[c];
+    }
+  }
+  {
+    const float* hw1 = base1 + A1.head_off; // [k = 0][c][h = 0], bias behind it
+    fill_tile(q + aq::kHeadTile, 2, C1, [&](int co, int ci) { return co == 0 ? hw1[ci] : 0.0f; });
+    q[aq::kTConsts + 8] = hw1[C1];
+  }
+  for (int l = 0; l < aq::kLayers; l++)
+  {
+    const float* cw = base0 + A0.layer_off[l];
+    const float* cb = cw + (size_t)3 * C0 * C0;
+    const float* mx = cb + C0;
+    const float* w1 = mx + C0;
+    const float* b1 = w1 + (size_t)C0 * C0;
+    float* d = q + aq::kBigConsts + l * 64;
+    for (int c = 0; c < C0; c++)
+    {
+      d[c] = cb[c];
+      d[16 + c] = mx[c];
+      d[32 + c] = b1[c];
+      d[48 + c] = l == 0 ? base0[c] : 0.0f; // array 0's rechannel column [ci = 0][co]
+    }
+  }
+  a1.q_w_off = (int)w0;
+  a1.q_ok = 1;
+}
+
 // The official "lite" size (12 -> 6 channels) misses the matrix-core kernel only because 6 is not a multiple of 4.
 // Zero-padding such arrays to the next multiple (weights, biases, mixin, rechannels all zero for the extra channels)
 // is exact on the real channels: the padded ones carry f(0) through the activations and meet zero weights everywhere.
@@ -2097,6 +2188,7 @@ Plan build_wavenet_plan(const WaveNetSpec& wn, WrShapeSet* jit_shapes)
     build_a1_kt(plan);
     build_a1_kp(plan);
     build_a1_il(plan);
+    build_a1_q(plan);
   }
   build_wr(wn, plan, jit_shapes);
   return plan;

@@ -361,7 +361,8 @@ struct A1Plan
   KtDesc kt_desc[kKtChunkMax];
   int32_t kp_ok = 0; // nam_kp_kernel can run this model too: it IS the topology of kp_table.h (plan.cpp: build_a1_kp)
   int32_t kq_w_off = 0; // blob float offset of nam_kq_kernel's weight block (tiles | constants | rechannel column; kernel_kq.hip)
-  int32_t kp_pad[2] = {0, 0};
+  int32_t q_ok = 0; // nam_a1_q_kernel runs this model: it IS the topology of aq_table.h (plan.cpp: build_a1_q)
+  int32_t q_w_off = 0; // blob float offset of its weight block (aq_table.h: kWrOff .. kBlockFloats)
 };
 
 // ---- register-resident WaveNet (nam_wn_reg_kernel) ----------------------------------------------------------------

@@ -819,7 +819,7 @@ def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, monkeypatch, na
         b.set_kernel(nam.KERNEL_A1_IL)
         assert b.get_kernel() == nam.KERNEL_A1_IL and b.kernel_name() == want_name
         if p2 and not generic:  # launches of more than one block: the two-wave-set form of the same kernel
-            assert b.kernel_name(512) == "nam_a1_p4_kernel"
+            assert b.kernel_name(512) == ("nam_a1_q_kernel" if name == "wavenet_a1_standard" else "nam_a1_p4_kernel")
         b.Reset(prewarm=True)
         y = b.process_stream(x, max_frames)
         b.close()
@@ -886,7 +886,7 @@ def test_persistent_block_mode_matches_oracle(nam_lib, oracle):
     # the kernels that speak the session protocol: nam_a1_p2_kernel (a workgroup per stream), nam_wn_reg_kernel (a
     # wavefront per stream), nam_lstm_row_kernel (a wavefront per four streams: 7 streams = a ragged last workgroup),
     # nam_lstm_wide_kernel (a wavefront per stream)
-    for name, kname in (("wavenet_a1_standard", "nam_a1_p4_kernel"), ("synth_a1_feather", "nam_a1_p4_kernel"), ("synth_a1_lite", "nam_a1_p4_kernel"),
+    for name, kname in (("wavenet_a1_standard", "nam_a1_q_kernel"), ("synth_a1_feather", "nam_a1_p4_kernel"), ("synth_a1_lite", "nam_a1_p4_kernel"),
                         ("wavenet_a2_max", "nam_wn_reg_kernel"), ("lstm", "nam_lstm_row_kernel"),
                         ("synth_lstm_h4x2", "nam_lstm_row_kernel"), ("synth_lstm_h18x2", "nam_lstm_wide_kernel")):
         model = nam.get_dsp(model_path(name), fast_tanh=True)
