@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/nam_hip.h"
+#include "slimmable.h"
 
 #ifdef NAM_SAMPLE_FLOAT
   #define NAM_SAMPLE float
@@ -96,14 +97,6 @@ public:
 
 private:
   bool mPreviousPrewarmOnReset;
-};
-
-class SlimmableModel // reference NAM/slimmable.h:13-29
-{
-public:
-  virtual ~SlimmableModel() = default;
-  virtual void SetSlimmableSize(const double val) = 0;
-  virtual std::vector<double> GetSlimmableSizeBreakpoints() const { return {}; }
 };
 
 class DSP
