@@ -89,7 +89,10 @@ typedef struct nam_hip_model_info
   int64_t num_weights;
   int32_t fast_tanh; /* load-time switch replacing the global Activation::enable_fast_tanh (activations.cpp:168) */
   int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: one of the A1 MFMA kernels can; bit 2: the
-                            interleaved-frame MFMA kernel can; bit 3: in its compile-time-topology form (official sizes) */
+                            interleaved-frame MFMA kernel can; bit 3: in its compile-time-topology form (official sizes);
+                            bit 4: nam_wn_reg_kernel can; bit 5: the model asked for nam_wn_reg_kernel compiled for its own layer
+                            shapes and that compile was not available here (no compiler / sources / private cache directory:
+                            a line on stderr and NAM_HIP_FIELD_DESCRIPTION say why) — it runs, on a slower form */
   int64_t state_bytes_per_stream; /* HBM history per stream */
   char version[32]; /* .nam "version" */
 } nam_hip_model_info;

@@ -258,6 +258,12 @@ class Model:
         m = re.findall(r"wn_reg=0 \(([^)]*)\)", self.describe())
         return m[-1] if m else ""
 
+    def jit_failed(self) -> str:
+        """Why the per-model compile of nam_wn_reg_kernel was not available ('' when it was, or was not needed)."""
+        import re
+        m = re.findall(r"wn_reg_jit=failed \((.*?)\)(?: \||$)", self.describe())
+        return m[-1] if m else ""
+
     def GetSlimmableSizeBreakpoints(self) -> List[float]:
         buf = (ctypes.c_double * 64)()
         n = _check(self._L.nam_hip_model_slimmable_breakpoints(self._h, buf, 64))

@@ -21,12 +21,16 @@ constexpr int kLayers = 10; // per array
 constexpr int kJobT = 10, kJobM0 = 11, kJobHead = 21, kJobs = 22;
 constexpr int kRings = 20;
 constexpr int kTable = 64; // write-position words in front of a stream's rings
-constexpr int kNst = 12;
-// stage s = jobs [kFirst[s], kFirst[s + 1]); wave i of the workgroup runs stage kStageOfWave[i]; waves i, i + 4, i + 8 share
-// a SIMD. Estimated issue cycles per buffer (matrix + vector): a big layer 2.65 k, a small layer 0.8 k, the transition
-// 0.55 k -> per SIMD {L0-1, L2, T} 8.5 k | {L3-4, L5, M0} 8.75 k | {L6-7, L8, M1} 8.75 k | {L9, M2-5, M6-9 + head} 9.05 k
-constexpr int kFirst[kNst + 1] = {0, 2, 3, 5, 6, 8, 9, 10, 11, 12, 13, 17, 22};
-constexpr int kStageOfWave[kNst] = {0, 2, 4, 6, 1, 3, 5, 10, 7, 8, 9, 11};
+constexpr int kNst = 16;
+// stage s = jobs [kFirst[s], kFirst[s + 1]); wave i of the workgroup runs stage kStageOfWave[i]; waves i, i + 4, i + 8, i + 12
+// share a SIMD (tools/src/simd_map.hip). FOUR waves per SIMD: one wave issues a vector instruction every ~8.6 cycles, three
+// share the port at 3.0 cycles per instruction, four at ~2.2 (tools/src/valu_rate.hip) — and a stage's own instruction stream
+// is a floor under the period whatever the SIMD's load (profiles/r04/a1q_timeline_12_stages.txt: the five-job last stage of
+// the twelve-stage cut never waited). Every big layer is a stage of its own, the small layers go in pairs. Matrix + vector
+// port cycles per buffer: a big layer 2.65 k, a pair of small layers 1.5 k -> per SIMD {L0, L1, L2, M9 + head} 8.85 k |
+// {L3, L4, L5, T + M0} 9.25 k | {L6, L7, M1-2, M3-4} 8.3 k | {L8, L9, M5-6, M7-8} 8.35 k
+constexpr int kFirst[kNst + 1] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 22};
+constexpr int kStageOfWave[kNst] = {0, 3, 6, 8, 1, 4, 7, 9, 2, 5, 11, 13, 15, 10, 12, 14};
 static_assert(kFirst[kNst] == kJobs, "aq stage table");
 
 constexpr bool is_big(int job) { return job < kLayers; }
@@ -58,8 +62,10 @@ constexpr int stage_of(int job)
 constexpr bool starts_stage(int job) { return kFirst[stage_of(job)] == job; }
 // a job's input area in LDS: planes of 16-byte rows, [C / 4 planes][rows]. Resident ring: R rows (plane pitch rounded up
 // to 256 bytes: the four lane groups of a b128 access then never share a bank). A stage's FIRST job whose ring is in HBM
-// (or that has none: the transition) takes its input through a 64-row area.
-constexpr int in_rows(int job) { return res(job) ? ring_len(job) : (job > 0 && job < kJobHead && starts_stage(job)) ? kBlockF : 0; }
+// (or that has none: the transition) takes its input through a small area: two sub-blocks (32 rows) for a big layer, one
+// buffer (64 rows) for the transition and for a small layer.
+constexpr bool takes_area(int job) { return job > 0 && job < kJobHead && starts_stage(job) && !res(job); }
+constexpr int in_rows(int job) { return res(job) ? ring_len(job) : takes_area(job) ? (is_big(job) ? 32 : kBlockF) : 0; }
 constexpr int plane_b(int job) { return (in_rows(job) * 16 + 255) / 256 * 256; }
 constexpr int in_bytes(int job) { return plane_b(job) * (chans(job) / 4); }
 
@@ -81,14 +87,16 @@ static_assert(kBlockFloats % 4 == 0, "aq weight block");
 constexpr int kWB = 0;
 constexpr int kFlagB = kWB + kBlockFloats * 4; // 256 bytes of single-writer words
 constexpr int kSlotB0 = kFlagB + 256;
-// boundary b = stage b -> b + 1: a slot with the head accumulator (planes of 16-byte rows), the input sample, a token
-constexpr int kBigSlot = 4 * 1024 + 256 + 16, kSmallSlot = 2 * 1024 + 256 + 16;
-constexpr bool big_slot(int b) { return kFirst[b + 1] <= kJobT; } // the consumer's first job reads 16 channels
+// boundary b = stage b -> b + 1: a slot with the head accumulator (planes of 16-byte rows), the input sample, a token.
+// Into a big stage: two sub-blocks deep ([4 planes][32 rows] | input sample [32] | token); into the transition: a whole
+// buffer of sub-blocks ([4 planes][64 rows] | [64] | token); between small stages: one buffer ([2 planes][64 rows] | [64] | token)
+constexpr int kSubSlot = 2 * 1024 + 128 + 16, kBigSlot = 4 * 1024 + 256 + 16, kSmallSlot = 2 * 1024 + 256 + 16;
+constexpr int slot_bytes(int b) { return is_big(kFirst[b + 1]) ? kSubSlot : kFirst[b + 1] == kJobT ? kBigSlot : kSmallSlot; }
 constexpr int slot_b(int b)
 {
   int o = kSlotB0;
   for (int i = 0; i < b; i++)
-    o += big_slot(i) ? kBigSlot : kSmallSlot;
+    o += slot_bytes(i);
   return o;
 }
 constexpr int kInB0 = (slot_b(kNst - 1) + 255) / 256 * 256;
@@ -101,6 +109,6 @@ constexpr int in_b(int job)
 }
 constexpr int kLdsBytes = in_b(kJobs);
 static_assert(kLdsBytes <= 160 * 1024, "aq LDS layout");
-static_assert(kFlagB % 16 == 0 && kSlotB0 % 16 == 0 && kBigSlot % 16 == 0 && kSmallSlot % 16 == 0, "aq LDS alignment");
+static_assert(kFlagB % 16 == 0 && kSlotB0 % 16 == 0 && kSubSlot % 16 == 0 && kBigSlot % 16 == 0 && kSmallSlot % 16 == 0, "aq LDS alignment");
 } // namespace aq
 } // namespace namhip

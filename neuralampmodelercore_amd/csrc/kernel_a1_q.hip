@@ -35,6 +35,40 @@ using aq_i4 = __attribute__((ext_vector_type(4))) int;
 __device__ mf::f4 aq_sb_load4(aq_i4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
 __device__ void aq_sb_store4(mf::f4 v, aq_i4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.store.v4f32");
 
+// The activations with every fused multiply-add spelled out and contraction off: the compiler's own choice of what to fuse
+// differs between instantiations of one kernel (it depends on the code around the expression), and a session must render
+// bit for bit what a plain launch renders (tests/test_gpu_breadth.py: test_pipelined_kernel_against_the_four_wave_kernel).
+// Fasttanh: NAM/activations.h:91-98, same operation order as device_common.h: fast_tanh_hw; Tanh: 1 - 2 / (exp(2 x) + 1).
+#pragma clang fp contract(off)
+template <int ACT_T>
+__device__ __forceinline__ mf::f4 aq_act4(const mf::f4& v)
+{
+  mf::f4 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+  {
+    const float x = v[i];
+    if constexpr (ACT_T == ACT_FASTTANH)
+    {
+      const float ax = __builtin_fabsf(x);
+      const float x2 = x * x;
+      const float t1 = __builtin_fmaf(0.821226666969744f, ax, 0.893229853513558f);
+      const float t2 = __builtin_fmaf(2.45550750702956f, ax, 2.45550750702956f);
+      const float num = x * __builtin_fmaf(t1, x2, t2);
+      const float w = __builtin_fmaf(0.814642734961073f, x * ax, x);
+      const float den = __builtin_fmaf(2.44506634652299f + x2, __builtin_fabsf(w), 2.44506634652299f);
+      r[i] = num * __builtin_amdgcn_rcpf(den);
+    }
+    else
+    {
+      static_assert(ACT_T == ACT_TANH, "nam_a1_q_kernel is compiled for Fasttanh and Tanh");
+      const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+      r[i] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    }
+  }
+  return r;
+}
+
 namespace aq
 {
 constexpr int kNoRow = 1 << 26; // a ring row index no descriptor holds: the access is dropped / returns 0
@@ -56,9 +90,15 @@ constexpr int max_far_small()
 }
 } // namespace aq
 
-template <int ACT_T, bool WT, bool PERSIST>
+// DBG: the profiling instantiation (A1Args::dbg, nam_hip_batch_debug_timeline): workgroup 0's stage s writes row s of the
+// buffer — shader-clock stamps at kernel entry, behind the prologue's barrier, at its first and last hand-over, behind its
+// write-back; the cycles it spent waiting for input and for its output slot; the buffers it processed.
+template <int ACT_T, bool WT, bool PERSIST, bool DBG = false>
 __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __restrict__ blob, const A1Args a)
 {
+  long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (DBG)
+    dbg_t[0] = clock64();
   using namespace mf;
   using il::kOob;
   using i4 = aq_i4;
@@ -85,8 +125,6 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   const float* in = a.in ? a.in + (size_t)stream * a.io_stride : nullptr;
   float* out = a.out ? a.out + (size_t)stream * a.io_stride : nullptr;
   const float head_scale = a.head_scale;
-  const float act_p0 = a.act_p0;
-  const int act = a.act; // (only read by the run-time-dispatch instantiation)
   const int io_bytes = PERSIST ? 0x7ffffff0 : a.n_frames * 4;
   const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(in ? in : st), 0, in ? io_bytes : 0, 0x00020000);
   const auto rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out ? out : st), 0, out ? io_bytes : 0, 0x00020000);
@@ -138,13 +176,36 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   // ---- single-writer words in LDS (kernel_a1_p4.hip): [16 + 2 b] buffers handed over across boundary b, [16 + 2 b + 1]
   // buffers whose LDS reads the consumer has issued; [48], [49] stage 0's first-command decision ----
   const unsigned flag_b = (unsigned)aq::kFlagB;
-  auto wait_word = [&](unsigned byte_addr, int want) { // until the word has reached `want`
-    int tmp;
-    asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_sub_u32 %0, %0, %2\n\tv_cmp_gt_i32 vcc, 0, %0\n\t"
-                 "s_cbranch_vccz 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
-                 : "=&v"(tmp)
-                 : "v"(byte_addr), "v"(want)
-                 : "vcc");
+  auto wait_word = [&](unsigned byte_addr, int want) { // until the word has reached `want` (wave-uniform; wrap-safe)
+    // one vector instruction per look (the matrix / vector issue port is what this kernel runs out of): the word goes to the
+    // scalar unit, which does the comparison
+    int tmp, stmp;
+    want = uni(want);
+    asm volatile("1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_sub_i32 %1, %1, %3\n\t"
+                 "s_cmp_lt_i32 %1, 0\n\ts_cbranch_scc0 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 : "=&v"(tmp), "=&s"(stmp)
+                 : "v"(byte_addr), "s"(want)
+                 : "scc");
+  };
+  auto wait_in = [&](unsigned byte_addr, int want) {
+    if constexpr (DBG)
+    {
+      const long long t0 = clock64();
+      wait_word(byte_addr, want);
+      dbg_t[5] += clock64() - t0;
+    }
+    else
+      wait_word(byte_addr, want);
+  };
+  auto wait_out = [&](unsigned byte_addr, int want) {
+    if constexpr (DBG)
+    {
+      const long long t0 = clock64();
+      wait_word(byte_addr, want);
+      dbg_t[6] += clock64() - t0;
+    }
+    else
+      wait_word(byte_addr, want);
   };
   auto set_word = [&](unsigned byte_addr, int v) {
     asm volatile("" ::: "memory");
@@ -156,30 +217,44 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   auto cons_b = [&](int b) { return flag_b + (unsigned)(16 + 2 * b + 1) * 4u; };
 
   // a resident ring: stream state <-> LDS planes. 16-channel rings: lane (g, n) moves the quad g of row r0 + n; 8-channel
-  // rings: lane (h = lane & 1, r = lane >> 1) the quad h of row r0 + r
-  auto ring_to_lds = [&](int R, int ring_off_f, unsigned lds_b, unsigned plane_b, bool wide) {
-    const int per = wide ? 16 : 32;
+  // rings: lane (h = lane & 1, r = lane >> 1) the quad h of row r0 + r. Every request of a ring is in flight before the
+  // first row is stored (one memory round trip per ring, not one per sixteen rows: a launch of a few buffers pays for it)
+  auto ring_to_lds = [&](auto r_tag, int ring_off_f, unsigned lds_b, unsigned plane_b, auto wide_tag) {
+    constexpr int R = decltype(r_tag)::value;
+    constexpr bool wide = decltype(wide_tag)::value;
+    constexpr int per = wide ? 16 : 32, NI = (R + per - 1) / per;
     const int rl = wide ? n : (lane >> 1);
     const unsigned pl = wide ? (unsigned)g : (unsigned)(lane & 1);
-#pragma unroll 2
-    for (int r0 = 0; r0 < R; r0 += per)
+    f4 t[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
     {
-      const int row = r0 + rl;
-      const f4 v = aq_sb_load4(wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
+      const int row = i * per + rl;
+      t[i] = aq_sb_load4(wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+    {
+      const int row = i * per + rl;
       if (row < R)
-        lds_st4(lds, lds_b + pl * plane_b + (unsigned)row * 16u, v);
+        lds_st4(lds, lds_b + pl * plane_b + (unsigned)row * 16u, t[i]);
     }
   };
-  auto lds_to_ring = [&](int R, int ring_off_f, unsigned lds_b, unsigned plane_b, bool wide) {
-    const int per = wide ? 16 : 32;
+  auto lds_to_ring = [&](auto r_tag, int ring_off_f, unsigned lds_b, unsigned plane_b, auto wide_tag) {
+    constexpr int R = decltype(r_tag)::value;
+    constexpr bool wide = decltype(wide_tag)::value;
+    constexpr int per = wide ? 16 : 32, NI = (R + per - 1) / per;
     const int rl = wide ? n : (lane >> 1);
     const unsigned pl = wide ? (unsigned)g : (unsigned)(lane & 1);
-#pragma unroll 2
-    for (int r0 = 0; r0 < R; r0 += per)
+    f4 t[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+      t[i] = lds_ld4(lds, lds_b + pl * plane_b + (unsigned)min(i * per + rl, R - 1) * 16u);
+#pragma unroll
+    for (int i = 0; i < NI; i++)
     {
-      const int row = r0 + rl;
-      const f4 v = lds_ld4(lds, lds_b + pl * plane_b + (unsigned)min(row, R - 1) * 16u);
-      aq_sb_store4(v, wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
+      const int row = i * per + rl;
+      aq_sb_store4(t[i], wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
     }
   };
 
@@ -248,7 +323,10 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   };
 
   // ==============================================================================================
-  // BIG stages (array 0): jobs J0 .. J0 + NJS - 1 are layers of 16 channels
+  // BIG stages (array 0): jobs J0 .. J0 + NJS - 1 are layers of 16 channels. A buffer flows through them as FOUR SUB-BLOCKS
+  // of 16 frames — lane (g, n) holds channels 4 g .. 4 g + 3 of frame 16 i + n of sub-block i —, each handed to the next stage
+  // as soon as it is done: the first buffer of a launch (and every buffer of a lone caller) is in four big stages at once
+  // instead of one, the stage bodies are a quarter of the code, and the words "produced" / "consumed" count sub-blocks.
   // ==============================================================================================
   auto run_big = [&](auto s_tag) {
     constexpr int SS = decltype(s_tag)::value;
@@ -256,6 +334,10 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     constexpr bool FIRST = SS == 0;
     constexpr int QIN = SS - 1, QOUT = SS;
     constexpr int NFAR = aq::far_jobs_before(SS, JN);
+    // how many sub-blocks the slot (and a non-resident input area) holds: two into a big stage, the whole buffer into the
+    // transition, which takes it at once
+    constexpr int DIN = 2, DOUT = JN == aq::kJobT ? 4 : 2;
+    static_assert(aq::is_big(JN) || JN == aq::kJobT, "aq: array 0's last stage hands over to the transition");
     // ---- this stage's weights: registers for the whole launch. Tile q of job j (plan.cpp: build_a1_ws, FULL layout):
     // lane (g, i) holds W[out = i][in = 4 g + s], s = 0 .. 3 — the A operand of k-step s ----
     f4 W[NJS][4];
@@ -283,39 +365,41 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       [&](auto u_tag) {
         constexpr int TJ = J0 + decltype(u_tag)::value;
         if constexpr (aq::res(TJ))
-          ring_to_lds(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), true);
+          ring_to_lds(std::integral_constant<int, aq::ring_len(TJ)>{}, aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), std::true_type{});
       },
       std::make_integer_sequence<int, NJS>{});
-    // HBM rings: the far taps' rows of the first buffer
-    f4 far[NFAR > 0 ? NFAR : 1][2][4];
-    auto fetch_far = [&](auto tj_tag, int wpj) { // rows (wpj + 16 F + n - L) mod R of ring TJ, L = 2 d, d
+    // HBM rings: the far taps' rows, requested ONE SUB-BLOCK ahead (every one of them is at least two buffers old)
+    f4 far[NFAR > 0 ? NFAR : 1][2];
+    auto fetch_far = [&](auto tj_tag, int sb) { // rows (sb + n - L) mod R of ring TJ, L = 2 d, d; sb = position of the sub-block's first frame
       constexpr int TJ = decltype(tj_tag)::value;
       constexpr int R = aq::ring_len(TJ), D = aq::dil(TJ), FI = aq::far_jobs_before(SS, TJ);
 #pragma unroll
       for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-        {
-          const int sb = wrap_s(wpj - (2 - j) * D, R);
-          far[FI][j][F] = aq_sb_load4(rs16, (int)wrap_row(sb, (unsigned)(16 * F + n), R), (int)g16, aq::ring_off(TJ) * 4, 0);
-        }
+        far[FI][j] = aq_sb_load4(rs16, (int)wrap_row(wrap_s(sb - (2 - j) * D, R), (unsigned)n, R), (int)g16, aq::ring_off(TJ) * 4, 0);
     };
-    // (an HBM-ring job that is not the stage's first asks for its rows inside the job in front of it: the registers are then
-    // not live while that job's taps are)
-    if constexpr (!aq::res(J0))
-      fetch_far(std::integral_constant<int, J0>{}, wp[0]);
+    il::for_each_index(
+      [&](auto u_tag) {
+        constexpr int TJ = J0 + decltype(u_tag)::value;
+        if constexpr (!aq::res(TJ))
+          fetch_far(std::integral_constant<int, TJ>{}, wp[TJ - J0]);
+      },
+      std::make_integer_sequence<int, NJS>{});
     float inp = 0.0f; // stage 0: the next buffer's input sample of frame `lane`
     if constexpr (FIRST)
       inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, frame * 4, uni((int)boff0), kInAux));
     lds_barrier(); // weights, constants, rings and flags are in place
+    if constexpr (DBG)
+      dbg_t[1] = clock64();
 
-    f4 xs[4], hd[4];
-    float cnd[4];
+    f4 xs, hd;
+    float cnd = 0.0f;
     unsigned long long spec_cmd = 0; // PERSIST, stage 0: the early look at the next command ...
     float inp_spec = 0.0f; // ... and the input sample requested on a hit
-    int k = 0;
+    int k = 0; // buffers finished by this stage
+    int m = 0; // sub-blocks finished by this stage (4 k + i, modulo 2^32: the words are compared through differences)
+    int i = 0; // sub-block of the buffer
 
-    // One layer: z = act(conv(x) + mixin(cond)); head += z; x += layer1x1(z)   (model.cpp:183-393)
+    // One layer on one sub-block: z = act(conv(x) + mixin(cond)); head += z; x += layer1x1(z)   (model.cpp:183-393)
     auto job = [&](auto j_tag) {
       constexpr int JI = decltype(j_tag)::value;
       constexpr int U = JI - J0;
@@ -325,103 +409,79 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       constexpr int FI = aq::far_jobs_before(SS, JI);
       __builtin_amdgcn_sched_barrier(0);
       const int wpj = wp[U];
-      // (a) the job's input rows
+      int sb = wpj + 16 * i; // ring position of the sub-block's first frame (scalar unit)
+      sb -= sb >= R ? R : 0;
+      // (a) the sub-block's input rows
+      const unsigned row_cur = (RES || !TAKES) ? wrap_row(sb, (unsigned)n, R) : (unsigned)(16 * (m & (DIN - 1)) + n);
       if constexpr (TAKES)
-      {
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-        {
-          const unsigned row = RES ? wrap_row(wpj, (unsigned)(16 * F + n), R) : (unsigned)(16 * F + n);
-          xs[F] = lds_ld4(lds, gb[U] + row * 16u);
-        }
-      }
+        xs = lds_ld4(lds, gb[U] + row_cur * 16u);
       else if constexpr (RES)
       {
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-          lds_st4(lds, gb[U] + wrap_row(wpj, (unsigned)(16 * F + n), R) * 16u, xs[F]);
-        asm volatile("" ::: "memory"); // the taps read OTHER lanes' rows: not above these stores
+        lds_st4(lds, gb[U] + row_cur * 16u, xs);
+        asm volatile("" ::: "memory"); // the taps read OTHER lanes' rows: not above this store
       }
       if constexpr (!RES)
-      {
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-        {
-          const unsigned row = wrap_row(wpj, (unsigned)(16 * F + n), R);
-          aq_sb_store4(xs[F], rs16, 16 * F + n < nvalid ? (int)row : aq::kNoRow, (int)g16, aq::ring_off(JI) * 4, kAppAux);
-        }
-      }
-      int wpn = wpj + nvalid; // the ring's position for the next buffer (scalar unit)
-      wpn -= wpn >= R ? R : 0;
-      // (b) the taps' rows: LDS ring, or the registers requested a buffer ago
-      f4 bt[2][4];
+        aq_sb_store4(xs, rs16, 16 * i + n < nvalid ? (int)wrap_row(sb, (unsigned)n, R) : aq::kNoRow, (int)g16, aq::ring_off(JI) * 4, kAppAux);
+      // (b) the taps' rows: LDS ring, or the registers requested a sub-block ago
+      f4 bt[2];
 #pragma unroll
       for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-        {
-          if constexpr (RES)
-            bt[j][F] = lds_ld4(lds, gb[U] + wrap_row(wrap_s(wpj - (2 - j) * D, R), (unsigned)(16 * F + n), R) * 16u);
-          else
-            bt[j][F] = far[FI][j][F];
-        }
+      {
+        if constexpr (RES)
+          bt[j] = lds_ld4(lds, gb[U] + wrap_row(wrap_s(sb - (2 - j) * D, R), (unsigned)n, R) * 16u);
+        else
+          bt[j] = far[FI][j];
+      }
       if constexpr (TAKES)
-        set_word(cons_b(QIN), k + 1); // every LDS read of what the previous stage may overwrite next is issued
-      // persistent session, stage 0: look at the next ring slot in job 0 and, when the command is already there, request the
-      // next buffer's input sample from it in job 1 (kernel_kq.hip)
+        set_word(cons_b(QIN), m + 1); // every LDS read of what the previous stage may overwrite next is issued
+      // persistent session, stage 0: look at the next ring slot in the buffer's first sub-block and, when the command is
+      // already there, request the next buffer's input sample from it in the third (kernel_kq.hip)
       if constexpr (PERSIST && JI == 0)
       {
-        const unsigned long long v = ring_load(na + 1);
-        spec_cmd = ((unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)v);
+        if (i == 0)
+        {
+          const unsigned long long v = ring_load(na + 1);
+          spec_cmd = ((unsigned long long)(unsigned)uni((int)(unsigned)(v >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)v);
+        }
+        if (i == 2)
+        {
+          const bool hit = (unsigned)(spec_cmd >> 32) == na + 2;
+          const int soff = uni(hit ? (int)((unsigned)spec_cmd * 4u) : 0);
+          inp_spec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, hit ? frame * 4 : (int)kOob, soff, kInAux));
+        }
       }
-      if constexpr (PERSIST && JI == 1)
-      {
-        const bool hit = (unsigned)(spec_cmd >> 32) == na + 2;
-        const int soff = uni(hit ? (int)((unsigned)spec_cmd * 4u) : 0);
-        inp_spec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, hit ? frame * 4 : (int)kOob, soff, kInAux));
-      }
-      // (c) conv + mixin: one chain per frame group, seeded with bias + mixin * input
+      // (c) conv + mixin: two chains (a lone wave's dependent MFMA waits 40 cycles, issue is 32), the first seeded with
+      // bias + mixin * input; taps oldest first
       constexpr unsigned cb = (unsigned)(aq::kWB + (aq::kBigConsts + JI * 64) * 4);
       const f4 bv = lds_ld4(lds, cb + g16), mv = lds_ld4(lds, cb + 64u + g16);
-      f4 acc[4];
+      f4 acc = __builtin_elementwise_fma(mv, f4{cnd, cnd, cnd, cnd}, bv), acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int F = 0; F < 4; F++)
-        acc[F] = __builtin_elementwise_fma(mv, f4{cnd[F], cnd[F], cnd[F], cnd[F]}, bv);
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-          for (int F = 0; F < 4; F++)
-            acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][j][s], bt[j][F][s], acc[F], 0, 0, 0);
-      // the far taps' rows of the NEXT buffer, into the registers just consumed (the stage's first job); the rows of the
-      // stage's next job, an HBM ring's, for THIS buffer (all of them at least two buffers old)
-      if constexpr (!RES && U == 0)
-        fetch_far(j_tag, wpn);
-#pragma unroll
-      for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-          acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][s], xs[F][s], acc[F], 0, 0, 0);
-      if constexpr (U + 1 < NJS && !aq::res(JI + 1 < aq::kJobs ? JI + 1 : 0))
-        fetch_far(std::integral_constant<int, (U + 1 < NJS ? JI + 1 : JI)>{}, wp[U + 1 < NJS ? U + 1 : U]);
+      for (int s_ = 0; s_ < 4; s_++)
+      {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][0][s_], bt[0][s_], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][1][s_], bt[1][s_], acc2, 0, 0, 0);
+      }
+      // the far taps' rows of the NEXT sub-block, into the registers just consumed
+      if constexpr (!RES)
+      {
+        int wpn_ = wpj + nvalid;
+        wpn_ -= wpn_ >= R ? R : 0;
+        int nsb = sb + 16;
+        nsb -= nsb >= R ? R : 0;
+        fetch_far(j_tag, i == 3 ? wpn_ : nsb);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][0], xs[0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][1], xs[1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][2], xs[2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][3], xs[3], acc2, 0, 0, 0);
       // (d) activation, head accumulator, layer 1x1 + residual
       const f4 b1v = lds_ld4(lds, cb + 128u + g16);
+      const f4 z = aq_act4<ACT_T>(acc + acc2);
+      hd += z;
+      xs += b1v;
 #pragma unroll
-      for (int F = 0; F < 4; F++)
-      {
-        const f4 z = act4<ACT_T>(act, acc[F], act_p0);
-        hd[F] += z;
-        acc[F] = z;
-        xs[F] += b1v;
-        __builtin_amdgcn_sched_barrier(0); // one frame group's activation at a time: sixteen interleaved chains spill
-      }
-#pragma unroll
-      for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-          xs[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][3][s], acc[F][s], xs[F], 0, 0, 0);
-      wp[U] = wpn;
+      for (int s_ = 0; s_ < 4; s_++)
+        xs = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][3][s_], z[s_], xs, 0, 0, 0);
     };
 
     boff = boff0;
@@ -431,6 +491,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     {
       bool exit_tok = false;
       float cond = 0.0f;
+      constexpr unsigned islot = (unsigned)aq::slot_b(QIN < 0 ? 0 : QIN), oslot = (unsigned)aq::slot_b(QOUT);
       if constexpr (FIRST)
       {
         exit_tok = !have;
@@ -439,51 +500,22 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       }
       else
       {
-        // the token, the head accumulator and the input sample of buffer k (its rows: job 0)
-        constexpr unsigned slot = (unsigned)aq::slot_b(QIN < 0 ? 0 : QIN);
-        wait_word(prod_b(QIN), k + 1);
+        // the token of buffer k travels with its first sub-block
+        wait_in(prod_b(QIN), m + 1);
         asm volatile("" ::: "memory");
-        const i4 tok = *reinterpret_cast<const i4*>(lds + slot + 4352u);
-#pragma unroll
-        for (int F = 0; F < 4; F++)
-        {
-          hd[F] = lds_ld4(lds, slot + g16 * 64u + (unsigned)(16 * F + n) * 16u);
-          cnd[F] = *reinterpret_cast<const float*>(lds + slot + 4096u + (unsigned)(16 * F + n) * 4u);
-        }
+        const i4 tok = *reinterpret_cast<const i4*>(lds + islot + (unsigned)(DIN * 1024 + DIN * 64));
         boff = (unsigned)uni(tok[0]);
         nvalid = uni(tok[1]);
         exit_tok = uni(tok[2]) != 0;
         more = PERSIST || uni(tok[3]) != 0;
       }
-      // hand-over to the next stage: the rows into its first ring (or 64-row area), the rest into the slot
-      auto hand_over = [&](bool is_exit) {
-        constexpr unsigned slot = (unsigned)aq::slot_b(QOUT);
-        wait_word(cons_b(QOUT), k); // the consumer has issued every LDS read of buffer k - 1
-        asm volatile("" ::: "memory");
-        if (!is_exit)
-        {
-#pragma unroll
-          for (int F = 0; F < 4; F++)
-          {
-            const unsigned row = aq::res(JN) ? wrap_row(wpo, (unsigned)(16 * F + n), aq::ring_len(JN)) : (unsigned)(16 * F + n);
-            lds_st4(lds, gbn + row * 16u, xs[F]);
-            lds_st4(lds, slot + g16 * 64u + (unsigned)(16 * F + n) * 16u, hd[F]);
-            if (g == 0)
-              *reinterpret_cast<float*>(lds + slot + 4096u + (unsigned)(16 * F + n) * 4u) = cnd[F];
-          }
-        }
-        if (lane == 0)
-          *reinterpret_cast<i4*>(lds + slot + 4352u) = i4{(int)boff, nvalid, is_exit ? 1 : 0, more ? 1 : 0};
-        set_word(prod_b(QOUT), k + 1);
-        if constexpr (aq::res(JN))
-        {
-          wpo += is_exit ? 0 : nvalid;
-          wpo -= wpo >= aq::ring_len(JN) ? aq::ring_len(JN) : 0;
-        }
-      };
       if (exit_tok)
       {
-        hand_over(true);
+        wait_out(cons_b(QOUT), m - (DOUT - 1));
+        asm volatile("" ::: "memory");
+        if (lane == 0)
+          *reinterpret_cast<i4*>(lds + oslot + (unsigned)(DOUT * 1024 + DOUT * 64)) = i4{(int)boff, nvalid, 1, 0};
+        set_word(prod_b(QOUT), m + 1);
         break;
       }
       if constexpr (FIRST)
@@ -491,19 +523,70 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         cond = inp; // this buffer's input sample (requested a buffer ago)
         if constexpr (!PERSIST) // next block's (offset beyond the launch's frames -> 0)
           inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, frame * 4, uni((k + 1) * (kBlock * 4)), 0));
-        // array 0's rechannel (1 -> 16, model.cpp:488-490): x = column * input
-        const f4 rech = lds_ld4(lds, (unsigned)(aq::kWB + aq::kBigConsts * 4) + 192u + g16);
-#pragma unroll
-        for (int F = 0; F < 4; F++)
+      }
+#pragma unroll 1
+      for (i = 0; i < 4; i++)
+      {
+        if constexpr (FIRST)
         {
-          cnd[F] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 * F + n) * 4, __builtin_bit_cast(int, cond)));
-          xs[F] = rech * cnd[F];
-          hd[F] = f4{0.f, 0.f, 0.f, 0.f};
+          // array 0's rechannel (1 -> 16, model.cpp:488-490): x = column * input
+          const f4 rech = lds_ld4(lds, (unsigned)(aq::kWB + aq::kBigConsts * 4) + 192u + g16);
+          cnd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 * i + n) * 4, __builtin_bit_cast(int, cond)));
+          xs = rech * cnd;
+          hd = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        else
+        {
+          if (i > 0)
+          {
+            wait_in(prod_b(QIN), m + 1);
+            asm volatile("" ::: "memory");
+          }
+          const unsigned qr = (unsigned)(16 * (m & (DIN - 1)) + n); // the sub-block's rows in the slot
+          hd = lds_ld4(lds, islot + g16 * (unsigned)(DIN * 16) + qr * 16u);
+          cnd = *reinterpret_cast<const float*>(lds + islot + (unsigned)(DIN * 1024) + qr * 4u);
+        }
+        il::for_each_index([&](auto u_tag) { job(std::integral_constant<int, J0 + decltype(u_tag)::value>{}); },
+                           std::make_integer_sequence<int, NJS>{});
+        // hand-over of the sub-block: its rows into the next stage's first ring (or input area), the rest into the slot; the
+        // consumer has issued every LDS read of the sub-block DOUT back (whose slot rows — and, four back, ring rows — these
+        // overwrite)
+        wait_out(cons_b(QOUT), m - (DOUT - 1));
+        asm volatile("" ::: "memory");
+        {
+          int so = wpo + 16 * i;
+          so -= (aq::res(JN) && so >= aq::ring_len(JN)) ? aq::ring_len(JN) : 0;
+          const unsigned qr = (unsigned)(16 * (m & (DOUT - 1)) + n);
+          const unsigned row = aq::res(JN) ? wrap_row(so, (unsigned)n, aq::ring_len(JN)) : qr;
+          lds_st4(lds, gbn + row * 16u, xs);
+          lds_st4(lds, oslot + g16 * (unsigned)(DOUT * 16) + qr * 16u, hd);
+          if (g == 0)
+            *reinterpret_cast<float*>(lds + oslot + (unsigned)(DOUT * 1024) + qr * 4u) = cnd;
+          if (i == 0 && lane == 0)
+            *reinterpret_cast<i4*>(lds + oslot + (unsigned)(DOUT * 1024 + DOUT * 64)) = i4{(int)boff, nvalid, 0, more ? 1 : 0};
+        }
+        set_word(prod_b(QOUT), m + 1);
+        m = (int)((unsigned)m + 1u);
+        if constexpr (DBG)
+        {
+          dbg_t[3] = clock64();
+          dbg_t[2] = dbg_t[2] ? dbg_t[2] : dbg_t[3];
+          dbg_t[7] = m;
         }
       }
-      il::for_each_index([&](auto u_tag) { job(std::integral_constant<int, J0 + decltype(u_tag)::value>{}); },
-                         std::make_integer_sequence<int, NJS>{});
-      hand_over(false);
+      // the rings move on by the buffer's frames (scalar unit)
+#pragma unroll
+      for (int u = 0; u < NJS; u++)
+      {
+        int np = wp[u] + nvalid;
+        np -= np >= aq::ring_len(J0 + u) ? aq::ring_len(J0 + u) : 0;
+        wp[u] = np;
+      }
+      if constexpr (aq::res(JN))
+      {
+        wpo += nvalid;
+        wpo -= wpo >= aq::ring_len(JN) ? aq::ring_len(JN) : 0;
+      }
       if constexpr (FIRST)
       {
         // the next buffer of this stage (kernel_kq.hip)
@@ -555,116 +638,38 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       [&](auto u_tag) {
         constexpr int TJ = J0 + decltype(u_tag)::value;
         if constexpr (aq::res(TJ))
-          lds_to_ring(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), true);
+          lds_to_ring(std::integral_constant<int, aq::ring_len(TJ)>{}, aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), std::true_type{});
       },
       std::make_integer_sequence<int, NJS>{});
     store_positions(aq::ring_id(J0), NJS, wp);
   };
 
   // ==============================================================================================
-  // the TRANSITION stage (job 10): array 1's rechannel and array 0's head rechannel, 16 -> 8 each, one lane per frame
-  // (model.cpp:476-490: array 1's head accumulator starts as array 0's head output; its layers run on rechannel(x))
-  // ==============================================================================================
-  auto run_t = [&](auto s_tag) {
-    constexpr int SS = decltype(s_tag)::value;
-    constexpr int QIN = SS - 1, QOUT = SS, JN = aq::kFirst[SS + 1];
-    static_assert(aq::kFirst[SS] == aq::kJobT && JN == aq::kJobM0 && aq::res(JN), "aq: the transition is a stage of its own");
-    int wpo = __builtin_amdgcn_readlane(wposv, aq::ring_id(JN));
-    lds_barrier();
-#pragma unroll 1
-    for (int k = 0;; k++)
-    {
-      constexpr unsigned slot = (unsigned)aq::slot_b(QIN), xin = (unsigned)aq::in_b(aq::kJobT);
-      wait_word(prod_b(QIN), k + 1);
-      asm volatile("" ::: "memory");
-      const i4 tok = *reinterpret_cast<const i4*>(lds + slot + 4352u);
-      const bool exit_tok = uni(tok[2]) != 0;
-      f4 x16[4], h16[4];
-#pragma unroll
-      for (int p = 0; p < 4; p++)
-      {
-        x16[p] = lds_ld4(lds, xin + (unsigned)p * 1024u + frame16);
-        h16[p] = lds_ld4(lds, slot + (unsigned)p * 1024u + frame16);
-      }
-      const float cond = *reinterpret_cast<const float*>(lds + slot + 4096u + (unsigned)lane * 4u);
-      set_word(cons_b(QIN), k + 1);
-      nvalid = uni(tok[1]);
-      constexpr unsigned oslot = (unsigned)aq::slot_b(QOUT);
-      if (exit_tok)
-      {
-        wait_word(cons_b(QOUT), k);
-        asm volatile("" ::: "memory");
-        if (lane == 0)
-          *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
-        set_word(prod_b(QOUT), k + 1);
-        break;
-      }
-      // x8 = Wr x16; h8 = bias + Wh h16: per output half one chain, input channels in order
-      constexpr unsigned wr = (unsigned)(aq::kWB + aq::kWrOff * 4), wh = (unsigned)(aq::kWB + aq::kWhOff * 4), tc = (unsigned)(aq::kWB + aq::kTConsts * 4);
-      f4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
-      f4 ha = lds_ld4(lds, tc), hb = lds_ld4(lds, tc + 16u);
-#pragma unroll
-      for (int p = 0; p < 4; p++)
-      {
-        const f4 w0 = lds_ld4(lds, wr + cls128 + (unsigned)p * 16u), w1 = lds_ld4(lds, wr + cls128 + 64u + (unsigned)p * 16u);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          xa = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[c], x16[p][c], xa, 0, 0, 0);
-          xb = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[c], x16[p][c], xb, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 4; p++)
-      {
-        const f4 w0 = lds_ld4(lds, wh + cls128 + (unsigned)p * 16u), w1 = lds_ld4(lds, wh + cls128 + 64u + (unsigned)p * 16u);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          ha = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[c], h16[p][c], ha, 0, 0, 0);
-          hb = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[c], h16[p][c], hb, 0, 0, 0);
-        }
-      }
-      wait_word(cons_b(QOUT), k);
-      asm volatile("" ::: "memory");
-      {
-        constexpr int RN = aq::ring_len(JN);
-        const unsigned row = wrap_row(wpo, (unsigned)frame, RN) * 16u;
-        lds_st4(lds, (unsigned)aq::in_b(JN) + row, xa);
-        lds_st4(lds, (unsigned)(aq::in_b(JN) + aq::plane_b(JN)) + row, xb);
-        lds_st4(lds, oslot + frame16, ha);
-        lds_st4(lds, oslot + 1024u + frame16, hb);
-        *reinterpret_cast<float*>(lds + oslot + 2048u + (unsigned)lane * 4u) = cond;
-        if (lane == 0)
-          *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
-        wpo += nvalid;
-        wpo -= wpo >= RN ? RN : 0;
-      }
-      set_word(prod_b(QOUT), k + 1);
-    }
-  };
-
-  // ==============================================================================================
-  // SMALL stages (array 1, 8 channels; the last one also the head): one lane per frame (kernel_kq.hip's job on rings)
+  // SMALL stages (array 1, 8 channels): one lane per frame, 64 frames at a time (kernel_kq.hip's job on rings). The first of
+  // them starts with the TRANSITION (job 10): array 1's rechannel and array 0's head rechannel, 16 -> 8 each (model.cpp:476-490:
+  // array 1's head accumulator starts as array 0's head output; its layers run on rechannel(x)); the last one ends with the
+  // head (job 21).
   // ==============================================================================================
   auto run_small = [&](auto s_tag) {
     constexpr int SS = decltype(s_tag)::value;
-    constexpr int J0 = aq::kFirst[SS], JE = aq::kFirst[SS + 1], LAST = SS == NST - 1;
-    constexpr int NL = (LAST ? JE - 1 : JE) - J0; // layers (the last stage's final job is the head)
-    constexpr int JN = LAST ? 0 : JE;
+    constexpr int J0 = aq::kFirst[SS], JE = aq::kFirst[SS + 1];
+    constexpr bool LAST = SS == NST - 1, HAS_T = J0 == aq::kJobT;
+    constexpr int JM0 = HAS_T ? J0 + 1 : J0; // the stage's first layer
+    constexpr int NL = (LAST ? JE - 1 : JE) - JM0; // layers (the last stage's final job is the head)
+    constexpr int JN = LAST ? JM0 : JE; // the next stage's first job (a small layer)
     constexpr int QIN = SS - 1, QOUT = SS;
-    constexpr int NFAR = aq::far_jobs_before(SS, J0 + NL);
-    static_assert(LAST || aq::res(JN), "aq: a small stage hands its rows to a resident ring");
+    constexpr int NFAR = aq::far_jobs_before(SS, JM0 + NL);
+    static_assert(NL >= 1 && (LAST || aq::is_small(JN)), "aq: small stages hold layers");
     int wp[NL];
 #pragma unroll
     for (int u = 0; u < NL; u++)
-      wp[u] = __builtin_amdgcn_readlane(wposv, aq::ring_id(J0 + u));
-    int wpo = LAST ? 0 : __builtin_amdgcn_readlane(wposv, aq::ring_id(JN));
+      wp[u] = __builtin_amdgcn_readlane(wposv, aq::ring_id(JM0 + u));
+    int wpo = (!LAST && aq::res(JN)) ? __builtin_amdgcn_readlane(wposv, aq::ring_id(JN)) : 0;
     il::for_each_index(
       [&](auto u_tag) {
-        constexpr int TJ = J0 + decltype(u_tag)::value;
+        constexpr int TJ = JM0 + decltype(u_tag)::value;
         if constexpr (aq::res(TJ))
-          ring_to_lds(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), false);
+          ring_to_lds(std::integral_constant<int, aq::ring_len(TJ)>{}, aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), std::false_type{});
       },
       std::make_integer_sequence<int, NL>{});
     struct Row
@@ -685,21 +690,23 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     };
     il::for_each_index(
       [&](auto u_tag) {
-        constexpr int TJ = J0 + decltype(u_tag)::value;
+        constexpr int TJ = JM0 + decltype(u_tag)::value;
         if constexpr (!aq::res(TJ))
-          fetch_far(std::integral_constant<int, TJ>{}, wp[TJ - J0]);
+          fetch_far(std::integral_constant<int, TJ>{}, wp[TJ - JM0]);
       },
       std::make_integer_sequence<int, NL>{});
     lds_barrier();
+    if constexpr (DBG)
+      dbg_t[1] = clock64();
 
     f4 x0, x1, head0, head1;
     float cond = 0.0f;
     int k = 0;
     auto job = [&](auto j_tag) {
       constexpr int JI = decltype(j_tag)::value;
-      constexpr int U = JI - J0, LI = JI - aq::kJobM0;
+      constexpr int U = JI - JM0, LI = JI - aq::kJobM0;
       constexpr int R = aq::ring_len(JI), D = aq::dil(JI);
-      constexpr bool RES = aq::res(JI), TAKES = U == 0;
+      constexpr bool RES = aq::res(JI), TAKES = U == 0 && !HAS_T; // the input rows come from the previous stage (LDS)
       constexpr int FI = aq::far_jobs_before(SS, JI);
       constexpr unsigned rb0 = (unsigned)aq::in_b(JI), rb1 = rb0 + (unsigned)aq::plane_b(JI);
       __builtin_amdgcn_sched_barrier(0);
@@ -707,8 +714,9 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       const unsigned row0 = wrap_row(wpj, (unsigned)frame, R);
       if constexpr (TAKES)
       {
-        x0 = lds_ld4(lds, rb0 + row0 * 16u);
-        x1 = lds_ld4(lds, rb1 + row0 * 16u);
+        const unsigned r_in = RES ? row0 * 16u : frame16; // (an HBM-ring layer takes its rows through a 64-row area)
+        x0 = lds_ld4(lds, rb0 + r_in);
+        x1 = lds_ld4(lds, rb1 + r_in);
       }
       else if constexpr (RES)
       {
@@ -770,7 +778,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         fetch_far(j_tag, wpn);
       tap(t0 + 512u, x0, x1, acc0, acc1);
       const f4 b1v0 = lds_ld4(lds, cb + 64u), b1v1 = lds_ld4(lds, cb + 80u);
-      const f4 z0 = act4<ACT_T>(act, acc0, act_p0), z1 = act4<ACT_T>(act, acc1, act_p0);
+      const f4 z0 = aq_act4<ACT_T>(acc0), z1 = aq_act4<ACT_T>(acc1);
       head0 += z0;
       head1 += z1;
       f4 y0 = x0 + b1v0, y1 = x1 + b1v1;
@@ -783,23 +791,77 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
 #pragma unroll 1
     for (;; k++)
     {
-      constexpr unsigned slot = (unsigned)aq::slot_b(QIN);
-      wait_word(prod_b(QIN), k + 1);
-      asm volatile("" ::: "memory");
-      const i4 tok = *reinterpret_cast<const i4*>(lds + slot + 2304u);
-      head0 = lds_ld4(lds, slot + frame16);
-      head1 = lds_ld4(lds, slot + 1024u + frame16);
-      cond = *reinterpret_cast<const float*>(lds + slot + 2048u + (unsigned)lane * 4u);
+      constexpr unsigned slot = (unsigned)aq::slot_b(QIN), oslot = (unsigned)aq::slot_b(LAST ? QIN : QOUT);
+      i4 tok;
+      bool exit_tok;
+      if constexpr (HAS_T)
+      {
+        // array 0's last stage hands over sub-blocks: the token comes with the first, the buffer is whole with the fourth
+        constexpr unsigned xin = (unsigned)aq::in_b(aq::kJobT);
+        const int m0 = (int)(4u * (unsigned)k);
+        wait_in(prod_b(QIN), m0 + 1);
+        asm volatile("" ::: "memory");
+        tok = *reinterpret_cast<const i4*>(lds + slot + 4352u);
+        exit_tok = uni(tok[2]) != 0;
+        if (!exit_tok)
+          wait_in(prod_b(QIN), m0 + 4);
+        asm volatile("" ::: "memory");
+        f4 x16[4], h16[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+        {
+          x16[p] = lds_ld4(lds, xin + (unsigned)p * 1024u + frame16);
+          h16[p] = lds_ld4(lds, slot + (unsigned)p * 1024u + frame16);
+        }
+        cond = *reinterpret_cast<const float*>(lds + slot + 4096u + (unsigned)lane * 4u);
+        set_word(cons_b(QIN), m0 + 4);
+        // x8 = Wr x16; h8 = bias + Wh h16: per output half one chain, input channels in order
+        constexpr unsigned wr = (unsigned)(aq::kWB + aq::kWrOff * 4), wh = (unsigned)(aq::kWB + aq::kWhOff * 4), tc = (unsigned)(aq::kWB + aq::kTConsts * 4);
+        x0 = x1 = f4{0.f, 0.f, 0.f, 0.f};
+        head0 = lds_ld4(lds, tc);
+        head1 = lds_ld4(lds, tc + 16u);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+        {
+          const f4 w0 = lds_ld4(lds, wr + cls128 + (unsigned)p * 16u), w1 = lds_ld4(lds, wr + cls128 + 64u + (unsigned)p * 16u);
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+          {
+            x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[c], x16[p][c], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[c], x16[p][c], x1, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+        {
+          const f4 w0 = lds_ld4(lds, wh + cls128 + (unsigned)p * 16u), w1 = lds_ld4(lds, wh + cls128 + 64u + (unsigned)p * 16u);
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+          {
+            head0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[c], h16[p][c], head0, 0, 0, 0);
+            head1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[c], h16[p][c], head1, 0, 0, 0);
+          }
+        }
+      }
+      else
+      {
+        wait_in(prod_b(QIN), k + 1);
+        asm volatile("" ::: "memory");
+        tok = *reinterpret_cast<const i4*>(lds + slot + 2304u);
+        head0 = lds_ld4(lds, slot + frame16);
+        head1 = lds_ld4(lds, slot + 1024u + frame16);
+        cond = *reinterpret_cast<const float*>(lds + slot + 2048u + (unsigned)lane * 4u);
+        exit_tok = uni(tok[2]) != 0;
+      }
       boff = (unsigned)uni(tok[0]);
       nvalid = uni(tok[1]);
-      const bool exit_tok = uni(tok[2]) != 0;
       if (exit_tok)
       {
-        set_word(cons_b(QIN), k + 1);
+        if constexpr (!HAS_T)
+          set_word(cons_b(QIN), k + 1);
         if constexpr (!LAST)
         {
-          constexpr unsigned oslot = (unsigned)aq::slot_b(LAST ? 0 : QOUT);
-          wait_word(cons_b(QOUT), k);
+          wait_out(cons_b(QOUT), k);
           asm volatile("" ::: "memory");
           if (lane == 0)
             *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
@@ -807,15 +869,20 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         }
         break;
       }
-      il::for_each_index([&](auto u_tag) { job(std::integral_constant<int, J0 + decltype(u_tag)::value>{}); },
+      il::for_each_index([&](auto u_tag) { job(std::integral_constant<int, JM0 + decltype(u_tag)::value>{}); },
                          std::make_integer_sequence<int, NL>{});
+      if constexpr (DBG)
+      {
+        dbg_t[3] = clock64();
+        dbg_t[2] = dbg_t[2] ? dbg_t[2] : dbg_t[3];
+        dbg_t[7] = k + 1;
+      }
       if constexpr (!LAST)
       {
-        constexpr unsigned oslot = (unsigned)aq::slot_b(LAST ? 0 : QOUT);
         constexpr int RN = aq::ring_len(JN);
-        wait_word(cons_b(QOUT), k);
+        wait_out(cons_b(QOUT), k);
         asm volatile("" ::: "memory");
-        const unsigned row = wrap_row(wpo, (unsigned)frame, RN) * 16u;
+        const unsigned row = aq::res(JN) ? wrap_row(wpo, (unsigned)frame, RN) * 16u : frame16;
         lds_st4(lds, (unsigned)aq::in_b(JN) + row, x0);
         lds_st4(lds, (unsigned)(aq::in_b(JN) + aq::plane_b(JN)) + row, x1);
         lds_st4(lds, oslot + frame16, head0);
@@ -823,8 +890,11 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         *reinterpret_cast<float*>(lds + oslot + 2048u + (unsigned)lane * 4u) = cond;
         if (lane == 0)
           *reinterpret_cast<i4*>(lds + oslot + 2304u) = tok;
-        wpo += nvalid;
-        wpo -= wpo >= RN ? RN : 0;
+        if constexpr (aq::res(JN))
+        {
+          wpo += nvalid;
+          wpo -= wpo >= RN ? RN : 0;
+        }
         set_word(prod_b(QOUT), k + 1);
       }
       else
@@ -853,12 +923,12 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     asm volatile("" ::: "memory");
     il::for_each_index(
       [&](auto u_tag) {
-        constexpr int TJ = J0 + decltype(u_tag)::value;
+        constexpr int TJ = JM0 + decltype(u_tag)::value;
         if constexpr (aq::res(TJ))
-          lds_to_ring(aq::ring_len(TJ), aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), false);
+          lds_to_ring(std::integral_constant<int, aq::ring_len(TJ)>{}, aq::ring_off(TJ), (unsigned)aq::in_b(TJ), (unsigned)aq::plane_b(TJ), std::false_type{});
       },
       std::make_integer_sequence<int, NL>{});
-    store_positions(aq::ring_id(J0), NL, wp);
+    store_positions(aq::ring_id(JM0), NL, wp);
   };
 
   il::for_each_index(
@@ -868,14 +938,24 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       {
         if constexpr (aq::is_big(aq::kFirst[SS]))
           run_big(s_tag);
-        else if constexpr (aq::kFirst[SS] == aq::kJobT)
-          run_t(s_tag);
         else
           run_small(s_tag);
       }
     },
     std::make_integer_sequence<int, NST>{});
 
+  if constexpr (DBG)
+  {
+    dbg_t[4] = clock64();
+    if (a.dbg && blockIdx.x == 0 && lane < 8)
+    {
+      long long v = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        v = lane == i ? dbg_t[i] : v;
+      a.dbg[S * 8 + lane] = v;
+    }
+  }
   if constexpr (PERSIST)
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -926,6 +1006,15 @@ bool a1_q_takes(int act)
 }
 hipError_t launch_a1_q(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
+  if (a.dbg && !a.p_ring) // developer tool (nam_hip_batch_debug_timeline): the stamped instantiation
+  {
+    static DynamicLdsLimit lds_limit;
+    const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_q_kernel<ACT_FASTTANH, false, false, true>), aq::kLdsBytes);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL((nam_a1_q_kernel<ACT_FASTTANH, false, false, true>), dim3(n_blocks), dim3(aq::kNst * 64), aq::kLdsBytes, stream, a.blob, a);
+    return hipGetLastError();
+  }
   if (act == ACT_FASTTANH)
     return launch_q_act<ACT_FASTTANH>(a, n_blocks, stream);
   if (act == ACT_TANH)

@@ -1245,9 +1245,12 @@ int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long
   if (ps.active)
   {
     const long off_in = d_in - ps.in_base, off_out = d_out - ps.out_base;
-    if (stride != ps.stride || off_in != off_out || off_in < 0 || off_in > 0x3fffffffl)
+    // a different window: the session ends, the next one starts here. So does a session whose sequence numbers have reached
+    // the rebase mark: one that never ends by itself (the C++ adapter's default: a session per Reset, flushes only) would
+    // otherwise run its count into bit 31, the "left" flag of the completion words; persist_start renumbers from 0.
+    if (stride != ps.stride || off_in != off_out || off_in < 0 || off_in > 0x3fffffffl || ps.seq >= ps.rebase_at)
     {
-      const int rc = persist_stop(b); // a different window: the session ends, the next one starts here
+      const int rc = persist_stop(b);
       if (rc != NAM_HIP_OK)
         return rc;
     }
@@ -1462,6 +1465,12 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
                                                                        : build_plan(sp);
         if (!again.wr.ok)
           again.wr.why += " [" + why + "]";
+        // loud: the model still runs, but off its compiled shapes (run-time-flag instantiations, or another kernel: 6 - 9 x
+        // slower, profiles/r03/defit_table.txt). nam_hip_model_info says so (has_a1_kernel bit 5), the description too.
+        again.wr.jit_failed = why.empty() ? "unknown reason" : why;
+        std::fprintf(stderr, "libnam_hip: %s: nam_wn_reg_kernel could not be compiled for this model's layer shapes (%s); it runs on %s\n",
+                     sp.architecture_name.c_str(), again.wr.jit_failed.c_str(),
+                     again.wr.ok ? "the run-time-flag instantiations" : "another kernel");
         p = std::move(again);
       }
     }
@@ -1697,7 +1706,8 @@ int64_t nam_hip_model_get_string(const nam_hip_model* model, int field, char* bu
           text += std::string(" a1_valu=") + (p.a1.valid ? "1" : "0") + " a1_mfma=" + ((p.a1.valid && p.a1.ws_ok) ? "1" : "0")
                   + " kt_mfma=" + ((p.a1.valid && p.a1.kt_ok) ? "1" : "0") + " kp=" + ((p.a1.valid && p.a1.kp_ok) ? "1" : "0") + " a1_il=" + ((p.a1.valid && p.a1.il_ok) ? "1" : "0")
                   + " a1_p2=" + ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? "1" : "0")
-                  + (p.wr.ok ? std::string(" wn_reg=1") : " wn_reg=0 (" + p.wr.why + ")");
+                  + (p.wr.ok ? std::string(" wn_reg=1") : " wn_reg=0 (" + p.wr.why + ")")
+                  + (p.wr.jit_failed.empty() ? std::string() : " wn_reg_jit=failed (" + p.wr.jit_failed + ")");
       }
       break;
     default: return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_model_get_string: unknown field");
@@ -1779,7 +1789,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
   info->fast_tanh = s.fast_tanh ? 1 : 0;
   info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0)
                         | ((p.a1.valid && p.a1.il_ok) ? 4 : 0) | ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? 8 : 0)
-                        | (p.wr.ok ? 16 : 0);
+                        | (p.wr.ok ? 16 : 0) | (p.wr.jit_failed.empty() ? 0 : 32);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
   return NAM_HIP_OK;
@@ -2267,6 +2277,7 @@ int nam_hip_batch_debug_timeline(nam_hip_batch* batch, int n_frames, long long* 
   const size_t bytes = 96 * 8 * sizeof(long long);
   NAM_HIP_CHECK(hipMalloc(&batch->dbg, bytes));
   NAM_HIP_CHECK(hipMemset(batch->dbg, 0, bytes));
+  NAM_HIP_CHECK(hipDeviceSynchronize()); // (the fill runs on the null stream, the launch on the batch's non-blocking one)
   int rc = NAM_HIP_OK;
   for (auto& g : batch->groups)
     if (!g.streams.empty() && rc == NAM_HIP_OK)

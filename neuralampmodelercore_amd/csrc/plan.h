@@ -438,6 +438,7 @@ struct WrPlan
 {
   bool ok = false;
   std::string why; // when !ok: the first unsupported thing
+  std::string jit_failed; // non-empty: the per-model compile this plan asked for was not available (why) — it was planned again without
   std::vector<WrOp> ops;
   std::vector<float> blob; // weights, then the tables (int bit patterns)
   int n_layers = 0; // = slots

@@ -11,14 +11,21 @@
 #include <atomic>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <sstream>
+#include <utility>
+#include <vector>
+
+extern char** environ;
 
 namespace namhip
 {
@@ -56,12 +63,45 @@ unsigned long long fnv(const std::string& s, unsigned long long h = 146959810393
   }
   return h;
 }
-bool make_dir(const std::string& d)
+// A cache directory holds code objects this process will load and run on the GPU: it must be a real directory (not a
+// symbolic link) that nobody else can write into — ours (or, for the install directory, root's) and neither group- nor
+// world-writable. `create`: make it (mode 0700) when it does not exist.
+bool cache_dir_ok(const std::string& d, bool create, bool must_own)
 {
   struct stat st;
-  if (stat(d.c_str(), &st) == 0)
-    return S_ISDIR(st.st_mode) && access(d.c_str(), W_OK) == 0;
-  return mkdir(d.c_str(), 0755) == 0;
+  if (lstat(d.c_str(), &st) != 0)
+  {
+    if (!create || mkdir(d.c_str(), 0700) != 0 || lstat(d.c_str(), &st) != 0)
+      return false;
+  }
+  if (!S_ISDIR(st.st_mode) || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0)
+    return false;
+  if (st.st_uid != geteuid() && (must_own || st.st_uid != 0))
+    return false;
+  return access(d.c_str(), W_OK | X_OK) == 0;
+}
+// hipcc with an argument vector (no shell: the paths come from the environment and from dladdr), output into `log`
+int run_compiler(const std::vector<std::string>& argv, const std::string& log)
+{
+  std::vector<char*> av;
+  for (const std::string& a : argv)
+    av.push_back(const_cast<char*>(a.c_str()));
+  av.push_back(nullptr);
+  posix_spawn_file_actions_t fa;
+  if (posix_spawn_file_actions_init(&fa) != 0)
+    return -1;
+  posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+  posix_spawn_file_actions_adddup2(&fa, 1, 2);
+  pid_t pid = 0;
+  const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+  posix_spawn_file_actions_destroy(&fa);
+  if (rc != 0)
+    return -1;
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0)
+    if (errno != EINTR)
+      return -1;
+  return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
 }
 const char* const kSources[] = {"kernel_wn_reg.hip", "device_common.h", "kernels.h", "plan.h", "model_spec.h", "persist_wave.h"};
 } // namespace
@@ -103,17 +143,36 @@ std::string wr_jit_build(const WrShapeSet& shapes, std::string& why)
   char key[32];
   std::snprintf(key, sizeof(key), "%016llx", h);
 
+  // the cache: NAM_HIP_JIT_CACHE, else jit/ next to the library (the install), else the user's own cache directory
+  // ($XDG_CACHE_HOME or ~/.cache), else a 0700 directory of this user under /tmp — never a directory someone else can write
   std::string cache;
-  if (const char* e = std::getenv("NAM_HIP_JIT_CACHE"))
-    cache = e;
-  else
-    cache = lib + "/jit";
-  if (!make_dir(cache))
   {
-    cache = "/tmp/nam_hip_jit_" + std::to_string((long)getuid());
-    if (!make_dir(cache))
+    std::vector<std::pair<std::string, bool>> cand; // {path, must be owned by this user}
+    if (const char* e = std::getenv("NAM_HIP_JIT_CACHE"))
+      cand.push_back({e, false});
+    else
     {
-      why = "per-model compile: no writable cache directory (NAM_HIP_JIT_CACHE)";
+      cand.push_back({lib + "/jit", false});
+      const char* xdg = std::getenv("XDG_CACHE_HOME");
+      const char* home = std::getenv("HOME");
+      if (xdg && xdg[0] == '/')
+        cand.push_back({std::string(xdg) + "/nam_hip_jit", true});
+      else if (home && home[0] == '/')
+      {
+        (void)mkdir((std::string(home) + "/.cache").c_str(), 0700);
+        cand.push_back({std::string(home) + "/.cache/nam_hip_jit", true});
+      }
+      cand.push_back({"/tmp/nam_hip_jit_" + std::to_string((long)geteuid()), true});
+    }
+    for (const auto& c : cand)
+      if (cache_dir_ok(c.first, true, c.second))
+      {
+        cache = c.first;
+        break;
+      }
+    if (cache.empty())
+    {
+      why = "per-model compile: no cache directory that only this user can write (NAM_HIP_JIT_CACHE)";
       return "";
     }
   }
@@ -134,9 +193,9 @@ std::string wr_jit_build(const WrShapeSet& shapes, std::string& why)
     std::ofstream f(hdr);
     f << "// generated by libnam_hip.so (wr_jit.cpp): the layer shapes of one model\n" << text;
   }
-  const std::string cmd = "'" + hipcc + "' --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -mllvm -amdgpu-mfma-vgpr-form -include '" + hdr
-                          + "' -I'" + src + "' -c -o '" + tmp + "' '" + src + "/kernel_wn_reg.hip' > '" + log + "' 2>&1";
-  const int rc = std::system(cmd.c_str());
+  const int rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                               "-include", hdr, "-I" + src, "-c", "-o", tmp, src + "/kernel_wn_reg.hip"},
+                              log);
   std::remove(hdr.c_str());
   if (rc != 0 || !readable(tmp))
   {

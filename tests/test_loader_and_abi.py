@@ -223,3 +223,39 @@ def test_register_resident_kernel_state_is_an_image_of_its_lds_rings(nam_lib):
     # channels, K = 4, dilations 1, 2); the op program's rings of the same model are the larger layout here
     m = nam_lib.get_dsp(model_path("wavenet_a2_max"))
     assert m.info.state_bytes_per_stream >= 4 * wr_floats([(3, 2, 1), (3, 2, 2), (4, 3, 1), (4, 3, 3), (4, 3, 5), (4, 4, 1), (4, 4, 2)])
+
+
+def test_per_model_compile_cache_directory_is_private(nam_lib, tmp_path, monkeypatch):
+    """csrc/wr_jit.cpp loads what it finds in its cache onto the GPU: a cache directory someone else could write into (group-
+    or world-writable, a symbolic link) is refused — the model then says why it is not on its compiled shapes —, a private one
+    is used, and a path with a quote in it reaches the compiler as one argument (no shell)."""
+    import stat
+    sys_path_golden = os.path.join(ROOT, "tests", "golden")
+    import sys
+    if sys_path_golden not in sys.path:
+        sys.path.insert(0, sys_path_golden)
+    import make_synthetic_models as msm
+    nam = nam_lib
+    p = str(tmp_path / "featured.nam")
+    msm.write_featured(p, 7001, wr_shapes=True, post_head=False)  # (seed 7001: shapes outside the ahead-of-time tables)
+    open_dir = tmp_path / "open"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o777)
+    monkeypatch.setenv("NAM_HIP_JIT_CACHE", str(open_dir))
+    m = nam.get_dsp(p, fast_tanh=False)
+    # loud: nam_hip_model_info bit 5 and the description say that the model runs off its compiled shapes, and why
+    assert m.info.has_a1_kernel & 32 and "only this user can write" in m.jit_failed(), m.describe()
+    assert not list(open_dir.iterdir())
+    link = tmp_path / "link"
+    private = tmp_path / "it's private"
+    private.mkdir(mode=0o700)
+    link.symlink_to(private)
+    monkeypatch.setenv("NAM_HIP_JIT_CACHE", str(link))
+    m = nam.get_dsp(p, fast_tanh=False)
+    assert m.info.has_a1_kernel & 32, "a symbolic link is not a cache directory"
+    monkeypatch.setenv("NAM_HIP_JIT_CACHE", str(private))
+    m = nam.get_dsp(p, fast_tanh=False)
+    assert m.info.has_a1_kernel & 16 and not (m.info.has_a1_kernel & 32) and m.jit_failed() == "", m.describe()
+    objs = [f for f in private.iterdir() if f.name.endswith(".hsaco")]
+    assert len(objs) == 1 and stat.S_IMODE(objs[0].stat().st_mode) & 0o022 == 0
+    assert [f.name for f in private.iterdir()] == [objs[0].name]  # no header / log / temporary file left behind

@@ -1,0 +1,105 @@
+// developer probe: vector-ALU issue cost on gfx950 — v_fma_f32 vs v_pk_fma_f32 vs v_rcp_f32 (independent chains), alone and
+// next to fp32 MFMAs, with 1 / 2 / 3 waves per SIMD (waves i, i + 4, i + 8 of a workgroup share a SIMD).
+//   hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate tools/src/valu_rate.hip && /tmp/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// MODE 0: 8 independent v_fma_f32 per iteration; 1: 8 v_pk_fma_f32 (16 FMAs); 2: 8 v_rcp_f32; 3: 4 MFMA 16x16x4 + 8 v_fma;
+// 4: 4 MFMA 16x16x4 alone; 5: 8 v_fma + 8 v_mul interleaved (16 plain); 6: 4 MFMA 4x4x1 + 8 v_fma
+template <int MODE>
+__global__ void k(float* p, long long* cyc, int iters)
+{
+  float a[8], m = p[threadIdx.x & 63], c = p[64 + (threadIdx.x & 63)];
+  f2 q[8];
+  f4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+  {
+    a[i] = p[128 + i + (threadIdx.x & 63)];
+    q[i] = f2{a[i], a[i] + 1.0f};
+  }
+  __syncthreads();
+  const long long t0 = clock64();
+  for (int it = 0; it < iters; it++)
+  {
+    if (MODE == 0 || MODE == 3 || MODE == 6)
+    {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+    }
+    if (MODE == 5)
+    {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+      {
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(q[i][0]) : "v"(m));
+      }
+    }
+    if (MODE == 1)
+    {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(f2{m, m}), "v"(f2{c, c}));
+    }
+    if (MODE == 2)
+    {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+    }
+    if (MODE == 3 || MODE == 4)
+    {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(m, c, acc[i], 0, 0, 0);
+    }
+    if (MODE == 6)
+    {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(m, c, acc[i], 0, 0, 0);
+    }
+  }
+  const long long t1 = clock64();
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    s += a[i] + q[i][0] + q[i][1];
+  p[threadIdx.x & 63] = s + acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+  if (threadIdx.x == 0)
+    cyc[0] = t1 - t0;
+}
+template <int MODE>
+void run(const char* name, float* d, long long* dc, int waves_per_simd, double per_iter)
+{
+  const int iters = 512;
+  for (int rep = 0; rep < 2; rep++)
+    hipLaunchKernelGGL((k<MODE>), dim3(1), dim3(256 * waves_per_simd), 0, 0, d, dc, iters);
+  long long c;
+  hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+  printf("%-46s %d wave(s)/SIMD: %7.2f cycles per iteration per SIMD (%5.2f per instruction of one wave, %5.2f per SIMD-instruction)\n", name,
+         waves_per_simd, (double)c / iters, (double)c / iters / per_iter, (double)c / iters / per_iter / waves_per_simd);
+}
+int main()
+{
+  float* d;
+  long long* dc;
+  hipMalloc(&d, 4096);
+  hipMalloc(&dc, 8);
+  hipMemset(d, 0, 4096);
+  for (int w = 1; w <= 3; w++)
+  {
+    run<0>("8 x v_fma_f32", d, dc, w, 8);
+    run<5>("8 x (v_fma_f32 + v_mul_f32)", d, dc, w, 16);
+    run<1>("8 x v_pk_fma_f32", d, dc, w, 8);
+    run<2>("8 x v_rcp_f32", d, dc, w, 8);
+    run<4>("4 x mfma 16x16x4", d, dc, w, 4);
+    run<3>("4 x mfma 16x16x4 + 8 x v_fma_f32", d, dc, w, 12);
+    run<6>("4 x mfma 4x4x1 + 8 x v_fma_f32", d, dc, w, 12);
+  }
+  return 0;
+}
