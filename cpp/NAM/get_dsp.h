@@ -152,7 +152,7 @@ inline bool has_custom_checkers()
 }
 inline nam_hip_load_options load_options(bool version_checked)
 {
-  nam_hip_load_options o{};
+  nam_hip_load_options o = NAM_HIP_LOAD_OPTIONS_INIT;
   o.fast_tanh = activations::Activation::using_fast_tanh ? 1 : 0;
   o.version_checked_by_caller = version_checked ? 1 : 0;
   return o;

@@ -129,8 +129,16 @@ typedef struct nam_hip_load_options
    * IVersionSupportChecker objects (NAM/get_dsp.h:19-25,60, get_dsp.cpp:92-128), which can only WIDEN what the core
    * checker accepts — so the library's built-in gate (0.5.0 <= version, minor <= 0.7) is skipped. */
   int32_t version_checked_by_caller;
-  int32_t reserved;
+  /* sizeof(nam_hip_load_options) as the CALLER compiled it (NAM_HIP_LOAD_OPTIONS_INIT sets it). The struct has grown once
+   * (16 bytes in library version 0.1: fast_tanh, n_luts, luts): the library reads a field only if struct_size says the caller's
+   * struct holds it — 0 (a caller built against the old header, or one that zero-fills) means "the first 16 bytes only", so
+   * garbage behind an old caller's struct can never switch the version gate off. */
+  int32_t struct_size;
 } nam_hip_load_options;
+#define NAM_HIP_LOAD_OPTIONS_INIT {0, 0, 0, 0, (int32_t)sizeof(nam_hip_load_options)}
+/* With version_checked_by_caller the caller's checkers have seen the TOP-LEVEL document only: nested documents (a WaveNet's
+ * condition_dsp, a container's submodels) still pass the library's built-in gate, where the reference consults its registry on
+ * every get_dsp call (NAM/get_dsp.cpp:92-128). A caller that widens support for nested files must check them itself. */
 NAM_HIP_API int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam_hip_load_options* options,
                                       nam_hip_model** out_model);
 NAM_HIP_API void nam_hip_model_free(nam_hip_model* model);

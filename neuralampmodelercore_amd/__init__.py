@@ -72,7 +72,7 @@ class _Lut(ctypes.Structure):
 
 class _LoadOptions(ctypes.Structure):
     _fields_ = [("fast_tanh", ctypes.c_int32), ("n_luts", ctypes.c_int32), ("luts", ctypes.POINTER(_Lut)),
-                ("version_checked_by_caller", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("version_checked_by_caller", ctypes.c_int32), ("struct_size", ctypes.c_int32)]
 
 
 def lib_path() -> str:
@@ -410,7 +410,7 @@ def _load_ex(path, text, fast_tanh, luts) -> "Model":
     arr = (_Lut * max(len(items), 1))()
     for i, (name, (lo, hi, n)) in enumerate(items):
         arr[i] = _Lut(name.encode(), float(lo), float(hi), int(n))
-    opts = _LoadOptions(1 if fast_tanh else 0, len(items), arr)
+    opts = _LoadOptions(1 if fast_tanh else 0, len(items), arr, 0, ctypes.sizeof(_LoadOptions))
     _check(L.nam_hip_model_load_ex(os.fsencode(path) if path is not None else None,
                                    text.encode("utf-8") if text is not None else None, ctypes.byref(opts), ctypes.byref(h)))
     return Model(h.value)
@@ -443,7 +443,7 @@ def get_dsp_data(conf: dict, fast_tanh: bool = False) -> Model:
     L = load_library()
     h = ctypes.c_void_p()
     w = np.ascontiguousarray(conf["weights"], dtype=np.float32)
-    opts = _LoadOptions(1 if fast_tanh else 0, 0, None)
+    opts = _LoadOptions(1 if fast_tanh else 0, 0, None, 0, ctypes.sizeof(_LoadOptions))
     md = conf.get("metadata")
     _check(L.nam_hip_model_load_parts(conf["version"].encode(), conf["architecture"].encode(), conf["config"].encode("utf-8"),
                                       md.encode("utf-8") if md else None, w.ctypes.data_as(ctypes.c_void_p), int(w.size),

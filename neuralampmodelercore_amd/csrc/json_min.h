@@ -424,9 +424,15 @@ inline void dump_to(const Value& v, std::string& out)
     case Value::Bool: out += v.b ? "true" : "false"; break;
     case Value::Number:
     {
+      // what the parser above reads back: NaN / Infinity / -Infinity as Python's json module writes them (non-finite
+      // numbers have no JSON form), the sign of zero kept, and the integer test only inside the range where the cast is defined
       if (v.num != v.num)
         out += "NaN";
-      else if (v.num == (double)(long long)v.num && v.num > -1e15 && v.num < 1e15)
+      else if (v.num == HUGE_VAL || v.num == -HUGE_VAL)
+        out += v.num > 0 ? "Infinity" : "-Infinity";
+      else if (v.num == 0.0 && std::signbit(v.num))
+        out += "-0.0";
+      else if (v.num > -1e15 && v.num < 1e15 && v.num == (double)(long long)v.num)
         out += std::to_string((long long)v.num);
       else
       {

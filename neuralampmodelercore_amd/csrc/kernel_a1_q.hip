@@ -390,6 +390,14 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     lds_barrier(); // weights, constants, rings and flags are in place
     if constexpr (DBG)
       dbg_t[1] = clock64();
+    // the layers' constants (bias, mixin, 1x1 bias by channel quad): registers for the whole launch, like the matrices
+    // (same-box A/B, profiles/r04/a1q_variants.txt: 5.63 -> 5.37 us per buffer inside a 200-buffer launch)
+    f4 cst[NJS][3];
+#pragma unroll
+    for (int u = 0; u < NJS; u++)
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        cst[u][q] = lds_ld4(lds, (unsigned)(aq::kWB + (aq::kBigConsts + (J0 + u) * 64) * 4) + (unsigned)q * 64u + g16);
 
     f4 xs, hd;
     float cnd = 0.0f;
@@ -452,8 +460,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       }
       // (c) conv + mixin: two chains (a lone wave's dependent MFMA waits 40 cycles, issue is 32), the first seeded with
       // bias + mixin * input; taps oldest first
-      constexpr unsigned cb = (unsigned)(aq::kWB + (aq::kBigConsts + JI * 64) * 4);
-      const f4 bv = lds_ld4(lds, cb + g16), mv = lds_ld4(lds, cb + 64u + g16);
+      const f4 bv = cst[U][0], mv = cst[U][1];
       f4 acc = __builtin_elementwise_fma(mv, f4{cnd, cnd, cnd, cnd}, bv), acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s_ = 0; s_ < 4; s_++)
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][2], xs[2], acc, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][3], xs[3], acc2, 0, 0, 0);
       // (d) activation, head accumulator, layer 1x1 + residual
-      const f4 b1v = lds_ld4(lds, cb + 128u + g16);
+      const f4 b1v = cst[U][2];
       const f4 z = aq_act4<ACT_T>(acc + acc2);
       hd += z;
       xs += b1v;
@@ -755,34 +762,42 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         acc0 = __builtin_elementwise_fma(m0, c4, acc0);
         acc1 = __builtin_elementwise_fma(m1, c4, acc1);
       }
-      auto tap = [&](unsigned tb, const f4& v0, const f4& v1, f4& o0, f4& o1) {
-        const f4 wa = lds_ld4(lds, tb + cls64), wb = lds_ld4(lds, tb + 16u + cls64);
-        const f4 wc = lds_ld4(lds, tb + 32u + cls64), wd = lds_ld4(lds, tb + 48u + cls64);
+      // a tap = 16 matrix instructions on a 256-byte tile; the NEXT tap's tile is requested before this tap's instructions are
+      // issued (a lone wave — the first buffer of a launch, a one-stream caller — otherwise sits out an LDS round trip per tap)
+      struct Tile
+      {
+        f4 a, b, c, d;
+      };
+      auto tile_ld = [&](unsigned tb) { return Tile{lds_ld4(lds, tb + cls64), lds_ld4(lds, tb + 16u + cls64), lds_ld4(lds, tb + 32u + cls64), lds_ld4(lds, tb + 48u + cls64)}; };
+      auto tap = [&](const Tile& w, const f4& v0, const f4& v1, f4& o0, f4& o1) {
 #pragma unroll
         for (int c = 0; c < 4; c++)
         {
-          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[c], v0[c], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[c], v0[c], o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.a[c], v0[c], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.c[c], v0[c], o1, 0, 0, 0);
         }
 #pragma unroll
         for (int c = 0; c < 4; c++)
         {
-          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[c], v1[c], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[c], v1[c], o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.b[c], v1[c], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.d[c], v1[c], o1, 0, 0, 0);
         }
       };
       constexpr unsigned t0 = (unsigned)(aq::kWB + (aq::kMTiles + LI * 4 * aq::kTileM) * 4);
-      tap(t0, b0[0], b1[0], acc0, acc1);
-      tap(t0 + 256u, b0[1], b1[1], acc0, acc1);
+      const Tile w0 = tile_ld(t0), w1 = tile_ld(t0 + 256u);
+      tap(w0, b0[0], b1[0], acc0, acc1);
+      const Tile w2 = tile_ld(t0 + 512u);
+      tap(w1, b0[1], b1[1], acc0, acc1);
       if constexpr (!RES)
         fetch_far(j_tag, wpn);
-      tap(t0 + 512u, x0, x1, acc0, acc1);
+      const Tile w3 = tile_ld(t0 + 768u);
+      tap(w2, x0, x1, acc0, acc1);
       const f4 b1v0 = lds_ld4(lds, cb + 64u), b1v1 = lds_ld4(lds, cb + 80u);
       const f4 z0 = aq_act4<ACT_T>(acc0), z1 = aq_act4<ACT_T>(acc1);
       head0 += z0;
       head1 += z1;
       f4 y0 = x0 + b1v0, y1 = x1 + b1v1;
-      tap(t0 + 768u, z0, z1, y0, y1);
+      tap(w3, z0, z1, y0, y1);
       x0 = y0;
       x1 = y1;
       wp[U] = wpn;

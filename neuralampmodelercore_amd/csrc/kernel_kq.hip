@@ -383,6 +383,9 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
 
   f4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, head0 = x0, head1 = x0;
   int nvalid = kBlock; // frames of the buffer this wave's stage is working on
+  // every buffer of this launch is whole (a session; a launch of a multiple of 64 frames): layers without far taps keep their
+  // history in the LDS window only and write its tail back when the launch leaves
+  const bool lazy = PERSIST || (a.n_frames % kBlock) == 0;
   float cond = 0.0f;
   unsigned long long spec_cmd = 0; // PERSIST, stage 0: the early look at the next command ...
   float inp_spec = 0.0f; // ... and the input sample requested on a hit
@@ -402,8 +405,11 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
     constexpr int F0 = kq::stage_far0(SS, JI);
     __builtin_amdgcn_sched_barrier(0);
     const f4 in0 = HEAD ? head0 : x0, in1 = HEAD ? head1 : x1;
-    // (a) the job's input -> its history ring: row (position + frame) mod R; -> the current rows of its window
+    // (a) the job's input -> its history ring: row (position + frame) mod R; -> the current rows of its window. A layer whose
+    // taps all lie inside one buffer (its window's tail IS its history: eleven of the A2 topology's 24 jobs) appends
+    // nothing while whole buffers flow — the tail goes back into the ring once, when the launch leaves (below)
     const int wpj = wp[U];
+    if (!(lazy && kq::far_taps(JI) == 0 && T > 0))
     {
       const unsigned v = (unsigned)(wpj + app_idx);
       const int widx = (int)min(v, v - (unsigned)RL);
@@ -661,6 +667,38 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
     },
     std::make_integer_sequence<int, NST>{});
 
+  // the tails of the layers that appended nothing (above): window rows [0, T) = the last T frames of the layer's input, into
+  // the ring rows in front of its (final) write position — the state is again what every kernel of the family expects
+  if (lazy)
+  {
+    asm volatile("" ::: "memory");
+    il::for_each_index(
+      [&](auto s_tag) {
+        constexpr int SS = decltype(s_tag)::value;
+        if (S == SS)
+        {
+          constexpr int J0 = kq::first_job(SS), NJS = kq::first_job(SS + 1) - J0;
+          il::for_each_index(
+            [&](auto u_tag) {
+              constexpr int U = decltype(u_tag)::value, TJ = J0 + U;
+              constexpr int T = kq::tail_rows(TJ), WR = kq::win_rows(TJ), WB0 = kq::win_b(TJ), WB1 = WB0 + WR * 16, RL = kq::ring_len(TJ);
+              if constexpr (kq::far_taps(TJ) == 0 && T > 0)
+              {
+                const unsigned row = (unsigned)(frame < T ? frame : 0) * 16u;
+                const f4 q0 = lds_ld4(lds, (unsigned)WB0 + row), q1 = lds_ld4(lds, (unsigned)WB1 + row);
+                int sb_ = wp[U] - T;
+                sb_ += sb_ < 0 ? RL : 0;
+                const unsigned v = (unsigned)(sb_ + frame);
+                const int idx = frame < T ? (int)min(v, v - (unsigned)RL) : kq::kNoRow;
+                kq_sb_store4(q0, rs, idx, 0, kq::ring_off(TJ) * 4, 0);
+                kq_sb_store4(q1, rs, idx, 16, kq::ring_off(TJ) * 4, 0);
+              }
+            },
+            std::make_integer_sequence<int, NJS>{});
+        }
+      },
+      std::make_integer_sequence<int, NST>{});
+  }
   // the write positions of this stage's rings go back into the state (lane r = ring r)
   il::for_each_index(
     [&](auto s_tag) {

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -1504,8 +1505,21 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
       b->map_failed = true; // no host-writable device memory here
       return 1;
     }
-    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->h_out_map), out_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
-    NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_out_map), b->h_out_map, 0));
+    // all three or none: a later call must not find the input window without the output window (it would submit commands
+    // with a null output base and copy from a null mapping)
+    if (hipHostMalloc(reinterpret_cast<void**>(&b->h_out_map), out_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_out_map), b->h_out_map, 0) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      if (b->h_out_map)
+        (void)hipHostFree(b->h_out_map);
+      (void)hipFree(b->in_bar);
+      b->in_bar = nullptr;
+      b->h_out_map = nullptr;
+      b->d_out_map = nullptr;
+      b->map_failed = true; // the copying path takes over
+      return 1;
+    }
   }
   const size_t rows_in = (size_t)b->n_streams * ic, rows_out = (size_t)b->n_streams * oc;
   for (size_t r = 0; r < rows_in; r++)
@@ -1573,7 +1587,7 @@ int nam_hip_version_support(const char* nam_file_version)
 
 const char* nam_hip_version(void)
 {
-  return "nam_hip 0.1.0 gfx950";
+  return "nam_hip 0.2.0 gfx950"; // 0.2: nam_hip_load_options::struct_size (0.1 callers: the first 16 bytes are read)
 }
 
 int nam_hip_model_load(const char* nam_path, int fast_tanh, nam_hip_model** out_model)
@@ -1607,7 +1621,9 @@ int nam_hip_model_load_ex(const char* nam_path, const char* json_text, const nam
     if (options)
     {
       lo.fast_tanh = options->fast_tanh != 0;
-      lo.skip_version_gate = options->version_checked_by_caller != 0;
+      // (a field behind the original 16 bytes is read only when the caller's struct_size covers it: include/nam_hip.h)
+      const bool has_v2 = options->struct_size >= (int32_t)(offsetof(nam_hip_load_options, struct_size) + sizeof(int32_t));
+      lo.skip_version_gate = has_v2 && options->version_checked_by_caller != 0;
       if (options->n_luts < 0 || (options->n_luts > 0 && !options->luts))
         throw std::runtime_error("nam_hip_model_load_ex: bad lookup-table list");
       for (int i = 0; i < options->n_luts; i++)
@@ -1678,7 +1694,11 @@ int nam_hip_model_load_parts(const char* version, const char* architecture, cons
   for (int64_t i = 0; i < n_weights; i++)
   {
     char buf[32];
-    std::snprintf(buf, sizeof(buf), i ? ",%.9g" : "%.9g", (double)weights[i]); // 9 digits: float round trip is exact
+    const double wv = (double)weights[i];
+    if (wv != wv || wv == HUGE_VAL || wv == -HUGE_VAL) // (no JSON form: the spellings json_min.h reads back)
+      std::snprintf(buf, sizeof(buf), i ? ",%s" : "%s", wv != wv ? "NaN" : wv > 0 ? "Infinity" : "-Infinity");
+    else
+      std::snprintf(buf, sizeof(buf), i ? ",%.9g" : "%.9g", wv); // 9 digits: float round trip is exact
     doc += buf;
   }
   doc += "]}";

@@ -99,6 +99,44 @@ for rnd, name, kernel, model, streams, steps in RESIDENT:
                 "consecutive buffers, so a lone 64-frame launch never runs it; the persistent block mode runs the same loop body per command",
         "lds_note": "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE of the resident launch / steps",
     })
+# the issue-port terms of bench.py's floor (fp32 MFMA pipe cycles, MFMA instructions) for the round-3 entries, from their own
+# counters: nam_a1_p4_kernel issues 16x16x4 instructions only (4 "MOPS" = 32 pipe cycles each), nam_kq_kernel 4x4x1 only
+# (761,856 per step, counted: profiles/r03/counters_kq_resident.txt; 8 pipe cycles each)
+for e in entries:
+    if e["kernel"] == "nam_a1_p4_kernel" and e.get("mfma_mops_f32"):
+        e["mfma_insts"] = e["mfma_mops_f32"] / 4.0
+        e["mfma_busy_cycles"] = e["mfma_insts"] * 32.0
+    if e["kernel"] == "nam_kq_kernel" and e["model"] == "A2":
+        e["mfma_insts"] = 761856.0
+        e["mfma_busy_cycles"] = 761856.0 * 8.0
+# round 4: scripts/gpu_prof_resident.sh writes counters_<tag>.json = {kernel, ns_per_step, per_step: {counter: value}} — a 300-step
+# resident launch of a later repetition (settled clocks), every counter divided by 300
+RESIDENT_R4 = [("r04", "counters_c2_q_resident.json", "nam_a1_q_kernel", "wavenet_a1_standard", 256),
+               ("r04", "counters_a2_kq_resident.json", "nam_kq_kernel", "A2", 256)]
+for rnd, name, kernel, model, streams in RESIDENT_R4:
+    path = os.path.join(ROOT, "profiles", rnd, name)
+    if not os.path.exists(path):
+        continue
+    d = json.load(open(path))
+    c = d["per_step"]
+    entries = [e for e in entries if not (e["kernel"] == kernel and e["model"] == model and e["streams"] == streams)]
+    entries.append({
+        "kernel": kernel, "model": model, "streams": streams, "block": 64, "launch": "block",
+        "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+        "kernel_cycles": c.get("GRBM_GUI_ACTIVE"),
+        "lds_idx_active_cycles": c.get("SQ_LDS_IDX_ACTIVE"),
+        "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
+        "insts_per_launch": {k: c.get("SQ_INSTS_" + k) for k in ("VALU", "SALU", "SMEM", "LDS", "VMEM_RD", "VMEM_WR")},
+        "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32"),
+        "mfma_insts": c.get("SQ_INSTS_MFMA"),
+        "mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+        "rocprof_avg_launch_us": round(d["ns_per_step"] / 1e3, 3),
+        "note": f"profiles/{rnd}/{name}: 300-step resident launches behind the bench's own spin-up (median {d['ns_per_step'] / 1e3:.3f} us per step), "
+                f"every counter divided by 300: FETCH_SIZE {c['FETCH_SIZE']:,.0f} KB x2 (gfx950 reports half of wide coalesced reads, "
+                f"MI355X_MICROARCH.md HBM section) + WRITE_SIZE {c['WRITE_SIZE']:,.0f} KB, separate --pmc passes (scripts/gpu_prof_resident.sh); "
+                "the kernel pipelines consecutive buffers, so a lone 64-frame launch never runs it; a session's launch runs the same loop body per command",
+        "lds_note": "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT of the resident launch / steps",
+    })
 json.dump({"entries": entries}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for e in entries:
     print(e["kernel"], e["model"], e["streams"], e["hbm_bytes_per_launch"], e.get("rocprof_avg_launch_us"), e.get("insts_per_launch"))

@@ -259,3 +259,46 @@ def test_per_model_compile_cache_directory_is_private(nam_lib, tmp_path, monkeyp
     objs = [f for f in private.iterdir() if f.name.endswith(".hsaco")]
     assert len(objs) == 1 and stat.S_IMODE(objs[0].stat().st_mode) & 0o022 == 0
     assert [f.name for f in private.iterdir()] == [objs[0].name]  # no header / log / temporary file left behind
+
+
+def test_load_options_struct_size_guards_the_version_gate(nam_lib):
+    """nam_hip_load_options grew once (library 0.1: 16 bytes). A caller built against the old header passes a struct that
+    ends behind `luts`: whatever lies there must not switch the built-in version gate off — the library reads
+    version_checked_by_caller only when struct_size covers it (include/nam_hip.h)."""
+    import ctypes
+    nam = nam_lib
+    L = nam.load_library()
+    assert "0.2" in L.nam_hip_version().decode()
+    doc = json.load(open(model_path("wavenet")))
+    doc["version"] = "0.9.0"  # beyond the built-in gate (minor <= 0.7)
+    text = json.dumps(doc).encode()
+    for struct_size, accepted in ((0, False), (16, False), (ctypes.sizeof(nam._LoadOptions), True)):
+        opts = nam._LoadOptions(0, 0, None, 1, struct_size)  # version_checked_by_caller = 1
+        h = ctypes.c_void_p()
+        rc = L.nam_hip_model_load_ex(None, text, ctypes.byref(opts), ctypes.byref(h))
+        assert (rc == 0) == accepted, (struct_size, rc, L.nam_hip_last_error())
+        if rc == 0:
+            L.nam_hip_model_free(h)
+
+
+def test_config_and_metadata_text_round_trips_non_finite_numbers(nam_lib):
+    """json_min.h writes what it reads: NaN / Infinity / -Infinity (no JSON form exists; Python's spellings), the sign of zero,
+    integers only inside the range where the test is defined — nam::dspData's config / metadata text goes back through
+    get_dsp(dspData&) (NAM/get_dsp.h:91), non-finite weights included."""
+    nam = nam_lib
+    doc = json.load(open(model_path("wavenet")))
+    doc["metadata"] = {"loudness": -20.5, "gain": float("nan"), "hi": float("inf"), "lo": float("-inf"), "zero": -0.0,
+                       "big": 1e300, "huge_int": 2 ** 70, "n": 3}
+    m = nam.get_dsp_json(json.dumps(doc), fast_tanh=False)
+    d = m.dsp_data()
+    meta = json.loads(d["metadata"])
+    assert np.isnan(meta["gain"]) and meta["hi"] == float("inf") and meta["lo"] == float("-inf")
+    assert meta["zero"] == 0.0 and np.signbit(meta["zero"]) and meta["big"] == 1e300 and meta["huge_int"] == float(2 ** 70) and meta["n"] == 3
+    conf = dict(d)  # (config / metadata stay JSON text, as nam::dspData carries them across the boundary)
+    m2 = nam.get_dsp_data(conf, fast_tanh=False)
+    assert json.loads(m2.dsp_data()["metadata"]).keys() == meta.keys()
+    w = d["weights"].copy()
+    w[3] = np.inf
+    conf["weights"] = w
+    m3 = nam.get_dsp_data(conf, fast_tanh=False)  # a non-finite weight travels as the spelling the parser reads
+    assert np.isinf(m3.dsp_data()["weights"][3])
