@@ -3,7 +3,7 @@
 # 8-GPU config (4: wavenet_a2_max.nam, 4,096 streams = 512 per GPU) on N GPUs of one node, one process per GPU, plus
 # the C++ tool's thread-per-device render. Streams never interact: ranks share no data-path collective (RCCL only
 # broadcasts the model text, scatters the input bank and gathers the rendered tail, neuralampmodelercore_amd/sharding.py).
-#   bash scripts/run_scale.sh [N=8] [out_dir=profiles/scale]
+#   bash scripts/run_scale.sh [N=8] [out_dir=profiles/scale]      (STEPS / WARMUP default to the driver's own 20 / 5: the N = 1 line is the BENCH line)
 # Writes <out_dir>/bench_config{2,4}_n<N>.json (the bench's one JSON line) and render_devices_n<N>.txt.
 cd "$(dirname "$0")/.."
 N=${1:-8}; OUT=${2:-profiles/scale}
@@ -12,9 +12,9 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 for C in 2 4; do
   if [ "$N" -gt 1 ]; then
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port ${MASTER_PORT:-29517} \
-      bench.py --gpus "$N" --config $C --steps ${STEPS:-2000} --warmup ${WARMUP:-200} --no-other-configs | grep '^{' > "$OUT/bench_config${C}_n${N}.json"
+      bench.py --gpus "$N" --config $C --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-other-configs | grep '^{' > "$OUT/bench_config${C}_n${N}.json"
   else
-    python bench.py --gpus 1 --config $C --steps ${STEPS:-2000} --warmup ${WARMUP:-200} --no-other-configs | grep '^{' > "$OUT/bench_config${C}_n${N}.json"
+    python bench.py --gpus 1 --config $C --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-other-configs | grep '^{' > "$OUT/bench_config${C}_n${N}.json"
   fi
   python - "$OUT/bench_config${C}_n${N}.json" <<'PY'
 import json, sys
