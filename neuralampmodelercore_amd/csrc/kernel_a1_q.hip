@@ -112,6 +112,17 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < NST; i++)
     S = wall == i ? aq::kStageOfWave[i] : S;
+  // The SIMD's arbiter favours its oldest wave — the EARLIEST stage of the four a SIMD holds. While the launch's first buffer
+  // is on its way that is backwards: the later stage has the buffer everything waits for, the earlier one only runs ahead.
+  // So the later stages of a SIMD start with the higher priority and every stage drops to 0 once its first buffer is through
+  // (first output of a launch 33.6 -> 25.7 us; left on for good the period goes 5.5 -> 6.1 us: profiles/r04/a1q_variants.txt)
+  __builtin_amdgcn_s_setprio((short)0);
+  if (wall >= 12)
+    __builtin_amdgcn_s_setprio((short)3);
+  else if (wall >= 8)
+    __builtin_amdgcn_s_setprio((short)2);
+  else if (wall >= 4)
+    __builtin_amdgcn_s_setprio((short)1);
   const int stream = a.stream_map ? a.stream_map[blockIdx.x] : (int)blockIdx.x;
   float* st = a.state + (size_t)stream * a.state_stride;
   const int n_blocks = PERSIST ? (1 << 30) : (a.n_frames + kBlock - 1) / kBlock;
@@ -458,16 +469,16 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
           inp_spec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, hit ? frame * 4 : (int)kOob, soff, kInAux));
         }
       }
-      // (c) conv + mixin: two chains (a lone wave's dependent MFMA waits 40 cycles, issue is 32), the first seeded with
-      // bias + mixin * input; taps oldest first
+      // (c) conv + mixin: one chain seeded with bias + mixin * input, taps oldest first (two chains and an add — a lone
+      // wave's dependent MFMA waits 40 cycles, issue is 32 — measured slower: profiles/r04/a1q_variants.txt)
       const f4 bv = cst[U][0], mv = cst[U][1];
-      f4 acc = __builtin_elementwise_fma(mv, f4{cnd, cnd, cnd, cnd}, bv), acc2 = {0.f, 0.f, 0.f, 0.f};
+      f4 acc = __builtin_elementwise_fma(mv, f4{cnd, cnd, cnd, cnd}, bv);
 #pragma unroll
       for (int s_ = 0; s_ < 4; s_++)
-      {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][0][s_], bt[0][s_], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][1][s_], bt[1][s_], acc2, 0, 0, 0);
-      }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; s_++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][1][s_], bt[1][s_], acc, 0, 0, 0);
       // the far taps' rows of the NEXT sub-block, into the registers just consumed
       if constexpr (!RES)
       {
@@ -477,13 +488,12 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         nsb -= nsb >= R ? R : 0;
         fetch_far(j_tag, i == 3 ? wpn_ : nsb);
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][0], xs[0], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][1], xs[1], acc2, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][2], xs[2], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][3], xs[3], acc2, 0, 0, 0);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; s_++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[U][2][s_], xs[s_], acc, 0, 0, 0);
       // (d) activation, head accumulator, layer 1x1 + residual
       const f4 b1v = cst[U][2];
-      const f4 z = aq_act4<ACT_T>(acc + acc2);
+      const f4 z = aq_act4<ACT_T>(acc);
       hd += z;
       xs += b1v;
 #pragma unroll
@@ -581,6 +591,8 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
           dbg_t[7] = m;
         }
       }
+      if (k == 0)
+        __builtin_amdgcn_s_setprio((short)0); // (the launch's first buffer is through this stage)
       // the rings move on by the buffer's frames (scalar unit)
 #pragma unroll
       for (int u = 0; u < NJS; u++)
@@ -892,6 +904,8 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         dbg_t[2] = dbg_t[2] ? dbg_t[2] : dbg_t[3];
         dbg_t[7] = k + 1;
       }
+      if (k == 0)
+        __builtin_amdgcn_s_setprio((short)0); // (the launch's first buffer is through this stage's layers)
       if constexpr (!LAST)
       {
         constexpr int RN = aq::ring_len(JN);

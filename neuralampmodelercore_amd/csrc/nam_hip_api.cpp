@@ -192,6 +192,9 @@ struct nam_hip_batch
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
   bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
+  bool short_blocking_call = false; // a blocking host call of up to four buffers is being served: the caller waits for it, so the FIRST buffer's
+                                    // latency is what counts — nam_a1_p4_kernel (four waves per layer: ~6 us through the model) rather than
+                                    // nam_a1_q_kernel (one wave per layer: ~30 us; faster only once buffers overlap)
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
   bool use_q = true; // the official 16 / 8 topology's pipeline runs nam_a1_q_kernel (kernel_a1_q.hip); NAM_HIP_A1Q=0: nam_a1_p4_kernel (A/B runs)
   bool use_kq = true; // the A2 topology's pipeline runs nam_kq_kernel (kernel_kq.hip) where it applies; NAM_HIP_KQ=0: nam_kp_kernel everywhere
@@ -708,7 +711,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames) && q_runs(b, p))
+        if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames) && q_runs(b, p) && !b->short_blocking_call)
         {
           // the 16 / 8 topology as twelve one-wave stages, most rings resident in LDS (kernel_a1_q.hip): its own weight block
           // + the FULL-layout tiles of array 0 (kept in registers)
@@ -1537,14 +1540,15 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
 #endif
   b->one_buffer_call = n_frames == kBlock; // (one command, then the caller waits: the stages of a pipeline would only queue up)
+  b->short_blocking_call = n_frames <= 4 * kBlock;
   const int rc = persist_submit(b, b->in_bar, b->d_out_map, n_frames, stride, b->stream);
   if (rc != NAM_HIP_OK)
   {
-    b->one_buffer_call = false;
+    b->one_buffer_call = b->short_blocking_call = false;
     return rc < 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: the host-mapped buffer was refused");
   }
   const int rw = persist_flush(b, b->stream);
-  b->one_buffer_call = false;
+  b->one_buffer_call = b->short_blocking_call = false;
   if (rw != NAM_HIP_OK)
     return rw;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
