@@ -140,9 +140,9 @@ def model_macs(path: str) -> int:
 
 
 def cpu_baseline(model_path: str, fast_tanh: bool, block: int, target_seconds: float = 12.0, extras: bool = True):
-    """CPU oracle ("port": our Eigen-free restatement of the reference path; the reference's own
-    Eigen binary cannot be built here) on ONE host core, benchmodel protocol (64-frame blocks,
-    Reset + prewarm first), on a bounded sample of the same workload."""
+    """CPU oracle ("port": our Eigen-free restatement of the reference path, bit-exact with the reference's own sources
+    built on a scalar Eigen stand-in — oracle/_ref, timed alongside as a floor: real Eigen is not in this image) on ONE
+    host core, benchmodel protocol (64-frame blocks, Reset + prewarm first), on a bounded sample of the same workload."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nam_oracle

@@ -7,15 +7,16 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library; the product (neuralampmodelercore_amd/) never links or calls it.
  *
- * Parity pinning: the reference's own Eigen binary cannot be built in this
- * container (Eigen submodule is empty), so this restatement is pinned against
- * the reference's primitive-level known-answer tests (tools/test/test_conv1d.cpp,
- * test_conv_1x1.cpp, test_wavenet/test_layer.cpp, test_film.cpp,
- * test_gating_activations.cpp, test_blending_detailed.cpp ...) re-expressed in
- * tests/test_oracle_kat.py, and cross-checked against an independent
- * PyTorch-CPU F.conv1d implementation (tests/test_oracle_torch_crosscheck.py).
- * Whole-model outputs are unpinned by the reference itself (its model-level
- * tests only assert isfinite), see DESIGN.md "Oracle".
+ * Parity pinning (PINNED): (1) the reference's OWN sources — NAM/*.cpp compiled where they lie by oracle/Makefile.ref
+ * against a self-written scalar Eigen stand-in (oracle/eigen_shim/Eigen/Dense; the Eigen submodule is empty here) into
+ * oracle/_ref/libnam_ref.so, a2_fast.cpp included — agree with this restatement BIT FOR BIT on every fixture model and on
+ * seeded feature-rich models (tests/test_reference_build.py); caveat: that build sums in the stand-in's k-order, not in
+ * real Eigen's blocked order (differences below the 5e-5 bar). (2) the reference's primitive-level known-answer tests
+ * (tools/test/test_conv1d.cpp, test_conv_1x1.cpp, test_wavenet/test_layer.cpp, test_film.cpp,
+ * test_gating_activations.cpp, test_blending_detailed.cpp ...) re-expressed in tests/test_oracle_kat.py. (3) an
+ * independent PyTorch-CPU F.conv1d implementation (tests/test_oracle_torch_crosscheck.py). Whole-model golden vectors
+ * do not exist in the reference (its model-level tests only assert isfinite): tests/golden/outputs.npz are this
+ * oracle's outputs, which (1) ties to the reference's code.
  *
  * Data layout mirrors the reference: matrices are column-major
  * (rows = channels, cols = frames): element (c, f) lives at data[f * C + c].

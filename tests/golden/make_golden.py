@@ -1,8 +1,9 @@
 """Regenerates tests/golden/outputs.npz: oracle outputs for every fixture model.
 
 The reference repository stores no golden output vectors (its model-level tests only assert
-isfinite), so these are produced by the CPU oracle (oracle/nam_oracle.{c,py}) — itself pinned against
-the reference's primitive KATs (tests/test_oracle_kat.py) and an independent PyTorch implementation
+isfinite), so these are produced by the CPU oracle (oracle/nam_oracle.{c,py}) — itself pinned bit for bit against
+the reference's own sources built here on an Eigen stand-in (oracle/Makefile.ref, tests/test_reference_build.py),
+against the reference's primitive KATs (tests/test_oracle_kat.py) and an independent PyTorch implementation
 (tests/test_oracle_torch_crosscheck.py). Protocol per model: Reset(48000, 64) with prewarm, then
 10 x 64 frames of the two-tone test signal of tools/test/test_a2_fast.cpp:118-128.
 
