@@ -21,6 +21,8 @@ OUT = os.path.join(ROOT, "cpp", "ref_tools")
 def test_reference_tools_compile_unmodified_against_the_adapter(nam_lib):
     if not os.path.isdir(os.path.join(REF, "tools")):
         pytest.skip("the reference tree is not on this machine (the binaries were built where it is)")
+    if "asan" in os.environ.get("LD_PRELOAD", ""):
+        pytest.skip("sanitizer run of the host library (scripts/asan_host_check.sh): the tools would need the sanitizer runtime to link")
     r = subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "cpp"), "ref_tools"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     for t in TOOLS:
