@@ -400,6 +400,69 @@ class StubEngine:
         pass
 
 
+def host_io(model_path: str, n_streams: int, fast_tanh: bool, budget_s: float = 0.4):
+    """Host buffers in, host buffers out (`host_io` of the default line; never `value`: the timed region of `value` starts with
+    the inputs in HBM): 256 streams of the headline model through the C ABI's two host-buffer forms — the blocking
+    nam_hip_batch_process_f32 (one buffer at a time: copy in, commands, wait, copy out) and the ticketed
+    nam_hip_batch_submit_f32 / nam_hip_batch_wait_f32 with NAM_HIP_PIPE_SLOTS buffers in flight (the resident launch renders
+    buffer k while the host copies k + 1 in and k - 1 out). Raw ctypes calls on preallocated arrays: the loop costs ~1 us
+    of interpreter per call."""
+    import ctypes
+    import numpy as np
+    import neuralampmodelercore_amd as nam
+    model = nam.get_dsp(model_path, fast_tanh=fast_tanh)
+    L = nam.load_library()
+    res = {}
+    rng = np.random.default_rng(5)
+    for frames in (64, 256, 1024):
+        b = model.batch(n_streams, frames)
+        b.set_persistent(True)
+        b.Reset(prewarm=True)
+        D = nam.Batch.PIPE_SLOTS
+        xs = [np.ascontiguousarray(rng.uniform(-0.5, 0.5, size=(n_streams, 1, frames)).astype(np.float32)) for _ in range(D)]
+        ys = [np.zeros((n_streams, 1, frames), dtype=np.float32) for _ in range(D)]
+        xp = [x.ctypes.data_as(ctypes.c_void_p) for x in xs]
+        yp = [y.ctypes.data_as(ctypes.c_void_p) for y in ys]
+        h = b._h
+        entry = {}
+        for mode in ("blocking", "tickets"):
+            def run(n):
+                if mode == "blocking":
+                    for i in range(n):
+                        if L.nam_hip_batch_process_f32(h, xp[i % D], yp[i % D], frames) != 0:
+                            raise RuntimeError(L.nam_hip_last_error().decode())
+                else:
+                    t = [ctypes.c_int64(-1) for _ in range(D)]
+                    for i in range(n):
+                        k = i % D
+                        if i >= D and L.nam_hip_batch_wait_f32(h, t[k], yp[k]) != 0:
+                            raise RuntimeError(L.nam_hip_last_error().decode())
+                        if L.nam_hip_batch_submit_f32(h, xp[k], frames, ctypes.byref(t[k])) != 0:
+                            raise RuntimeError(L.nam_hip_last_error().decode())
+                    for i in range(max(n - D, 0), n):
+                        if L.nam_hip_batch_wait_f32(h, t[i % D], yp[i % D]) != 0:
+                            raise RuntimeError(L.nam_hip_last_error().decode())
+            run(64)
+            n = 64
+            t0 = time.perf_counter()
+            run(n)
+            dt = time.perf_counter() - t0
+            n = int(min(max(n * budget_s / max(dt, 1e-6), 64), 200000))
+            t0 = time.perf_counter()
+            run(n)
+            dt = time.perf_counter() - t0
+            entry[mode] = {"value": round(n_streams * frames * n / SR / dt, 1), "us_per_call": round(dt / n * 1e6, 2), "calls": n}
+        entry["finite"] = bool(all(np.isfinite(y).all() for y in ys))
+        res[f"{frames}_frames"] = entry
+        b.close()
+    res["unit"] = "xRT, host buffer to host buffer"
+    res["in_flight"] = nam.Batch.PIPE_SLOTS
+    res["note"] = ("PCIe-inclusive: the host writes each input through the BAR window and reads each output from host-mapped memory "
+                   "the resident launch stores to; `tickets` = nam_hip_batch_submit_f32 / nam_hip_batch_wait_f32 with `in_flight` buffers "
+                   "between submit and wait, `blocking` = nam_hip_batch_process_f32. Not `value`.")
+    return res
+
+
 def percentile(sorted_vals, q):
     if not sorted_vals:
         return None
@@ -838,6 +901,10 @@ def main():
             scratch.close()
             scratch = None
         out["other_configs"] = run_other_configs(args)
+        try:
+            out["host_io"] = host_io(model_path, n_streams, bool(args.fast_tanh))
+        except Exception as e:  # (a side figure must not take the line with it)
+            out["host_io"] = {"error": f"{type(e).__name__}: {e}"}
         st = out["other_configs"].get("2_steady") or {}
         out["steady_state"] = {"value": st.get("value"), "ms_per_step": st.get("ms_per_step"), "steps_per_region": 500,
                                "note": "the same kernel, streams and session mode in regions of 500 steps (other_configs['2_steady']); "

@@ -269,6 +269,15 @@ public:
   {
     detail::check(nam_hip_batch_process_f32(mBatch.get(), in, out, num_frames));
   }
+  // process_batch in two halves, for callers that keep buffers in flight (up to NAM_HIP_PIPE_SLOTS): submit copies `in`
+  // and returns a ticket at once, wait blocks until that buffer's output is in `out` (include/nam_hip.h)
+  int64_t submit(const float* in, const int num_frames)
+  {
+    int64_t ticket = -1;
+    detail::check(nam_hip_batch_submit_f32(mBatch.get(), in, num_frames, &ticket));
+    return ticket;
+  }
+  void wait(const int64_t ticket, float* out) { detail::check(nam_hip_batch_wait_f32(mBatch.get(), ticket, out)); }
   void SetSlimmableSize(const int* stream_ids, int n, double ratio)
   {
     detail::check(nam_hip_batch_set_slimmable_size(mBatch.get(), stream_ids, n, ratio));

@@ -82,7 +82,7 @@ int main(int argc, char* argv[])
 {
   if (argc < 2)
   {
-    std::cerr << "Usage: benchmodel <model_path> [--slim <0..1>] [--no-fast-tanh] [--streams N [--resident]] [--buffer N] [--count-allocs]\n";
+    std::cerr << "Usage: benchmodel <model_path> [--slim <0..1>] [--no-fast-tanh] [--streams N [--resident | --in-flight D]] [--buffer N] [--count-allocs]\n";
     return 1;
   }
   const char* modelPath = argv[1];
@@ -92,6 +92,7 @@ int main(int argc, char* argv[])
   int bufferSize = AUDIO_BUFFER_SIZE;
   bool count_allocs = false, resident = false;
   const char* kernelName = "auto";
+  int inFlight = 0;
   for (int i = 2; i < argc; i++)
   {
     if (!std::strcmp(argv[i], "--count-allocs"))
@@ -104,6 +105,8 @@ int main(int argc, char* argv[])
       streams = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--buffer") && i + 1 < argc) // frames per process() call (the reference's tool: 64)
       bufferSize = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--in-flight") && i + 1 < argc) // with --streams: host buffers through BatchDSP::submit / wait, D tickets deep
+      inFlight = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--resident")) // with --streams: the audio stays in device memory (BatchDSP::process_device)
       resident = true;
     else if (!std::strcmp(argv[i], "--kernel") && i + 1 < argc) // with --streams: auto | generic | a1 | a1_mfma | a1_il | wn_reg (A/B runs)
@@ -222,6 +225,51 @@ int main(int argc, char* argv[])
       }
       std::vector<float> in((size_t)streams * batch.NumInputChannels() * bufferSize, 0.0f),
         out((size_t)streams * batch.NumOutputChannels() * bufferSize, 0.0f);
+      if (inFlight > 0)
+      {
+        // The feeder shape: a thread hands buffer k in and takes buffer k - D + 1 out, D buffers between the two (an audio
+        // server's network thread, a file renderer reading ahead). Each stream's host buffers are distinct per slot.
+        const int D = std::min(inFlight, (int)NAM_HIP_PIPE_SLOTS);
+        std::vector<std::vector<float>> ins(D, in), outs(D, out);
+        std::cout << "Running benchmark (" << streams << " streams, host buffers, " << D << " in flight)\n";
+        std::vector<int64_t> tickets(D, -1);
+        const bool no_out = std::getenv("NAM_BENCHMODEL_NOOUT") != nullptr; // (developer runs: the waits discard the output)
+        for (int w = 0; w < 16; w++)
+          batch.wait(batch.submit(ins[0].data(), bufferSize), outs[0].data());
+        std::vector<double> us(numBuffers, 0.0);
+        double us_wait = 0.0, us_submit = 0.0;
+        g_counting = count_allocs;
+        auto t1 = high_resolution_clock::now();
+        for (size_t i = 0; i < numBuffers; i++)
+        {
+          auto a = high_resolution_clock::now();
+          if (i >= (size_t)D) // the slot's previous ticket
+            batch.wait(tickets[i % D], no_out ? nullptr : outs[i % D].data());
+          auto m = high_resolution_clock::now();
+          tickets[i % D] = batch.submit(ins[i % D].data(), bufferSize);
+          auto e = high_resolution_clock::now();
+          us[i] = duration<double, std::micro>(e - a).count();
+          us_wait += duration<double, std::micro>(m - a).count();
+          us_submit += duration<double, std::micro>(e - m).count();
+        }
+        for (size_t i = numBuffers > (size_t)D ? numBuffers - D : 0; i < numBuffers; i++)
+          batch.wait(tickets[i % D], outs[i % D].data());
+        auto t2 = high_resolution_clock::now();
+        g_counting = false;
+        duration<double, std::milli> ms = t2 - t1;
+        std::cout << ms.count() << "ms for 2 s x " << streams << " streams = " << 2000.0 * streams / ms.count() << " x real time ("
+                  << ms.count() * 1e3 / (double)numBuffers << " us per buffer: wait " << us_wait / (double)numBuffers << ", submit "
+                  << us_submit / (double)numBuffers << "; per-buffer figures below: wait for the slot + submit)\n";
+        if (std::getenv("NAM_BENCHMODEL_DUMP")) // the first iterations one by one (where do the stalls sit?)
+        {
+          std::cout << "us per iteration, from iteration 64:";
+          for (size_t i = 64; i < std::min<size_t>(numBuffers, 64 + 96); i++)
+            std::cout << " " << (int)(us[i] + 0.5);
+          std::cout << "\n";
+        }
+        report(us, count_allocs);
+        return 0;
+      }
       std::cout << "Running benchmark (" << streams << " streams, host buffers)\n";
       std::vector<double> us(numBuffers, 0.0);
       for (int i = 0; i < 8; i++)

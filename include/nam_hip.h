@@ -245,6 +245,24 @@ NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);
  * calls were issued on; NULL = the batch's own). No-op outside persistent mode. */
 NAM_HIP_API int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream);
 
+/* DSP::process (NAM/dsp.h:97) for callers that keep buffers IN FLIGHT — a server feeding many streams from a network
+ * thread, an offline renderer reading a file ahead: submit copies `in` ([n_streams][in_channels][n_frames], host memory;
+ * the caller may reuse it at once), starts the work and returns a ticket; wait blocks until that buffer's output is
+ * there and copies it to `out` ([n_streams][out_channels][the submit's n_frames]; NULL: completed and discarded). Up to
+ * NAM_HIP_PIPE_SLOTS tickets may be in flight (the next submit fails with NAM_HIP_ERR_INVALID_ARGUMENT until the oldest
+ * has been waited for); buffers are rendered in submit order, a ticket is waited for once, in any order.
+ * In persistent mode (nam_hip_batch_set_persistent) buffers of a multiple of 64 frames are commands of the session, the
+ * input written through the PCIe window, the output stored to host memory by the resident launch itself — nam_a1_q_kernel
+ * and nam_kq_kernel publish every command, so a wait returns while the launch runs on with the buffers behind it; other
+ * kernels' tickets complete when the launch has drained its ring. (The pipeline of nam_a1_q_kernel holds five to six
+ * 64-frame buffers at a time: keep at least eight in flight at that size, four at 256 frames.) Outside persistent mode: pinned staging, copies and the
+ * launch enqueued on the batch's stream, an event behind them. Control calls (Reset, SetSlimmableSize, set_kernel,
+ * synchronize) complete the tickets in flight first; their outputs stay available to wait. The blocking process calls
+ * may be mixed in (tickets in flight complete first). */
+#define NAM_HIP_PIPE_SLOTS 16
+NAM_HIP_API int nam_hip_batch_submit_f32(nam_hip_batch* batch, const float* in, int n_frames, int64_t* out_ticket);
+NAM_HIP_API int nam_hip_batch_wait_f32(nam_hip_batch* batch, int64_t ticket, float* out);
+
 /* Wait for everything enqueued on the batch's own stream (and on the last caller-supplied one). Ends a persistent
  * session: afterwards nothing of the batch is running on the device (a device-wide hipDeviceSynchronize would
  * otherwise wait for the resident launch to expire). */

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
     "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_render_f32", "nam_hip_batch_synchronize",
     "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams", "nam_hip_batch_kernel_name",
-    "nam_hip_batch_set_persistent", "nam_hip_batch_flush",
+    "nam_hip_batch_set_persistent", "nam_hip_batch_flush", "nam_hip_batch_submit_f32", "nam_hip_batch_wait_f32",
     "nam_hip_batch_debug_timeline",
     "nam_hip_model_load_parts", "nam_hip_model_get_string", "nam_hip_model_get_weights", "nam_hip_sample_rate_from_nam",
     "nam_hip_batch_kernel_name_for", "nam_hip_version_support", "nam_hip_device_count",
@@ -136,6 +136,8 @@ def load_library():
     L.nam_hip_batch_process_f64.argtypes = [vp, vp, vp, ci]
     L.nam_hip_batch_process_device.argtypes = [vp, vp, vp, ci, ctypes.c_int64, vp]
     L.nam_hip_batch_render_f32.argtypes = [vp, vp, vp, vp]
+    L.nam_hip_batch_submit_f32.argtypes = [vp, vp, ci, ctypes.POINTER(ctypes.c_int64)]
+    L.nam_hip_batch_wait_f32.argtypes = [vp, ctypes.c_int64, vp]
     L.nam_hip_batch_synchronize.argtypes = [vp]
     L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
     L.nam_hip_batch_get_kernel.argtypes = [vp]
@@ -285,6 +287,7 @@ class Batch:
         h = ctypes.c_void_p()
         _check(self._L.nam_hip_batch_create(model._h, device, n_streams, max_frames, ctypes.byref(h)))
         self._h = h
+        self._ticket_frames = {}  # ticket -> n_frames of the buffers in flight (submit / wait)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -357,6 +360,38 @@ class Batch:
             out = np.empty((self.n_streams, oc, n), dtype=np.float32)
             fn = self._L.nam_hip_batch_process_f32
         _check(fn(self._h, x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n))
+        return out
+
+    PIPE_SLOTS = 16  # NAM_HIP_PIPE_SLOTS
+
+    def submit(self, x: np.ndarray) -> int:
+        """process() for callers that keep buffers in flight (nam_hip_batch_submit_f32): copies x ([n_streams, in_channels,
+        n] or [n_streams, n], float32), starts the work, returns a ticket for wait(). Up to PIPE_SLOTS tickets at a time."""
+        ic = self.model.NumInputChannels()
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[:, None, :]
+        if x.shape[0] != self.n_streams or x.shape[1] != ic:
+            raise ValueError(f"expected input [{self.n_streams}, {ic}, n], got {tuple(x.shape)}")
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        t = ctypes.c_int64(-1)
+        _check(self._L.nam_hip_batch_submit_f32(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[2], ctypes.byref(t)))
+        self._ticket_frames[t.value] = x.shape[2]
+        return t.value
+
+    def wait(self, ticket: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Blocks until the buffer behind `ticket` is rendered; returns [n_streams, out_channels, n] float32 (into `out` if given)."""
+        n = self._ticket_frames.get(ticket)
+        if n is None:  # (the library words the error)
+            _check(self._L.nam_hip_batch_wait_f32(self._h, int(ticket), None))
+            raise ValueError(f"ticket {ticket} is not in flight")
+        oc = self.model.NumOutputChannels()
+        if out is None:
+            out = np.empty((self.n_streams, oc, n), dtype=np.float32)
+        elif out.dtype != np.float32 or not out.flags.c_contiguous or out.size != self.n_streams * oc * n:
+            raise ValueError("out: a C-contiguous float32 array of n_streams x out_channels x n")
+        _check(self._L.nam_hip_batch_wait_f32(self._h, int(ticket), out.ctypes.data_as(ctypes.c_void_p)))
+        del self._ticket_frames[ticket]
         return out
 
     def process_stream(self, x: np.ndarray, block: Optional[int] = None) -> np.ndarray:

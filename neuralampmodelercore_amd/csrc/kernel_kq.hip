@@ -330,6 +330,11 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
           {
             __builtin_amdgcn_s_sleep(8);
             v = ring_load(na);
+            // (a lingering session's launch: as below — a workgroup that is up to date stays for the commands to come, unless
+            // the host says that none will)
+            if (a.p_linger > 100 && (unsigned)(v >> 32) != na + 1
+                && (unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == na)
+              break;
           } while ((unsigned)(v >> 32) != na + 1 && (long long)wall_clock64() < t_end);
         }
         if (lane == 0)
@@ -509,8 +514,11 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
     if constexpr (HEAD)
     {
       const float yout = head_scale * acc0[0];
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, frame < nvalid ? frame * 4 : (int)kOob, uni((int)boff),
-                                            PERSIST && !kOutHost ? 17 : 0);
+      if (kOutHost && a.p_out_host == 2) // ticketed host buffers: written through (kernel_a1_q.hip)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, frame < nvalid ? frame * 4 : (int)kOob, uni((int)boff), 17);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, frame < nvalid ? frame * 4 : (int)kOob, uni((int)boff),
+                                              PERSIST && !kOutHost ? 17 : 0);
     }
     else
     {
@@ -607,7 +615,23 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
       else if constexpr (PERSIST)
       {
         done++;
-        if (lane == 0 && (done & 15u) == 0u) // progress for the host's ring bookkeeping (not a completion signal)
+        if (kOutHost && a.p_out_host == 2)
+        {
+          // ... and the workgroup counts itself in behind them (kernel_a1_q.hip; kernels.h: p_cmd_count / p_cmd_done)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned before = 0u;
+          const unsigned cslot = (done - 1u) & (unsigned)a.p_ring_mask;
+          if (lane == 0)
+            before = __hip_atomic_fetch_add(a.p_cmd_count + cslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)uni((int)before) == gridDim.x - 1u && lane == 0)
+          {
+            __hip_atomic_store(a.p_cmd_count + cslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.p_cmd_done + cslot, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          if (lane == 0 && (done & 15u) == 0u)
+            __hip_atomic_store(a.p_prog + blockIdx.x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        else if (lane == 0 && (done & 15u) == 0u) // progress for the host's ring bookkeeping (not a completion signal)
           __hip_atomic_store(a.p_prog + blockIdx.x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       if constexpr (FIRST)
@@ -622,11 +646,16 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
             // the early look missed: look again; while the later stages still work, for a microsecond (bounded: the launch
             // never waits for a command)
             v = ring_load(tag - 1u);
-            const long long t_end = (long long)wall_clock64() + 100; // 1 us of the 100 MHz clock
+            const long long t_end = (long long)wall_clock64() + (a.p_linger > 0 ? a.p_linger : 100); // 1 us of the 100 MHz clock unless told otherwise (kernel_a1_q.hip)
             while ((unsigned)(v >> 32) != tag && (long long)wall_clock64() < t_end)
             {
               __builtin_amdgcn_s_sleep(16);
               v = ring_load(tag - 1u);
+              // a launch that lingers (ticketed host buffers) leaves at once when the host says that nothing follows the
+              // commands this workgroup has consumed (nam_hip_api.cpp: kPRingTail)
+              if (a.p_linger > 100 && (unsigned)(v >> 32) != tag
+                  && (unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag - 1u)
+                break;
             }
           }
           // ONE view of the ring slot for the whole wave (lane 0's): the lanes' loads are separate memory requests, and a

@@ -103,7 +103,16 @@ struct A1Args
   unsigned long long p_cmd0; // ... and this is the next command (the ring is not read for it)
   int p_grace; // ticks (100 MHz) a fresh launch looks for its first doorbell before it leaves again
   int p_out_host; // the session's output window is HOST memory (nam_a1_p4_kernel: kOutHost — plain result stores, ring
-                  // appends written through, one system-scope release fence before the completion word)
+                  // appends written through, one system-scope release fence before the completion word). 2 (nam_a1_q_kernel,
+                  // nam_kq_kernel): ticketed host buffers — results written through and p_prog published after EVERY command,
+                  // behind the results: the host takes a buffer's output while the launch runs on (nam_hip_batch_wait_f32)
+  int p_linger; // ticks (100 MHz) the launch looks for the NEXT command when it finds the ring empty, before it leaves (nam_a1_q_kernel,
+                // nam_kq_kernel; 0 = 1 us, the other kernels' constant): a ticket session's host hands a buffer in every 5 - 15 us
+  // ticketed host buffers (p_out_host == 2): p_cmd_count[c & p_ring_mask] (device memory) counts the workgroups that have finished
+  // command c and made its results visible; the last one zeroes it and stores c + 1 to p_cmd_done[c & p_ring_mask] (host-mapped):
+  // ONE word for the host to poll per buffer, one PCIe write per command
+  unsigned* p_cmd_count;
+  unsigned* p_cmd_done;
   long long* dbg; // optional: per-job phase timestamps of workgroup 0 (profiling builds / tools only), else nullptr
 };
 

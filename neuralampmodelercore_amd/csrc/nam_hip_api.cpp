@@ -124,6 +124,12 @@ namespace
 // Persistent block mode (nam_hip_batch_set_persistent): one resident launch of nam_a1_p2_kernel per session, fed one
 // command per 64-frame buffer through a device-memory ring (kernel_a1_p2.hip, PERSIST).
 constexpr unsigned kPRing = 1024; // commands in flight at most (power of two)
+// behind the ring: d_ring[kPRing] = the "leave" word of sessions whose launch lingers (ticketed host buffers: A1Args::p_linger) —
+// the host stores the session's command count there when it wants the launch gone (a flush, the end of the session): a
+// workgroup that has consumed exactly that many commands and finds no next one leaves at once instead of lingering
+constexpr unsigned kPRingTail = 8;
+constexpr int kTicketLinger = 20000; // 200 us of the 100 MHz clock: workgroups drift apart by up to NAM_HIP_PIPE_SLOTS buffers (16 x 5.3 us) —
+                                     // the one in front must outwait the host, which hands the next buffer in when the LAST one has finished an old one
 struct PersistSession
 {
   bool enabled = false; // the caller opted in
@@ -137,6 +143,8 @@ struct PersistSession
   unsigned* h_words = nullptr; // host-mapped: [0, n_wg) progress, [n_wg, 2 n_wg) completion (bit 31 = exited)
   unsigned* d_words = nullptr; // the same words as the device sees them
   unsigned* d_cons = nullptr; // device memory: commands consumed per workgroup (where its next launch resumes)
+  unsigned* d_cmd_count = nullptr; // device memory [kPRing]: workgroups through command c (A1Args::p_cmd_count), zero between commands
+  unsigned *h_cmd_done = nullptr, *d_cmd_done = nullptr; // host-mapped [kPRing]: c + 1 once every workgroup is through command c
   hipStream_t last_caller = nullptr; // the stream the last doorbell was rung on
   int grace = 0; // A1Args::p_grace of the next launch
   long long seq0 = -1; // A1Args::p_seq0 / p_cmd0 of the next launch
@@ -160,6 +168,24 @@ struct PersistSession
   // (NAM_HIP_PERSIST_REBASE_AT overrides it: tests)
   unsigned rebase_at = 0x40000000u;
   long timeout_ms = 20000; // a resident launch that makes no progress for this long is a device failure (NAM_HIP_PERSIST_TIMEOUT_MS)
+  // developer statistics (NAM_HIP_SESSION_STATS=1: printed when the batch is destroyed)
+  unsigned long long n_launches = 0, n_host_doorbells = 0, n_stream_doorbells = 0, n_starts = 0, n_flush_relaunches = 0;
+  double t_poll = 0, t_out = 0, t_in = 0, t_cmd = 0, t_poll_max = 0, t_out_max = 0, t_in_max = 0, t_cmd_max = 0; // us (NAM_HIP_SESSION_STATS)
+  unsigned long long n_waits = 0, n_polls = 0; // ticket waits, looks at the buffer's completion word
+  unsigned epoch = 0; // counts session starts (a ticket of an earlier session is complete: sessions end flushed)
+  bool prog_completes = false; // the running launch publishes its progress word behind every command's results (A1Args::p_out_host == 2)
+};
+
+// One buffer in flight between nam_hip_batch_submit_f32 and nam_hip_batch_wait_f32
+struct PipeSlot
+{
+  long long ticket = -1;
+  bool in_flight = false;
+  int n_frames = 0;
+  int how = 0; // 0: a command range of the host-mapped session | 1: copies + launch on the batch's stream, `done` behind them | 2: rendered by a blocking call, kept in `held`
+  unsigned seq_end = 0, epoch = 0; // how == 0: the session's command count behind this buffer, the session it belongs to
+  hipEvent_t done = nullptr;
+  std::vector<float> held;
 };
 } // namespace
 
@@ -184,6 +210,15 @@ struct nam_hip_batch
   float* in_bar = nullptr; // one address for both sides
   float *h_out_map = nullptr, *d_out_map = nullptr; // host address / the same memory as the device sees it
   bool map_failed = false; // the allocation was refused once: the copying path stays
+  // the ticketed entry points (nam_hip_batch_submit_f32) have windows of their own, the same two kinds of memory,
+  // NAM_HIP_PIPE_SLOTS buffers deep: [slot][row][max_frames], slot = ticket % NAM_HIP_PIPE_SLOTS
+  float* pipe_in_bar = nullptr;
+  float *pipe_h_out_map = nullptr, *pipe_d_out_map = nullptr;
+  bool pipe_map_failed = false;
+  PipeSlot pipe[NAM_HIP_PIPE_SLOTS];
+  long long pipe_next = 0; // the next ticket
+  bool pipe_session = false; // the session serves ticketed buffers: its launches publish every command (PersistSession::prog_completes)
+  float *pipe_h_in = nullptr, *pipe_h_out = nullptr, *pipe_d_in = nullptr, *pipe_d_out = nullptr; // staging of the copying form ([slot][row][max_frames])
   int kernel = NAM_HIP_KERNEL_AUTO;
   long long* dbg = nullptr; // device buffer of the profiling instantiation (nam_hip_batch_debug_timeline)
   bool was_reset = false;
@@ -677,6 +712,8 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.p_cons = a.p_prog = a.p_done = nullptr;
       a.p_grace = 0;
       a.p_out_host = 0;
+      a.p_linger = 0;
+      a.p_cmd_count = a.p_cmd_done = nullptr;
       a.p_seq0 = -1;
       a.p_cmd0 = 0;
       if (kernel == NAM_HIP_KERNEL_A1_IL)
@@ -707,7 +744,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_prog = b->ps.d_words;
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
-          a.p_out_host = b->ps.out_is_host ? 1 : 0;
+          a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
+          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok) ? kTicketLinger : 0;
+          a.p_cmd_count = b->ps.d_cmd_count;
+          a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
@@ -747,7 +787,10 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_prog = b->ps.d_words;
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
-          a.p_out_host = b->ps.out_is_host ? 1 : 0;
+          a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
+          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok) ? kTicketLinger : 0;
+          a.p_cmd_count = b->ps.d_cmd_count;
+          a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
@@ -1017,6 +1060,7 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
     NAM_HIP_CHECK(hipStreamWaitEvent(ps.kstream, ps.order, 0));
     ps.need_order = false;
   }
+  ps.n_launches++;
   ps.grace = grace_us * 100;
   ps.seq0 = seq0;
   ps.cmd0 = cmd0;
@@ -1025,6 +1069,18 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   for (int w = 0; w < ps.n_wg; w++)
     __atomic_and_fetch(&ps.h_words[ps.done_off + w], 0x7fffffffu, __ATOMIC_RELAXED);
   ps.outstanding = true;
+  // ticketed host buffers: nam_a1_q_kernel / nam_kq_kernel publish their progress word behind every command's results
+  // (the other kernels' progress words are bookkeeping only: their tickets complete when the launch has left)
+  {
+    const Plan& p = *g.plan;
+    ps.prog_completes = b->pipe_session && ps.out_is_host && !b->no_pipe
+                        && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || (ps.kind == PERSIST_KP && kq_runs(b, p)));
+    // ... and linger: a workgroup that finds itself up to date when a launch starts (another one's backlog was the reason for
+    // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
+    // linger and leave before the next launch could pick it up again
+    if (ps.prog_completes && ps.host_store_ok)
+      ps.grace = std::max(ps.grace, kTicketLinger);
+  }
   const int keep = b->kernel;
   if (ps.kind == PERSIST_A1_P2)
     b->kernel = NAM_HIP_KERNEL_A1_IL;
@@ -1067,11 +1123,26 @@ struct PersistWatch
 
 // Blocks until every submitted command has been consumed by every workgroup and its results are visible.
 // `caller`: the stream the doorbells were rung on.
+int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool whole);
+inline void push_out_host_stores();
 int persist_flush(nam_hip_batch* b, hipStream_t caller)
+{
+  return b->ps.active ? persist_wait(b, caller, b->ps.seq, true) : NAM_HIP_OK;
+}
+
+// `whole`: every submitted command (target == seq) and the launch gone. Otherwise: the first `target` commands of the
+// session rendered and visible — the launch may run on (its progress words count then, if it publishes them per command).
+int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool whole)
 {
   PersistSession& ps = b->ps;
   if (!ps.active)
     return NAM_HIP_OK;
+  if (whole && ps.outstanding && ps.prog_completes && ps.host_store_ok)
+  {
+    // a lingering launch: tell it that nothing follows command `seq` (kPRingTail)
+    __atomic_store_n(&ps.d_ring[kPRing], (unsigned long long)ps.seq, __ATOMIC_RELEASE);
+    push_out_host_stores();
+  }
   PersistWatch watch;
   bool ended = false; // the stream reported the launch complete: its words are final
   // The workgroups publish their count (behind a release fence behind their last results) when they LEAVE — which
@@ -1081,6 +1152,25 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
   int relaunches = 0;
   for (;;)
   {
+    if (!whole && ps.prog_completes)
+    {
+      // ONE word: stored by the last workgroup through the last command of the buffer, behind everybody's results
+      // (A1Args::p_cmd_done). A short spin on it between looks at the launch itself (the 2 n_wg words below, which the
+      // device writes all the time: a pass over them costs the host microseconds).
+      const unsigned* flag = &ps.h_cmd_done[(target - 1u) & (kPRing - 1u)];
+      for (int spin = 0; spin < 512; spin++)
+      {
+        ps.n_polls++;
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == target)
+        {
+          ps.n_waits++;
+          return NAM_HIP_OK; // (whether a launch is still running is the next call's question)
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+      }
+    }
     unsigned lo = ~0u, all_left = 0x80000000u;
     for (int w = 0; w < ps.n_wg; w++)
     {
@@ -1088,6 +1178,8 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
       lo = std::min(lo, v & 0x7fffffffu);
       all_left &= v;
     }
+    if (!whole && (int)(lo - target) >= 0)
+      return NAM_HIP_OK;
     if (ps.outstanding && !all_left)
     {
       if (ended) // the launch is gone and a workgroup never said goodbye: it died
@@ -1115,6 +1207,7 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
         NAM_HIP_CHECK(hipStreamSynchronize(ps.last_caller));
       delivered = true;
     }
+    ps.n_flush_relaunches++;
     if (++relaunches > 64)
       return fail(NAM_HIP_ERR_DEVICE, "persistent session: submitted buffers were not consumed");
     const int rc = persist_launch(b, 0);
@@ -1140,14 +1233,19 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
   const int n = b->n_streams; // (a session holds every stream of the batch)
   if (!ps.d_ring)
   {
-    ps.host_store_ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long),
+    ps.host_store_ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ps.d_ring), (kPRing + kPRingTail) * sizeof(unsigned long long),
                                              hipDeviceMallocFinegrained) == hipSuccess;
     if (!ps.host_store_ok)
     {
       (void)hipGetLastError();
-      NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_ring), kPRing * sizeof(unsigned long long)));
+      NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_ring), (kPRing + kPRingTail) * sizeof(unsigned long long)));
     }
     NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_cons), (size_t)b->n_streams * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_cmd_count), kPRing * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipMemset(ps.d_cmd_count, 0, kPRing * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_cmd_done), kPRing * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+    NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_cmd_done), ps.h_cmd_done, 0));
+    std::memset(ps.h_cmd_done, 0, kPRing * sizeof(unsigned));
     NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_words), 2 * (size_t)b->n_streams * sizeof(unsigned),
                                 hipHostMallocMapped | hipHostMallocCoherent));
     NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_words), ps.h_words, 0));
@@ -1159,6 +1257,7 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     NAM_HIP_CHECK(hipStreamCreateWithPriority(&ps.kstream, hipStreamNonBlocking, prio_hi));
     NAM_HIP_CHECK(hipEventCreateWithFlags(&ps.order, hipEventDisableTiming));
     NAM_HIP_CHECK(hipMemset(ps.d_ring, 0, kPRing * sizeof(unsigned long long)));
+    NAM_HIP_CHECK(hipMemset(ps.d_ring + kPRing, 0xff, kPRingTail * sizeof(unsigned long long))); // (the "leave" word: no count)
     NAM_HIP_CHECK(hipDeviceSynchronize());
     NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
     std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
@@ -1174,8 +1273,11 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     // ring slots carry tags near the old count, which a small count never matches; cleared anyway.
     NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
     NAM_HIP_CHECK(hipMemset(ps.d_ring, 0, kPRing * sizeof(unsigned long long)));
+    NAM_HIP_CHECK(hipMemset(ps.d_ring + kPRing, 0xff, kPRingTail * sizeof(unsigned long long))); // (the "leave" word: no count)
     NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipMemset(ps.d_cmd_count, 0, kPRing * sizeof(unsigned)));
     NAM_HIP_CHECK(hipDeviceSynchronize());
+    std::memset(ps.h_cmd_done, 0, kPRing * sizeof(unsigned)); // (tags of the old numbering)
     for (int w = 0; w < b->n_streams; w++)
     {
       ps.h_words[w] = 0u;
@@ -1221,6 +1323,8 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
   ps.n_wg = kind == PERSIST_LSTM_ROW ? (n + 3) / 4 : n;
   ps.active = true;
   ps.need_order = true;
+  ps.n_starts++;
+  ps.epoch++;
   return NAM_HIP_OK;
 }
 
@@ -1252,7 +1356,7 @@ int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long
     // a different window: the session ends, the next one starts here. So does a session whose sequence numbers have reached
     // the rebase mark: one that never ends by itself (the C++ adapter's default: a session per Reset, flushes only) would
     // otherwise run its count into bit 31, the "left" flag of the completion words; persist_start renumbers from 0.
-    if (stride != ps.stride || off_in != off_out || off_in < 0 || off_in > 0x3fffffffl || ps.seq >= ps.rebase_at)
+    if (stride != ps.stride || off_in != off_out || off_in < 0 || off_in > 0x1fff0000l /* (the kernels address a window through a 2 GB buffer descriptor) */ || ps.seq >= ps.rebase_at)
     {
       const int rc = persist_stop(b);
       if (rc != NAM_HIP_OK)
@@ -1320,6 +1424,7 @@ int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long
   // device-side write operation, which costs the host ~4 us and the device a small kernel per buffer).
   if (ps.host_store_ok && (!ps.last_caller || ps.last_caller == caller) && hipStreamQuery(caller) == hipSuccess)
   {
+    ps.n_host_doorbells++;
     __atomic_store_n(&ps.d_ring[slot], cmd, __ATOMIC_RELEASE);
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_sfence(); // (the BAR mapping may be write-combining: push the store out now)
@@ -1346,6 +1451,7 @@ int persist_submit_block(nam_hip_batch* b, const float* d_in, float* d_out, long
       if (rc != NAM_HIP_OK)
         return rc;
     }
+    ps.n_stream_doorbells++;
     NAM_HIP_CHECK(hipStreamWriteValue64(caller, ps.d_ring + slot, cmd, 0));
   }
   ps.seq++;
@@ -1364,6 +1470,10 @@ void persist_free(nam_hip_batch* b)
     (void)hipFree(ps.d_ring);
   if (ps.d_cons)
     (void)hipFree(ps.d_cons);
+  if (ps.d_cmd_count)
+    (void)hipFree(ps.d_cmd_count);
+  if (ps.h_cmd_done)
+    (void)hipHostFree(ps.h_cmd_done);
   if (ps.h_words)
     (void)hipHostFree(ps.h_words);
   if (ps.kstream)
@@ -1485,60 +1595,111 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
 
 // The blocking entry points inside a persistent session: the kernel reads the buffer from and writes it to HOST-MAPPED
 // memory (float32 rows [stream][channel][max_frames]); in_f32 / in_f64 and out_f32 / out_f64: exactly one of each.
-// Returns 0 when the buffer went through the session, 1 when the mode does not apply (not enabled / not eligible /
-// n_frames not a multiple of 64), < 0 on failure.
-int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_f64, float* out_f32, double* out_f64, int n_frames)
+// The host-mapped windows of the session's blocking (`slots` = 1: nam_hip_batch::in_bar, h_out_map) or ticketed
+// (NAM_HIP_PIPE_SLOTS: pipe_in_bar, pipe_h_out_map) entry points. false: no such memory here (the copying path serves the call).
+bool host_windows(nam_hip_batch* b, int slots, float*& in_bar, float*& h_out_map, float*& d_out_map, bool& failed)
+{
+  if (failed)
+    return false;
+  if (in_bar)
+    return true;
+  const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
+  const size_t pitch = (size_t)b->n_streams * std::max(ic, oc) * b->max_frames; // (one slot; the same for both windows: a command carries ONE offset)
+  if (hipExtMallocWithFlags(reinterpret_cast<void**>(&in_bar), pitch * slots * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    in_bar = nullptr;
+    failed = true; // no host-writable device memory here
+    return false;
+  }
+  // all three or none: a later call must not find the input window without the output window (it would submit commands
+  // with a null output base and copy from a null mapping)
+  if (hipHostMalloc(reinterpret_cast<void**>(&h_out_map), pitch * slots * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+      || hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out_map), h_out_map, 0) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    if (h_out_map)
+      (void)hipHostFree(h_out_map);
+    (void)hipFree(in_bar);
+    in_bar = nullptr;
+    h_out_map = nullptr;
+    d_out_map = nullptr;
+    failed = true; // the copying path takes over
+    return false;
+  }
+  return true;
+}
+
+// A row of audio into the PCIe window. Non-temporal stores: the window is write-combining memory, where glibc's memcpy
+// (rep movsb from a few KB up) moves 8 GB/s and 16-byte streaming stores 40 (tools/src/host_window_copy.hip,
+// profiles/r04/host_window_copy.txt).
+inline void copy_to_window(float* dst, const float* src, size_t n)
+{
+#if defined(__x86_64__)
+  size_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 15u) != 0)
+  {
+    dst[i] = src[i];
+    i++;
+  }
+  typedef float v4f __attribute__((vector_size(16)));
+  typedef float v4f_u __attribute__((vector_size(16), aligned(4)));
+  for (; i + 4 <= n; i += 4)
+    __builtin_nontemporal_store(*reinterpret_cast<const v4f_u*>(src + i), reinterpret_cast<v4f*>(dst + i));
+  for (; i < n; i++)
+    dst[i] = src[i];
+#else
+  std::memcpy(dst, src, n * sizeof(float));
+#endif
+}
+
+bool host_mapped_applies(nam_hip_batch* b, int n_frames)
 {
   if (!b->ps.enabled || n_frames % kBlock != 0 || n_frames > kPersistMaxFrames || !persist_eligible(b))
-    return 1;
+    return false;
   for (auto& g0 : b->groups)
     if (!g0.streams.empty() && g0.plan->arch == ARCH_WAVENET && g0.state_family >= 0 && g0.state_family != persist_family(b, g0))
-      return 1; // (the copying path reports the layout clash)
-  const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
-  const long stride = b->max_frames;
-  if (b->map_failed)
-    return 1;
-  if (!b->in_bar)
-  {
-    const size_t in_floats = (size_t)b->n_streams * ic * b->max_frames, out_floats = (size_t)b->n_streams * oc * b->max_frames;
-    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&b->in_bar), in_floats * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess)
-    {
-      (void)hipGetLastError();
-      b->in_bar = nullptr;
-      b->map_failed = true; // no host-writable device memory here
-      return 1;
-    }
-    // all three or none: a later call must not find the input window without the output window (it would submit commands
-    // with a null output base and copy from a null mapping)
-    if (hipHostMalloc(reinterpret_cast<void**>(&b->h_out_map), out_floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
-        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_out_map), b->h_out_map, 0) != hipSuccess)
-    {
-      (void)hipGetLastError();
-      if (b->h_out_map)
-        (void)hipHostFree(b->h_out_map);
-      (void)hipFree(b->in_bar);
-      b->in_bar = nullptr;
-      b->h_out_map = nullptr;
-      b->d_out_map = nullptr;
-      b->map_failed = true; // the copying path takes over
-      return 1;
-    }
-  }
-  const size_t rows_in = (size_t)b->n_streams * ic, rows_out = (size_t)b->n_streams * oc;
-  for (size_t r = 0; r < rows_in; r++)
-  {
-    float* dst = b->in_bar + r * stride;
-    if (in_f32)
-      std::memcpy(dst, in_f32 + r * n_frames, (size_t)n_frames * sizeof(float));
-    else // double -> float exactly as _set_condition_array does (NAM/wavenet/model.cpp:817)
-      for (int i = 0; i < n_frames; i++)
-        dst[i] = (float)in_f64[r * n_frames + i];
-  }
+      return false; // (the copying path reports the layout clash)
+  return true;
+}
+
+inline void push_out_host_stores()
+{
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_sfence(); // (write-combining stores through the BAR: out before the command that points at them)
 #else
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
 #endif
+}
+
+bool pipe_busy(const nam_hip_batch* b)
+{
+  for (const PipeSlot& sl : b->pipe)
+    if (sl.in_flight)
+      return true;
+  return false;
+}
+
+// Returns 0 when the buffer went through the session, 1 when the mode does not apply (not enabled / not eligible /
+// n_frames not a multiple of 64), < 0 on failure.
+int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_f64, float* out_f32, double* out_f64, int n_frames)
+{
+  if (!host_mapped_applies(b, n_frames) || !host_windows(b, 1, b->in_bar, b->h_out_map, b->d_out_map, b->map_failed))
+    return 1;
+  const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
+  const long stride = b->max_frames;
+  b->pipe_session = false; // (tickets in flight live in windows of their own: this call's window ends their session, flushed)
+  const size_t rows_in = (size_t)b->n_streams * ic, rows_out = (size_t)b->n_streams * oc;
+  for (size_t r = 0; r < rows_in; r++)
+  {
+    float* dst = b->in_bar + r * stride;
+    if (in_f32)
+      copy_to_window(dst, in_f32 + r * n_frames, (size_t)n_frames);
+    else // double -> float exactly as _set_condition_array does (NAM/wavenet/model.cpp:817)
+      for (int i = 0; i < n_frames; i++)
+        dst[i] = (float)in_f64[r * n_frames + i];
+  }
+  push_out_host_stores();
   b->one_buffer_call = n_frames == kBlock; // (one command, then the caller waits: the stages of a pipeline would only queue up)
   b->short_blocking_call = n_frames <= 4 * kBlock;
   const int rc = persist_submit(b, b->in_bar, b->d_out_map, n_frames, stride, b->stream);
@@ -1561,6 +1722,123 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
       for (int i = 0; i < n_frames; i++)
         out_f64[r * n_frames + i] = (double)src[i];
   }
+  return NAM_HIP_OK;
+}
+
+inline double stat_now_us()
+{
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool stats_on()
+{
+  static const bool on = [] { const char* e = std::getenv("NAM_HIP_SESSION_STATS"); return e && e[0] == '1'; }();
+  return on;
+}
+
+// ---- ticketed host buffers (include/nam_hip.h: nam_hip_batch_submit_f32 / nam_hip_batch_wait_f32) ----
+int pipe_submit(nam_hip_batch* b, const float* in, int n_frames, PipeSlot& sl, int slot)
+{
+  const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
+  const size_t rows_in = (size_t)b->n_streams * ic, rows_out = (size_t)b->n_streams * oc;
+  sl.n_frames = n_frames;
+  if (host_mapped_applies(b, n_frames) && host_windows(b, NAM_HIP_PIPE_SLOTS, b->pipe_in_bar, b->pipe_h_out_map, b->pipe_d_out_map, b->pipe_map_failed))
+  {
+    // the session: the input goes through the PCIe window into the slot's rows, the commands follow it; the resident
+    // launch writes the slot's rows of the host-side window
+    const long stride = b->max_frames, at = (long)slot * (long)std::max(rows_in, rows_out) * b->max_frames;
+    const double t0 = stats_on() ? stat_now_us() : 0.0;
+    for (size_t r = 0; r < rows_in; r++)
+      copy_to_window(b->pipe_in_bar + at + r * stride, in + r * n_frames, (size_t)n_frames);
+    push_out_host_stores();
+    const double t1 = stats_on() ? stat_now_us() : 0.0;
+    b->pipe_session = true;
+    const int rc = persist_submit(b, b->pipe_in_bar + at, b->pipe_d_out_map + at, n_frames, stride, b->stream);
+    if (stats_on())
+    {
+      const double t2 = stat_now_us();
+      b->ps.t_in += t1 - t0, b->ps.t_cmd += t2 - t1;
+      b->ps.t_in_max = std::max(b->ps.t_in_max, t1 - t0), b->ps.t_cmd_max = std::max(b->ps.t_cmd_max, t2 - t1);
+    }
+    if (rc != NAM_HIP_OK)
+      return rc < 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: the host-mapped buffer was refused");
+    sl.how = 0;
+    sl.seq_end = b->ps.seq;
+    sl.epoch = b->ps.epoch;
+    return NAM_HIP_OK;
+  }
+  if (!b->ps.enabled || !persist_eligible(b))
+  {
+    // launches on the batch's stream: pinned staging in, copy, launch, copy, pinned staging out — all enqueued, an event behind them
+    const size_t slot_in = rows_in * b->max_frames, slot_out = rows_out * b->max_frames;
+    if (!b->pipe_h_in)
+    {
+      NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->pipe_h_in), slot_in * NAM_HIP_PIPE_SLOTS * sizeof(float), hipHostMallocDefault));
+      NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b->pipe_h_out), slot_out * NAM_HIP_PIPE_SLOTS * sizeof(float), hipHostMallocDefault));
+      NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b->pipe_d_in), slot_in * NAM_HIP_PIPE_SLOTS * sizeof(float)));
+      NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b->pipe_d_out), slot_out * NAM_HIP_PIPE_SLOTS * sizeof(float)));
+    }
+    if (!sl.done)
+      NAM_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    float *hi = b->pipe_h_in + slot * slot_in, *ho = b->pipe_h_out + slot * slot_out;
+    float *di = b->pipe_d_in + slot * slot_in, *dn = b->pipe_d_out + slot * slot_out;
+    std::memcpy(hi, in, rows_in * n_frames * sizeof(float));
+    NAM_HIP_CHECK(hipMemcpyAsync(di, hi, rows_in * n_frames * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    const int rc = nam_hip_batch_process_device(b, di, dn, n_frames, n_frames, nullptr);
+    if (rc != NAM_HIP_OK)
+      return rc;
+    NAM_HIP_CHECK(hipMemcpyAsync(ho, dn, rows_out * n_frames * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    NAM_HIP_CHECK(hipEventRecord(sl.done, b->stream));
+    sl.how = 1;
+    return NAM_HIP_OK;
+  }
+  // a session batch with a ragged length (or without host-mapped memory): rendered now, handed out by the wait
+  sl.held.resize(rows_out * n_frames);
+  const int rc = nam_hip_batch_process_f32(b, in, sl.held.data(), n_frames);
+  if (rc != NAM_HIP_OK)
+    return rc;
+  sl.how = 2;
+  return NAM_HIP_OK;
+}
+
+int pipe_wait(nam_hip_batch* b, PipeSlot& sl, int slot, float* out)
+{
+  const int oc = b->model->spec->out_channels();
+  const size_t rows_out = (size_t)b->n_streams * oc;
+  const int n_frames = sl.n_frames;
+  if (sl.how == 0)
+  {
+    const double t0 = stats_on() ? stat_now_us() : 0.0;
+    if (b->ps.active && sl.epoch == b->ps.epoch) // (a session that has ended ended flushed)
+    {
+      const int rc = persist_wait(b, b->stream, sl.seq_end, false);
+      if (rc != NAM_HIP_OK)
+        return rc;
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const double t1 = stats_on() ? stat_now_us() : 0.0;
+    if (out)
+    {
+      const size_t rows_in = (size_t)b->n_streams * b->model->spec->in_channels();
+      const long stride = b->max_frames, at = (long)slot * (long)std::max(rows_in, rows_out) * b->max_frames;
+      for (size_t r = 0; r < rows_out; r++)
+        std::memcpy(out + r * n_frames, b->pipe_h_out_map + at + r * stride, (size_t)n_frames * sizeof(float));
+    }
+    if (stats_on())
+    {
+      const double t2 = stat_now_us();
+      b->ps.t_poll += t1 - t0, b->ps.t_out += t2 - t1;
+      b->ps.t_poll_max = std::max(b->ps.t_poll_max, t1 - t0), b->ps.t_out_max = std::max(b->ps.t_out_max, t2 - t1);
+    }
+  }
+  else if (sl.how == 1)
+  {
+    NAM_HIP_CHECK(hipEventSynchronize(sl.done));
+    if (out)
+      std::memcpy(out, b->pipe_h_out + (size_t)slot * rows_out * b->max_frames, rows_out * n_frames * sizeof(float));
+  }
+  else if (out)
+    std::memcpy(out, sl.held.data(), rows_out * n_frames * sizeof(float));
+  sl.in_flight = false;
   return NAM_HIP_OK;
 }
 
@@ -1912,6 +2190,17 @@ void nam_hip_batch_destroy(nam_hip_batch* batch)
     return;
   (void)hipSetDevice(batch->device);
   (void)quiesce(batch);
+  if (const char* e = std::getenv("NAM_HIP_SESSION_STATS"))
+    if (e[0] == '1' && batch->ps.n_starts)
+      std::fprintf(stderr, "nam_hip session: %llu starts, %llu launches (%llu from a wait / flush), %llu commands stored by the host, %llu through the stream\n",
+                   batch->ps.n_starts, batch->ps.n_launches, batch->ps.n_flush_relaunches, batch->ps.n_host_doorbells, batch->ps.n_stream_doorbells);
+  if (const char* e = std::getenv("NAM_HIP_SESSION_STATS"))
+    if (e[0] == '1' && batch->ps.n_waits)
+      std::fprintf(stderr, "nam_hip tickets: %llu waits, %.1f looks at the completion word each\n", batch->ps.n_waits, (double)batch->ps.n_polls / batch->ps.n_waits);
+  if (stats_on() && batch->ps.n_waits)
+    std::fprintf(stderr, "nam_hip tickets, us per buffer (max): wait for the count %.2f (%.1f), copy out %.2f (%.1f), copy in %.2f (%.1f), commands %.2f (%.1f)\n",
+                 batch->ps.t_poll / batch->ps.n_waits, batch->ps.t_poll_max, batch->ps.t_out / batch->ps.n_waits, batch->ps.t_out_max,
+                 batch->ps.t_in / batch->ps.n_waits, batch->ps.t_in_max, batch->ps.t_cmd / batch->ps.n_waits, batch->ps.t_cmd_max);
   persist_free(batch);
   for (auto& g : batch->groups)
     free_group(g);
@@ -1925,6 +2214,21 @@ void nam_hip_batch_destroy(nam_hip_batch* batch)
     (void)hipFree(batch->in_bar);
   if (batch->h_out_map)
     (void)hipHostFree(batch->h_out_map);
+  if (batch->pipe_in_bar)
+    (void)hipFree(batch->pipe_in_bar);
+  if (batch->pipe_h_out_map)
+    (void)hipHostFree(batch->pipe_h_out_map);
+  if (batch->pipe_h_in)
+    (void)hipHostFree(batch->pipe_h_in);
+  if (batch->pipe_h_out)
+    (void)hipHostFree(batch->pipe_h_out);
+  if (batch->pipe_d_in)
+    (void)hipFree(batch->pipe_d_in);
+  if (batch->pipe_d_out)
+    (void)hipFree(batch->pipe_d_out);
+  for (PipeSlot& sl : batch->pipe)
+    if (sl.done)
+      (void)hipEventDestroy(sl.done);
   if (batch->stream)
     (void)hipStreamDestroy(batch->stream);
   delete batch;
@@ -2090,6 +2394,43 @@ int nam_hip_batch_process_f32(nam_hip_batch* batch, const float* in, float* out,
   NAM_HIP_CHECK(hipMemcpyAsync(out, batch->d_out, out_bytes, hipMemcpyDeviceToHost, batch->stream));
   NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
   return NAM_HIP_OK;
+}
+
+int nam_hip_batch_submit_f32(nam_hip_batch* batch, const float* in, int n_frames, int64_t* out_ticket)
+{
+  if (!batch || !in || !out_ticket || n_frames <= 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_submit_f32: bad argument");
+  if (n_frames > batch->max_frames)
+    return fail(NAM_HIP_ERR_TOO_MANY_FRAMES, "nam_hip_batch_submit_f32: n_frames exceeds max_frames");
+  const int slot = (int)(batch->pipe_next % NAM_HIP_PIPE_SLOTS);
+  PipeSlot& sl = batch->pipe[slot];
+  if (sl.in_flight)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_submit_f32: " + std::to_string(NAM_HIP_PIPE_SLOTS) + " buffers are in flight; wait for ticket "
+                                                + std::to_string(sl.ticket) + " first");
+  return guarded([&]() -> int {
+    NAM_HIP_CHECK(hipSetDevice(batch->device));
+    const int rc = pipe_submit(batch, in, n_frames, sl, slot);
+    if (rc != NAM_HIP_OK)
+      return rc;
+    sl.ticket = batch->pipe_next++;
+    sl.in_flight = true;
+    *out_ticket = sl.ticket;
+    return NAM_HIP_OK;
+  });
+}
+
+int nam_hip_batch_wait_f32(nam_hip_batch* batch, int64_t ticket, float* out)
+{
+  if (!batch || ticket < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_wait_f32: bad argument");
+  const int slot = (int)(ticket % NAM_HIP_PIPE_SLOTS);
+  PipeSlot& sl = batch->pipe[slot];
+  if (!sl.in_flight || sl.ticket != ticket)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_wait_f32: ticket " + std::to_string(ticket) + " is not in flight (never issued, or waited for already)");
+  return guarded([&]() -> int {
+    NAM_HIP_CHECK(hipSetDevice(batch->device));
+    return pipe_wait(batch, sl, slot, out);
+  });
 }
 
 int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float* const* out, const int64_t* n_frames)

@@ -1,0 +1,123 @@
+"""Host buffers in flight: nam_hip_batch_submit_f32 / nam_hip_batch_wait_f32 (include/nam_hip.h) — DSP::process (NAM/dsp.h:97)
+cut in two for callers that hand buffer k in while buffers k-1 .. k-3 are still being rendered. Every form the library
+serves a ticket with — commands of the persistent session with per-command completion (nam_a1_q_kernel, nam_kq_kernel),
+commands that complete when the launch has drained its ring (nam_wn_reg_kernel, the LSTM row kernel), copies and launches
+on the batch's stream (outside persistent mode), a blocking render kept for the wait (ragged lengths) — against the
+blocking entry point on a second batch of the same model fed the same audio, every stream and frame, and stream 0 against
+the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import model_path
+from signals import stream_bank
+
+pytestmark = pytest.mark.gpu
+
+# (model fixture, streams, persistent, frames per buffer, buffers, kernel expected in the session or None)
+CASES = {
+    "a1_standard_session_64": ("wavenet_a1_standard", 96, True, 64, 48, "nam_a1_q_kernel"),
+    "a1_standard_session_256": ("wavenet_a1_standard", 256, True, 256, 12, "nam_a1_q_kernel"),
+    "a2_full_session_64": ("A2", 128, True, 64, 40, "nam_kq_kernel"),
+    "a2_max_session_128": ("wavenet_a2_max", 64, True, 128, 16, "nam_wn_reg_kernel"),
+    "lstm_session_64": ("lstm", 33, True, 64, 24, None),
+    "a1_standard_launches_64": ("wavenet_a1_standard", 40, False, 64, 24, None),
+    "wavenet_launches_96": ("wavenet", 7, False, 96, 10, None),
+    "lstm_launches_64": ("lstm", 9, False, 64, 10, None),
+    "a1_standard_session_ragged_100": ("wavenet_a1_standard", 16, True, 100, 9, None),
+}
+
+
+def _feed(batch, x, frames, depth):
+    """buffer k in, buffer k - depth out"""
+    nb = x.shape[-1] // frames
+    ys, tickets = [], []
+    for k in range(nb):
+        if len(tickets) == depth:
+            ys.append(batch.wait(tickets.pop(0)))
+        tickets.append(batch.submit(x[:, k * frames:(k + 1) * frames]))
+    while tickets:
+        ys.append(batch.wait(tickets.pop(0)))
+    return np.concatenate(ys, axis=2)
+
+
+@pytest.mark.parametrize("depth", [1, 4, 16])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_tickets_against_the_blocking_call(nam_lib, oracle, case, depth):
+    nam = nam_lib
+    name, n_streams, persistent, frames, nb, kname = CASES[case]
+    if depth != 4 and "session_64" not in case:
+        pytest.skip("depths 1 and 16 are covered on the session cases")
+    x = stream_bank(n_streams, nb * frames, seed=700 + len(case))
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    ref_b = model.batch(n_streams, frames)
+    ref_b.set_persistent(persistent)
+    ref_b.Reset(prewarm=True)
+    want = ref_b.process_stream(x, frames)
+    ref_b.close()
+    b = model.batch(n_streams, frames)
+    assert bool(b.set_persistent(persistent)) == persistent
+    if kname:
+        assert b.kernel_name() == kname
+    b.Reset(prewarm=True)
+    got = _feed(b, x, frames, depth)
+    b.close()
+    assert got.shape == want.shape and np.isfinite(got).all()
+    # (a blocking call of up to four buffers runs nam_a1_p4_kernel where the session runs nam_a1_q_kernel: sums associated differently)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got - want).max()) <= 2e-5 * scale
+    ref = oracle.get_dsp(model_path(name), fast_tanh=True)
+    ref.Reset(48000.0, frames)
+    r = ref.process_stream(x[0], frames)[0]
+    assert float(np.max(np.abs(r - got[0, 0]))) <= 5e-5 * max(1.0, float(np.max(np.abs(r))))
+
+
+def test_ticket_rules(nam_lib):
+    """NAM_HIP_PIPE_SLOTS in flight, the next is refused until the oldest has been waited for; a ticket is waited for once; waits
+    in any order; Reset completes what is in flight and keeps the outputs; blocking calls may be mixed in"""
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    D = nam.Batch.PIPE_SLOTS
+    n, frames = 24, 64
+    nb = D + 12
+    x = stream_bank(n, nb * frames, seed=77)
+    buf = lambda k: x[:, k * frames:(k + 1) * frames]
+    ref_b = model.batch(n, frames)
+    ref_b.set_persistent(True)
+    ref_b.Reset(prewarm=True)
+    want = ref_b.process_stream(x, frames)
+    ref_b.close()
+    scale = max(1.0, float(np.abs(want).max()))
+    b = model.batch(n, frames)
+    b.set_persistent(True)
+    b.Reset(prewarm=True)
+    t = [b.submit(buf(k)) for k in range(D)]
+    assert t == list(range(D))
+    with pytest.raises(nam.NamHipError, match="in flight"):
+        b.submit(buf(D))
+    y = {}
+    y[2] = b.wait(t[2])  # any order
+    y[0] = b.wait(t[0])
+    with pytest.raises(Exception, match="not in flight"):
+        b.wait(t[0])
+    t.append(b.submit(buf(D)))  # slot 0 is free again
+    assert t[D] == D
+    for k in [1] + list(range(3, D + 1)):
+        y[k] = b.wait(t[k])
+    # a blocking call between tickets (the streams' state carries on)
+    y[D + 1] = b.process(buf(D + 1))
+    t2 = b.submit(buf(D + 2))
+    y[D + 3] = b.process(buf(D + 3))  # with a ticket in flight: it completes first
+    y[D + 2] = b.wait(t2)
+    got = np.concatenate([y[k] for k in range(D + 4)], axis=2)
+    assert float(np.abs(got - want[:, :, :(D + 4) * frames]).max()) <= 2e-5 * scale
+    # Reset with tickets in flight: they complete first, their outputs stay
+    t4, t5 = b.submit(buf(D + 4)), b.submit(buf(D + 5))
+    b.Reset(prewarm=True)
+    y45 = np.concatenate([b.wait(t4), b.wait(t5)], axis=2)
+    assert float(np.abs(y45 - want[:, :, (D + 4) * frames:(D + 6) * frames]).max()) <= 2e-5 * scale
+    # ... and the batch starts over: the first buffers again
+    z = _feed(b, x[:, :6 * frames], frames, 4)
+    assert float(np.abs(z - want[:, :, :6 * frames]).max()) <= 2e-5 * scale
+    with pytest.raises(nam.NamHipError):
+        b.submit(np.zeros((n, 1, frames + 1), dtype=np.float32))  # more than max_frames
+    b.close()
