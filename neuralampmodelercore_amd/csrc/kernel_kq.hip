@@ -22,10 +22,11 @@ namespace namhip
 //     other instructions;
 //   * NST = 12 stages of ONE wave each (kq::first_job: jobs cut so that three stages per SIMD balance, kq::stage_of_wave),
 //     stage s on buffer n - s, one-slot LDS queues between them (x, head accumulator, input sample, token);
-//   * a tap's operand: lookback 0 = the registers; 0 < L < 64 = the layer's LDS WINDOW [tail: the last T rows of the
-//     previous buffer | the current 64 rows], two planes of 16-byte rows (conflict-free b128 reads at a compile-time
-//     offset from the lane's row); L >= 64 = rows of the layer's HBM ring, requested ONE BUFFER AHEAD: the registers of a
-//     far tap are asked again for the next buffer right behind the instructions that consumed them;
+//   * a tap's operand: lookback 0 = the registers; 0 < L <= T = the layer's LDS WINDOW [tail: the last T rows in front
+//     of this buffer | the current 64 rows], two planes of 16-byte rows (conflict-free b128 reads at a compile-time
+//     offset from the lane's row; T: kq::tail_rows — below one buffer, or the layer's whole history where that is at most
+//     192 rows); L > T = rows of the layer's HBM ring, requested ONE BUFFER AHEAD: the registers of a far tap are asked
+//     again for the next buffer right behind the instructions that consumed them;
 //   * weights: one 256-byte tile per tap in LDS [lane % 4][h][c], read as four broadcast b128.
 // Sums: per output half one chain per layer seeded with bias + mixin * input, taps oldest first, input channels in order.
 // ================================================================================================
@@ -55,29 +56,41 @@ constexpr int max_jobs()
   return m;
 }
 constexpr int lookback(int job, int j) { return (kKs[job] - 1 - j) * kDs[job]; }
-constexpr int tail_rows(int job) // the largest lookback of the job below one buffer: that many rows of its previous input stay in LDS
+// A job's LDS window holds its input's last T rows in front of the current buffer's 64: taps up to T back read it at a
+// compile-time offset from the lane's row, taps further back ("far") read the HBM ring one buffer ahead. T = the largest
+// lookback below one buffer — or the job's WHOLE history where that is at most kWinMax rows (three rows per lane: the
+// A2 topology's dilation-17 layers, 85 rows, and its 15-tap dilation-13 layer, 182: sixteen far taps and four rings'
+// appends per buffer less; the tail then shifts down by 64 rows per buffer instead of being overwritten)
+constexpr int kWinMax = 3 * kBlock;
+constexpr int win_limit(int job)
+{
+  const int all = (kKs[job] - 1) * kDs[job];
+  return (all >= kBlock && all <= kWinMax) ? all : kBlock - 1;
+}
+constexpr int tail_rows(int job)
 {
   int t = 0;
   for (int j = 0; j < kKs[job]; j++)
   {
     const int L = lookback(job, j);
-    t = (L < kBlock && L > t) ? L : t;
+    t = (L <= win_limit(job) && L > t) ? L : t;
   }
   return t;
 }
+constexpr bool is_far(int job, int j) { return lookback(job, j) > tail_rows(job); }
 constexpr int win_rows(int job) { return tail_rows(job) > 0 ? tail_rows(job) + kBlock + 1 : 0; } // tail | current | one dump row
 constexpr int far_taps(int job)
 {
   int c = 0;
   for (int j = 0; j < kKs[job]; j++)
-    c += lookback(job, j) >= kBlock ? 1 : 0;
+    c += is_far(job, j) ? 1 : 0;
   return c;
 }
 constexpr int far_before(int job, int j) // far taps of the job in front of tap j
 {
   int c = 0;
   for (int i = 0; i < j; i++)
-    c += lookback(job, i) >= kBlock ? 1 : 0;
+    c += is_far(job, i) ? 1 : 0;
   return c;
 }
 constexpr int stage_far0(int s, int job) // far taps of stage s in front of `job`
@@ -293,11 +306,11 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
               [&](auto j_tag) {
                 constexpr int j = decltype(j_tag)::value;
                 constexpr int L = kq::lookback(TJ, j);
-                if constexpr (L >= kBlock)
+                if constexpr (kq::is_far(TJ, j))
                   fetch(rows[F0 + kq::far_before(TJ, j)], std::integral_constant<int, TJ>{}, L, wp[U], frame);
               },
               std::make_integer_sequence<int, K>{});
-            if constexpr (T > 0) // tail row r = the frame T - r before the first buffer: lanes r < T
+            if constexpr (T > 0 && T <= kBlock) // tail row r = the frame T - r before the first buffer: lanes r < T
               fetch(tails[U], std::integral_constant<int, TJ>{}, T, wp[U], frame < T ? frame : kq::kNoRow);
           },
           std::make_integer_sequence<int, NJS>{});
@@ -373,11 +386,26 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
           [&](auto u_tag) {
             constexpr int U = decltype(u_tag)::value, TJ = J0 + U;
             constexpr int T = kq::tail_rows(TJ), WR = kq::win_rows(TJ), WB0 = kq::win_b(TJ), WB1 = WB0 + WR * 16;
-            if constexpr (T > 0)
+            if constexpr (T > 0 && T <= kBlock)
             {
               const unsigned row = (unsigned)(frame < T ? frame : T + kBlock) * 16u;
               lds_st4(lds, (unsigned)WB0 + row, tails[U].q0);
               lds_st4(lds, (unsigned)WB1 + row, tails[U].q1);
+            }
+            else if constexpr (T > kBlock)
+            {
+              // the job's whole history lives in LDS: the ring as it lies in the state, row for row
+              constexpr int RL = kq::ring_len(TJ);
+#pragma unroll
+              for (int r0 = 0; r0 < RL; r0 += kBlock)
+              {
+                const int r = r0 + frame;
+                const int idx = r < RL ? r : kq::kNoRow;
+                const f4 q0 = kq_sb_load4(rs, idx, 0, kq::ring_off(TJ) * 4, 0), q1 = kq_sb_load4(rs, idx, 16, kq::ring_off(TJ) * 4, 0);
+                const unsigned rw = (unsigned)(r < RL ? r : RL) * 16u;
+                lds_st4(lds, (unsigned)WB0 + rw, q0);
+                lds_st4(lds, (unsigned)WB1 + rw, q1);
+              }
             }
           },
           std::make_integer_sequence<int, NJS>{});
@@ -421,7 +449,16 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
       kq_sb_store4(in0, rs, widx, 0, kq::ring_off(JI) * 4, WT && !PERSIST ? 17 : 0);
       kq_sb_store4(in1, rs, widx, 16, kq::ring_off(JI) * 4, WT && !PERSIST ? 17 : 0);
     }
-    if constexpr (T > 0)
+    if constexpr (T > kBlock)
+    {
+      // the resident ring: row (position + frame) mod R, as the append to the HBM ring would have it
+      const unsigned v = (unsigned)(wpj + frame);
+      const unsigned cur16 = min(v, v - (unsigned)RL) * 16u;
+      lds_st4(lds, (unsigned)WB0 + cur16, in0);
+      lds_st4(lds, (unsigned)WB1 + cur16, in1);
+      asm volatile("" ::: "memory");
+    }
+    else if constexpr (T > 0)
     {
       lds_st4(lds, (unsigned)(WB0 + T * 16) + frame16, in0);
       lds_st4(lds, (unsigned)(WB1 + T * 16) + frame16, in1);
@@ -463,8 +500,17 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
         f4 b0, b1;
         if constexpr (L == 0)
           b0 = in0, b1 = in1;
-        else if constexpr (L >= kBlock)
+        else if constexpr (kq::is_far(JI, j))
           b0 = rows[F0 + kq::far_before(JI, j)].q0, b1 = rows[F0 + kq::far_before(JI, j)].q1;
+        else if constexpr (T > kBlock)
+        {
+          int sb_ = wpj - L;
+          sb_ += sb_ < 0 ? RL : 0;
+          const unsigned v = (unsigned)(sb_ + frame);
+          const unsigned a16 = min(v, v - (unsigned)RL) * 16u;
+          b0 = lds_ld4(lds, (unsigned)WB0 + a16);
+          b1 = lds_ld4(lds, (unsigned)WB1 + a16);
+        }
         else
         {
           b0 = lds_ld4(lds, (unsigned)(WB0 + (T - L) * 16) + frame16);
@@ -497,12 +543,12 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
         }
         // a far tap's rows for the NEXT buffer, into the registers just consumed (rows up to this buffer's last frame: this
         // wave appended them at the top of the job)
-        if constexpr (L >= kBlock)
+        if constexpr (kq::is_far(JI, j))
           fetch(rows[F0 + kq::far_before(JI, j)], j_tag, L, wpn, frame);
       },
       std::make_integer_sequence<int, K>{});
     // (d) the window's tail for the next buffer: the last T rows of this input (behind the taps' reads: LDS runs in order)
-    if constexpr (T > 0)
+    if constexpr (T > 0 && T <= kBlock)
     {
       asm volatile("" ::: "memory"); // (behind every tap's read of the old tail)
       const unsigned row = (unsigned)(frame >= kBlock - T ? frame - (kBlock - T) : T + kBlock) * 16u;
@@ -711,16 +757,32 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
             [&](auto u_tag) {
               constexpr int U = decltype(u_tag)::value, TJ = J0 + U;
               constexpr int T = kq::tail_rows(TJ), WR = kq::win_rows(TJ), WB0 = kq::win_b(TJ), WB1 = WB0 + WR * 16, RL = kq::ring_len(TJ);
-              if constexpr (kq::far_taps(TJ) == 0 && T > 0)
+              if constexpr (kq::far_taps(TJ) == 0 && T > 0 && T <= kBlock)
               {
-                const unsigned row = (unsigned)(frame < T ? frame : 0) * 16u;
+                int fr = frame; // (opaque: see below)
+                asm volatile("" : "+v"(fr));
+                const unsigned row = (unsigned)(fr < T ? fr : 0) * 16u;
                 const f4 q0 = lds_ld4(lds, (unsigned)WB0 + row), q1 = lds_ld4(lds, (unsigned)WB1 + row);
                 int sb_ = wp[U] - T;
                 sb_ += sb_ < 0 ? RL : 0;
-                const unsigned v = (unsigned)(sb_ + frame);
-                const int idx = frame < T ? (int)min(v, v - (unsigned)RL) : kq::kNoRow;
+                const unsigned v = (unsigned)(sb_ + fr);
+                const int idx = fr < T ? (int)min(v, v - (unsigned)RL) : kq::kNoRow;
                 kq_sb_store4(q0, rs, idx, 0, kq::ring_off(TJ) * 4, 0);
                 kq_sb_store4(q1, rs, idx, 16, kq::ring_off(TJ) * 4, 0);
+              }
+              else if constexpr (T > kBlock) // the resident ring goes back as it lies
+              {
+                int fr = frame; // (opaque: the rows' indices are computed HERE, not hoisted above the stage's loop and kept in registers across it)
+                asm volatile("" : "+v"(fr));
+#pragma unroll
+                for (int r0 = 0; r0 < RL; r0 += kBlock)
+                {
+                  const int r = r0 + fr;
+                  const unsigned row = (unsigned)(r < RL ? r : 0) * 16u;
+                  const f4 q0 = lds_ld4(lds, (unsigned)WB0 + row), q1 = lds_ld4(lds, (unsigned)WB1 + row);
+                  kq_sb_store4(q0, rs, r < RL ? r : kq::kNoRow, 0, kq::ring_off(TJ) * 4, 0);
+                  kq_sb_store4(q1, rs, r < RL ? r : kq::kNoRow, 16, kq::ring_off(TJ) * 4, 0);
+                }
               }
             },
             std::make_integer_sequence<int, NJS>{});
