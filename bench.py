@@ -400,7 +400,7 @@ class StubEngine:
         pass
 
 
-def host_io(model_path: str, n_streams: int, fast_tanh: bool, budget_s: float = 0.4):
+def host_io(model_path: str, n_streams: int, fast_tanh: bool, budget_s: float = 0.3):
     """Host buffers in, host buffers out (`host_io` of the default line; never `value`: the timed region of `value` starts with
     the inputs in HBM): 256 streams of the headline model through the C ABI's two host-buffer forms — the blocking
     nam_hip_batch_process_f32 (one buffer at a time: copy in, commands, wait, copy out) and the ticketed
@@ -448,10 +448,14 @@ def host_io(model_path: str, n_streams: int, fast_tanh: bool, budget_s: float = 
             run(n)
             dt = time.perf_counter() - t0
             n = int(min(max(n * budget_s / max(dt, 1e-6), 64), 200000))
-            t0 = time.perf_counter()
-            run(n)
-            dt = time.perf_counter() - t0
-            entry[mode] = {"value": round(n_streams * frames * n / SR / dt, 1), "us_per_call": round(dt / n * 1e6, 2), "calls": n}
+            dts = []
+            for _ in range(2):  # (the better of two passes: the host's copies share the box with whatever else it runs)
+                t0 = time.perf_counter()
+                run(n)
+                dts.append(time.perf_counter() - t0)
+            dt = min(dts)
+            entry[mode] = {"value": round(n_streams * frames * n / SR / dt, 1), "us_per_call": round(dt / n * 1e6, 2), "calls": n,
+                           "us_per_call_passes": [round(d_ / n * 1e6, 2) for d_ in dts]}
         entry["finite"] = bool(all(np.isfinite(y).all() for y in ys))
         res[f"{frames}_frames"] = entry
         b.close()

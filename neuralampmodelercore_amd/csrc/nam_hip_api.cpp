@@ -745,7 +745,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
-          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok) ? kTicketLinger : 0;
+          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? kTicketLinger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -788,7 +788,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
-          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok) ? kTicketLinger : 0;
+          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? kTicketLinger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -1078,7 +1078,7 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
     // ... and linger: a workgroup that finds itself up to date when a launch starts (another one's backlog was the reason for
     // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
     // linger and leave before the next launch could pick it up again
-    if (ps.prog_completes && ps.host_store_ok)
+    if (ps.prog_completes && ps.host_store_ok && ps.n_wg <= b->n_cus)
       ps.grace = std::max(ps.grace, kTicketLinger);
   }
   const int keep = b->kernel;
@@ -1137,7 +1137,7 @@ int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool who
   PersistSession& ps = b->ps;
   if (!ps.active)
     return NAM_HIP_OK;
-  if (whole && ps.outstanding && ps.prog_completes && ps.host_store_ok)
+  if (whole && ps.outstanding && ps.prog_completes && ps.host_store_ok && ps.n_wg <= b->n_cus)
   {
     // a lingering launch: tell it that nothing follows command `seq` (kPRingTail)
     __atomic_store_n(&ps.d_ring[kPRing], (unsigned long long)ps.seq, __ATOMIC_RELEASE);

@@ -16,6 +16,7 @@ print("  zeros", j.get("zeros_input"), "fast_tanh_off", j.get("fast_tanh_off"), 
 for k, v in j["other_configs"].items():
     print(k, v.get("value"), v.get("ms_per_step"), (v.get("config") or {}).get("kernel"), v.get("max_abs_err_vs_oracle"), v.get("error"))
 print("cpu", j.get("cpu_baseline", {}).get("value"), j.get("cpu_baseline", {}).get("kind"))
+print("host_io", {k: (v.get("blocking", {}).get("value"), v.get("tickets", {}).get("value")) for k, v in (j.get("host_io") or {}).items() if isinstance(v, dict)}, (j.get("host_io") or {}).get("error"))
 PY
 bash scripts/gpu_prof_resident.sh c2_q nam_a1_q_kernel --config 2 2>&1 | tail -45
 timeout 300 python tools/a1q_timeline.py 20 400 > gpurun_out/r4_timeline.txt 2>&1; grep -v amdgpu.ids gpurun_out/r4_timeline.txt | head -20

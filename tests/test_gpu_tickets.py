@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "a1_standard_session_64": ("wavenet_a1_standard", 96, True, 64, 48, "nam_a1_q_kernel"),
     "a1_standard_session_256": ("wavenet_a1_standard", 256, True, 256, 12, "nam_a1_q_kernel"),
+    "a1_standard_session_turns_64": ("wavenet_a1_standard", 300, True, 64, 24, "nam_a1_q_kernel"),  # more workgroups than CUs
     "a2_full_session_64": ("A2", 128, True, 64, 40, "nam_kq_kernel"),
     "a2_max_session_128": ("wavenet_a2_max", 64, True, 128, 16, "nam_wn_reg_kernel"),
     "lstm_session_64": ("lstm", 33, True, 64, 24, None),

@@ -302,3 +302,16 @@ def test_config_and_metadata_text_round_trips_non_finite_numbers(nam_lib):
     conf["weights"] = w
     m3 = nam.get_dsp_data(conf, fast_tanh=False)  # a non-finite weight travels as the spelling the parser reads
     assert np.isinf(m3.dsp_data()["weights"][3])
+
+
+def test_ticket_entry_points_refuse_bad_arguments(nam_lib):
+    """nam_hip_batch_submit_f32 / nam_hip_batch_wait_f32 without a batch (no device needed): an error code and a message, no crash"""
+    import ctypes
+    L = nam_lib.load_library()
+    t = ctypes.c_int64(-1)
+    x = (ctypes.c_float * 64)()
+    assert L.nam_hip_batch_submit_f32(None, x, 64, ctypes.byref(t)) == nam_lib.ERR_INVALID_ARGUMENT
+    assert b"nam_hip_batch_submit_f32" in L.nam_hip_last_error()
+    assert L.nam_hip_batch_wait_f32(None, 0, x) == nam_lib.ERR_INVALID_ARGUMENT
+    assert b"nam_hip_batch_wait_f32" in L.nam_hip_last_error()
+    assert nam_lib.Batch.PIPE_SLOTS == int(re.search(r"#define NAM_HIP_PIPE_SLOTS (\d+)", open(os.path.join(ROOT, "include", "nam_hip.h")).read()).group(1))
