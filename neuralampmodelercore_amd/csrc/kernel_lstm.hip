@@ -469,6 +469,61 @@ __device__ __forceinline__ float tanh_like(float x)
 {
   return FAST ? mf::fast_tanh_hw(x) : mf::tanh_hw(x);
 }
+// The step in as few instructions as it takes: a lone wave issues one every ~8.6 cycles whatever it is, so the instruction
+// COUNT of the step is its time (profiles/r04/valu_rate_microbench.txt).
+// tanh_like(x) = x * ratio(x). FAST: the reference's rational (activations.h:29-41)
+//   x (a + a |x| + (b + c |x|) x^2) / (d + (d + x^2) |x + e x |x||)
+// with |x + e x |x|| = |x| (1 + e |x|) (e > 0), a gate's factor A (1 or 0.5) folded into the numerator's coefficients
+// (kn = {A c, A a}, kc = {A b, A a}: per-lane registers) and the independent pairs on v_pk_fma_f32:
+// (x^2, 1 + e |x|) and (A (b + c |x|), A (a + a |x|)). `late`: a value from the end of the sequence (fake dependencies).
+using f2 = __attribute__((ext_vector_type(2))) float;
+template <bool FAST>
+__device__ __forceinline__ float ratio(const float x, const float A, const f2 kn, const f2 kc, float& late)
+{
+  if constexpr (FAST)
+  {
+    const float ax = __builtin_fabsf(x);
+    const f2 axax = {ax, ax};
+    const f2 sw = __builtin_elementwise_fma(axax, f2{ax, 0.814642734961073f}, f2{0.0f, 1.0f}); // (x^2, 1 + e |x|)
+    const f2 t = __builtin_elementwise_fma(kn, axax, kc); // A (b + c |x|), A (a + a |x|)
+    const float n = __builtin_fmaf(t.x, sw.x, t.y);
+    const float z = ax * sw.y;
+    const float q = sw.x + 2.44506634652299f;
+    const float den = __builtin_fmaf(q, z, 2.44506634652299f);
+    late = den;
+    return n * mf::rcp(den);
+  }
+  else
+  {
+    // A tanh(x) / x is not what the exp form gives: the caller multiplies by x again — keep the exact form: A tanh(x) = x * (A tanh(x) / x)
+    // would divide by zero, so the libm form hands back A tanh(x) and sets `late` to 0 (see the callers)
+    const float t = A * mf::tanh_hw(x);
+    late = t;
+    return t;
+  }
+}
+// acc += sum over the NH hidden units of (lane 4 j of the 16-lane row of h) * w[j]: one VOP2 DPP instruction per term (the
+// compiler's own form is a DPP move + an FMA each: its DPP combiner runs before v_fma becomes v_fmac), ONE asm statement (the
+// compiler pads every asm statement with a wait state of its own). Two wait states in front: a DPP read needs them between
+// the source's write (the step before) and itself, and the hazard recogniser does not look into inline asm.
+#define NAM_LROW_TERM(W, N) "v_fmac_f32_dpp %0, %1, " W " row_newbcast:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"
+template <int NH>
+__device__ __forceinline__ void recurrent_terms(float& acc, const float h, const float* w)
+{
+  if constexpr (NH == 1)
+    asm("s_nop 1\n\t" NAM_LROW_TERM("%2", 0) : "+v"(acc) : "v"(h), "v"(w[0]));
+  else if constexpr (NH == 2)
+    asm("s_nop 1\n\t" NAM_LROW_TERM("%2", 0) "\n\t" NAM_LROW_TERM("%3", 4) : "+v"(acc) : "v"(h), "v"(w[0]), "v"(w[1]));
+  else if constexpr (NH == 3)
+    asm("s_nop 1\n\t" NAM_LROW_TERM("%2", 0) "\n\t" NAM_LROW_TERM("%3", 4) "\n\t" NAM_LROW_TERM("%4", 8)
+        : "+v"(acc)
+        : "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]));
+  else
+    asm("s_nop 1\n\t" NAM_LROW_TERM("%2", 0) "\n\t" NAM_LROW_TERM("%3", 4) "\n\t" NAM_LROW_TERM("%4", 8) "\n\t" NAM_LROW_TERM("%5", 12)
+        : "+v"(acc)
+        : "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+}
+#undef NAM_LROW_TERM
 } // namespace lrow
 
 template <int NL, int NI, int NH, bool FAST>
@@ -493,6 +548,9 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
   // sigmoid(x) = 0.5 tanh(x / 2) + 0.5 for gates i, f, o; tanh for g: act(x) = A T(B x) + C. B (1 or 0.5: exact) is
   // folded into the lane's weights.
   const float cA = k == 2 ? 1.0f : 0.5f, cB = cA, cC = k == 2 ? 0.0f : 0.5f;
+  // the rational's numerator coefficients times A (gates) / times 1 (tanh of the cell state): lrow::act_affine
+  const lrow::f2 knA = {0.821226666969744f * cA, 2.45550750702956f * cA}, kcA = {0.893229853513558f * cA, 2.45550750702956f * cA};
+  const lrow::f2 kn1 = {0.821226666969744f, 2.45550750702956f}, kc1 = {0.893229853513558f, 2.45550750702956f};
 
   // this lane's gate row of every layer: bias, input weights, recurrent weights (zero rows for the padding unit)
   constexpr int NW = NI > NH ? NI : NH;
@@ -552,10 +610,11 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
           xr[e][j] = pers ? persist_in(px) : *px;
         }
       }
-    auto step = [&](auto t_tag) {
+    auto step = [&](auto t_tag, auto whole_tag) {
       constexpr int T = decltype(t_tag)::value;
-      if (T >= nvalid) // (wavefront-uniform)
-        return;
+      if constexpr (!decltype(whole_tag)::value)
+        if (T >= nvalid) // (wavefront-uniform; a whole block — every block but a launch's ragged last one — runs the steps without the test)
+          return;
 #pragma unroll
       for (int l = 0; l < NL; l++)
       {
@@ -578,27 +637,35 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
           if constexpr (NH > 3)
             pre = fmaf(wi[l][3], lrow::row_bcast<12>(hb_), pre);
         }
-        // (two partial sums: the recurrent FMAs are the head of the step's dependency chain)
-        float rec = wh[l][0] * lrow::row_bcast<0>(h[l]);
-        if constexpr (NH > 1)
-          pre = fmaf(wh[l][1], lrow::row_bcast<4>(h[l]), pre);
-        if constexpr (NH > 2)
-          rec = fmaf(wh[l][2], lrow::row_bcast<8>(h[l]), rec);
-        if constexpr (NH > 3)
-          pre = fmaf(wh[l][3], lrow::row_bcast<12>(h[l]), pre);
-        pre += rec;
-        const float g = fmaf(cA, lrow::tanh_like<FAST>(pre), cC);
-        // the unit's four gates meet in every lane of its quad
-        const float gi = lrow::quad_bcast<0>(g), gf = lrow::quad_bcast<1>(g), gg = lrow::quad_bcast<2>(g),
-                    go = lrow::quad_bcast<3>(g);
-        const float cn = fmaf(gf, c[l], gi * gg);
-        const float hn = go * lrow::tanh_like<FAST>(cn);
+        // the recurrent terms, one chain (longer than an FMA's latency apart anyway), each ONE instruction. h(t - 1) was written
+        // by the step before: two wait states in front of the first DPP read of it
+        lrow::recurrent_terms<NH>(pre, h[l], wh[l]);
+        float late;
+        float g = lrow::ratio<FAST>(pre, cA, knA, kcA, late);
+        g = FAST ? fmaf(g, pre, cC) : g + cC;
+        // the unit's gates meet in lanes 0 and 2 of its quad — i * g on one DPP multiply (quad_perm [2, 3, 0, 1]: lane 0 reads g,
+        // lane 2 reads i), + f * c on one DPP multiply-add. Lanes 1 and 3 compute something nobody reads: h goes on from
+        // lane 0 of the quad (row_newbcast 0 / 4 / 8 / 12), the state and the history row are written by it
+        float cn;
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "=&v"(cn)
+            : "v"(g), "v"(c[l]));
+        // h = o * tanh_like(c): o * c on a DPP multiply of its own — placed behind the ratio's denominator (a fake operand):
+        // well over two wait states behind c's write
+        float r = lrow::ratio<FAST>(cn, 1.0f, kn1, kc1, late);
+        float oc;
+        asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(oc) : "v"(g), "v"(FAST ? cn : r), "v"(late));
+        const float hn = FAST ? r * oc : oc;
         c[l] = cn;
         h[l] = hn;
       }
       hs[hs_slot + T] = h[NL - 1];
     };
-    il::for_each_index(step, std::make_integer_sequence<int, kBlock>{});
+    if (nvalid == kBlock)
+      il::for_each_index([&](auto t_tag) { step(t_tag, std::true_type{}); }, std::make_integer_sequence<int, kBlock>{});
+    else
+      il::for_each_index([&](auto t_tag) { step(t_tag, std::false_type{}); }, std::make_integer_sequence<int, kBlock>{});
     // head: y[ch][t] = bh + Wh . h_top(t), lane = frame (coalesced stores)
     if (a.out)
       for (int r = 0; r < 4; r++)
