@@ -474,23 +474,24 @@ __device__ __forceinline__ float tanh_like(float x)
 // tanh_like(x) = x * ratio(x). FAST: the reference's rational (activations.h:29-41)
 //   x (a + a |x| + (b + c |x|) x^2) / (d + (d + x^2) |x + e x |x||)
 // with |x + e x |x|| = |x| (1 + e |x|) (e > 0), a gate's factor A (1 or 0.5) folded into the numerator's coefficients
-// (kn = {A c, A a}, kc = {A b, A a}: per-lane registers) and the independent pairs on v_pk_fma_f32:
-// (x^2, 1 + e |x|) and (A (b + c |x|), A (a + a |x|)). `late`: a value from the end of the sequence (fake dependencies).
+// (per-lane registers kn, kc) and the independent pairs on v_pk_fma_f32: (x^2 + d, 1 + e |x|) and the numerator's two
+// linear factors. `late`: a value from the end of the sequence (fake dependencies).
 using f2 = __attribute__((ext_vector_type(2))) float;
 template <bool FAST>
 __device__ __forceinline__ float ratio(const float x, const float A, const f2 kn, const f2 kc, float& late)
 {
   if constexpr (FAST)
   {
+    // with q = x^2 + d: numerator / x = t1 x^2 + t2 = t1 q + (t2 - d t1), and t2 - d t1 is linear in |x| like t2: the x^2 never
+    // has to exist by itself
     const float ax = __builtin_fabsf(x);
     const f2 axax = {ax, ax};
-    const f2 sw = __builtin_elementwise_fma(axax, f2{ax, 0.814642734961073f}, f2{0.0f, 1.0f}); // (x^2, 1 + e |x|)
-    const f2 t = __builtin_elementwise_fma(kn, axax, kc); // A (b + c |x|), A (a + a |x|)
-    const float n = __builtin_fmaf(t.x, sw.x, t.y);
-    const float z = ax * sw.y;
-    const float q = sw.x + 2.44506634652299f;
-    const float den = __builtin_fmaf(q, z, 2.44506634652299f);
+    const f2 qw = __builtin_elementwise_fma(axax, f2{ax, 0.814642734961073f}, f2{2.44506634652299f, 1.0f}); // (x^2 + d, 1 + e |x|)
+    const f2 t = __builtin_elementwise_fma(kn, axax, kc); // A (b + c |x|), A ((a - d b) + (a - d c) |x|)
+    const float z = ax * qw.y;
+    const float den = __builtin_fmaf(qw.x, z, 2.44506634652299f);
     late = den;
+    const float n = __builtin_fmaf(t.x, qw.x, t.y);
     return n * mf::rcp(den);
   }
   else
@@ -523,6 +524,51 @@ __device__ __forceinline__ void recurrent_terms(float& acc, const float h, const
         : "+v"(acc)
         : "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
 }
+// The whole pre-activation of layer 0's gate row: bias + input term(s) + recurrent terms in ONE asm statement — the input term
+// (a DPP move of the sample's lane + an FMA with the bias; independent of h) stands in front and IS the two wait states the
+// first DPP read of h needs. Operands: %0 acc, %1 scratch, %2 x0, %3 wi0, %4 wb, %5 x1, %6 wi1, %7 h, %8 .. %11 wh, %12 = lane of
+// the sample in its 16-lane row.
+#define NAM_LROW_DPP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define NAM_LROW_X0 "v_mov_b32_dpp %1, %2 row_newbcast:%12" NAM_LROW_DPP "v_fma_f32 %0, %3, %1, %4\n\t"
+#define NAM_LROW_X1 "v_fmac_f32_dpp %0, %5, %6 row_newbcast:%12" NAM_LROW_DPP
+#define NAM_LROW_H0 "v_fmac_f32_dpp %0, %7, %8 row_newbcast:0" NAM_LROW_DPP
+#define NAM_LROW_H1 "v_fmac_f32_dpp %0, %7, %9 row_newbcast:4" NAM_LROW_DPP
+#define NAM_LROW_H2 "v_fmac_f32_dpp %0, %7, %10 row_newbcast:8" NAM_LROW_DPP
+#define NAM_LROW_H3 "v_fmac_f32_dpp %0, %7, %11 row_newbcast:12" NAM_LROW_DPP
+#define NAM_LROW_ASM(TEXT) \
+  asm(TEXT : "=&v"(acc), "=&v"(tmp) \
+      : "v"(x0), "v"(wi[0]), "v"(wb), "v"(x1), "v"(wi[NI > 1 ? 1 : 0]), "v"(h), "v"(wh[0]), "v"(wh[NH > 1 ? 1 : 0]), "v"(wh[NH > 2 ? 2 : 0]), \
+        "v"(wh[NH > 3 ? 3 : 0]), "n"(N))
+template <int NI, int NH, int N>
+__device__ __forceinline__ float gate_row(const float x0, const float x1, const float* wi, const float wb, const float h, const float* wh)
+{
+  float acc, tmp;
+  if constexpr (NI == 1 && NH == 1)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_H0);
+  else if constexpr (NI == 1 && NH == 2)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_H0 NAM_LROW_H1);
+  else if constexpr (NI == 1 && NH == 3)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_H0 NAM_LROW_H1 NAM_LROW_H2);
+  else if constexpr (NI == 1)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_H0 NAM_LROW_H1 NAM_LROW_H2 NAM_LROW_H3);
+  else if constexpr (NH == 1)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_X1 NAM_LROW_H0);
+  else if constexpr (NH == 2)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_X1 NAM_LROW_H0 NAM_LROW_H1);
+  else if constexpr (NH == 3)
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_X1 NAM_LROW_H0 NAM_LROW_H1 NAM_LROW_H2);
+  else
+    NAM_LROW_ASM(NAM_LROW_X0 NAM_LROW_X1 NAM_LROW_H0 NAM_LROW_H1 NAM_LROW_H2 NAM_LROW_H3);
+  return acc;
+}
+#undef NAM_LROW_ASM
+#undef NAM_LROW_H3
+#undef NAM_LROW_H2
+#undef NAM_LROW_H1
+#undef NAM_LROW_H0
+#undef NAM_LROW_X1
+#undef NAM_LROW_X0
+#undef NAM_LROW_DPP
 #undef NAM_LROW_TERM
 } // namespace lrow
 
@@ -549,8 +595,11 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
   // folded into the lane's weights.
   const float cA = k == 2 ? 1.0f : 0.5f, cB = cA, cC = k == 2 ? 0.0f : 0.5f;
   // the rational's numerator coefficients times A (gates) / times 1 (tanh of the cell state): lrow::act_affine
-  const lrow::f2 knA = {0.821226666969744f * cA, 2.45550750702956f * cA}, kcA = {0.893229853513558f * cA, 2.45550750702956f * cA};
-  const lrow::f2 kn1 = {0.821226666969744f, 2.45550750702956f}, kc1 = {0.893229853513558f, 2.45550750702956f};
+  constexpr float kRa = 2.45550750702956f, kRb = 0.893229853513558f, kRc = 0.821226666969744f, kRd = 2.44506634652299f;
+  constexpr float kRa1 = (float)(2.45550750702956 - 2.44506634652299 * 0.821226666969744), kRa0 = (float)(2.45550750702956 - 2.44506634652299 * 0.893229853513558);
+  const lrow::f2 knA = {kRc * cA, kRa1 * cA}, kcA = {kRb * cA, kRa0 * cA};
+  const lrow::f2 kn1 = {kRc, kRa1}, kc1 = {kRb, kRa0};
+  (void)kRa, (void)kRd;
 
   // this lane's gate row of every layer: bias, input weights, recurrent weights (zero rows for the padding unit)
   constexpr int NW = NI > NH ? NI : NH;
@@ -621,11 +670,7 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
         // gate pre-activation of this lane's row (times B): b + Wi . in + Wh . h(t - 1)
         float pre = wb[l];
         if (l == 0)
-        {
-#pragma unroll
-          for (int e = 0; e < NI; e++)
-            pre = fmaf(wi[0][e], lrow::row_bcast<T % 16>(xr[e][T / 16]), pre);
-        }
+          pre = lrow::gate_row<NI, NH, T % 16>(xr[0][T / 16], xr[NI - 1][T / 16], wi[0], wb[0], h[0], wh[0]);
         else
         {
           const float hb_ = h[l > 0 ? l - 1 : 0]; // the layer below's h(t)
@@ -639,7 +684,8 @@ __global__ __launch_bounds__(64) void nam_lstm_row_kernel(const float* __restric
         }
         // the recurrent terms, one chain (longer than an FMA's latency apart anyway), each ONE instruction. h(t - 1) was written
         // by the step before: two wait states in front of the first DPP read of it
-        lrow::recurrent_terms<NH>(pre, h[l], wh[l]);
+        if (l > 0)
+          lrow::recurrent_terms<NH>(pre, h[l], wh[l]);
         float late;
         float g = lrow::ratio<FAST>(pre, cA, knA, kcA, late);
         g = FAST ? fmaf(g, pre, cC) : g + cC;
