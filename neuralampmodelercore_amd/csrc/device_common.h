@@ -147,13 +147,19 @@ __device__ __forceinline__ float tanh_hw(float x)
   const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f); // exp(2x) = 2^(2x*log2(e))
   return 1.0f - 2.0f * rcp(e + 1.0f);
 }
+// The reference's fast_tanh (NAM/activations.h:29-41): x (a + a |x| + (b + c |x|) x^2) / (d + (d + x^2) |x + e x |x||), in ten
+// instructions instead of eleven: |x + e x |x|| = |x| (1 + e |x|) (e > 0), and with q = x^2 + d the numerator / x is
+// t1 q + (t2 - d t1), whose second factor is linear in |x| like t2 — x^2 never exists by itself.
 __device__ __forceinline__ float fast_tanh_hw(const float x)
 {
+  constexpr float kA1 = (float)(2.45550750702956 - 2.44506634652299 * 0.821226666969744), kA0 = (float)(2.45550750702956 - 2.44506634652299 * 0.893229853513558);
   const float ax = fabsf(x);
-  const float x2 = x * x;
-  const float num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
-  const float den = 2.44506634652299f + (2.44506634652299f + x2) * fabsf(x + 0.814642734961073f * x * ax);
-  return num * rcp(den);
+  const float q = fmaf(ax, ax, 2.44506634652299f);
+  const float w = fmaf(0.814642734961073f, ax, 1.0f);
+  const float t1 = fmaf(0.821226666969744f, ax, 0.893229853513558f);
+  const float t2 = fmaf(kA1, ax, kA0);
+  const float den = fmaf(q, ax * w, 2.44506634652299f);
+  return (fmaf(t1, q, t2) * rcp(den)) * x;
 }
 __device__ __forceinline__ float sigmoid_hw(float x)
 {

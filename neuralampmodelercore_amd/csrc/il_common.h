@@ -57,4 +57,64 @@ __device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int,
   (f(std::integral_constant<int, I>{}), ...);
 }
 } // namespace il
+
+// A session launch waits for command `tag` (ring slot of sequence number tag - 1; `v` = what the slot held at the last look) for
+// `window` ticks of the 100 MHz clock. A launch that LINGERS (ticketed host buffers: A1Args::p_linger > 100; nam_a1_q_kernel,
+// nam_kq_kernel) has two more rules:
+//  * the host's "leave" word behind the ring (= the session's command count: nothing follows) ends the wait at once;
+//  * when the window has passed, the workgroup still stays while another workgroup is BEHIND it — p_cmd_count[mask + 1] holds
+//    the highest command every workgroup is through (atomic max by the last one through each). The host hands the next buffer
+//    in when the slowest workgroup has finished an old one; a workgroup that left meanwhile would miss it, the rest would have
+//    to run dry, linger and leave before the next launch could pick it up again — and then the two halves take turns being the
+//    one that left (measured: 1,024-frame buffers at 27 k xRT instead of 57 k, a relaunch per 16 buffers). Not once a workgroup
+//    of this launch HAS left (p_cmd_count[mask + 2], cleared by the host in front of every launch: session_leaving): the one
+//    behind may be the one that is gone. Capped at 20 ms.
+template <int SLEEP, class RingLoad>
+__device__ __forceinline__ unsigned long long session_wait_command(const A1Args& a, RingLoad ring_load, const unsigned tag, unsigned long long v,
+                                                                  const long long window)
+{
+  if ((unsigned)(v >> 32) == tag || window <= 0)
+    return v;
+  const bool lingers = a.p_linger > 100;
+  const long long t0 = (long long)wall_clock64(), t_end = t0 + window, t_cap = t0 + (lingers ? 2000000ll : window);
+  int why = 0; // (developer statistics: why the wait ended without a command — NAM_HIP_SESSION_STATS, a.dbg = a host-mapped array)
+  for (;;)
+  {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    v = ring_load(tag - 1u);
+    if ((unsigned)(v >> 32) == tag)
+      break;
+    const long long now = (long long)wall_clock64();
+    if (!lingers)
+    {
+      if (now >= t_end)
+        break;
+      continue;
+    }
+    if ((unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag - 1u)
+    {
+      why = 1;
+      break;
+    }
+    if (now >= t_end)
+    {
+      const unsigned all_done = __hip_atomic_load(a.p_cmd_count + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      why = now >= t_cap ? 2 : (int)(all_done - (tag - 1u)) >= 0 ? 3 : __hip_atomic_load(a.p_cmd_count + a.p_ring_mask + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 4 : 0;
+      if (why)
+      {
+        if (a.dbg && a.p_ring)
+          a.dbg[blockIdx.x] = ((long long)why << 56) | ((long long)(SLEEP == 8 ? 1 : 0) << 48) | ((long long)(all_done & 0xffffffu) << 24) | (long long)((tag - 1u) & 0xffffffu);
+        break;
+      }
+    }
+  }
+  (void)why;
+  return v;
+}
+// ... and a workgroup of a lingering launch that leaves says so (one lane)
+__device__ __forceinline__ void session_leaving(const A1Args& a)
+{
+  if (a.p_linger > 100)
+    __hip_atomic_fetch_add(a.p_cmd_count + a.p_ring_mask + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 } // namespace namhip

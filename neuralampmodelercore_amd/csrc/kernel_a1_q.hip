@@ -38,7 +38,7 @@ __device__ void aq_sb_store4(mf::f4 v, aq_i4 rsrc, int vindex, int voffset, int 
 // The activations with every fused multiply-add spelled out and contraction off: the compiler's own choice of what to fuse
 // differs between instantiations of one kernel (it depends on the code around the expression), and a session must render
 // bit for bit what a plain launch renders (tests/test_gpu_breadth.py: test_pipelined_kernel_against_the_four_wave_kernel).
-// Fasttanh: NAM/activations.h:91-98, same operation order as device_common.h: fast_tanh_hw; Tanh: 1 - 2 / (exp(2 x) + 1).
+// Fasttanh: NAM/activations.h:91-98 (the rational, rearranged: see below); Tanh: 1 - 2 / (exp(2 x) + 1).
 #pragma clang fp contract(off)
 template <int ACT_T>
 __device__ __forceinline__ mf::f4 aq_act4(const mf::f4& v)
@@ -50,14 +50,18 @@ __device__ __forceinline__ mf::f4 aq_act4(const mf::f4& v)
     const float x = v[i];
     if constexpr (ACT_T == ACT_FASTTANH)
     {
+      // x (a + a |x| + (b + c |x|) x^2) / (d + (d + x^2) |x + e x |x||) in ten instructions instead of eleven: |x + e x |x|| =
+      // |x| (1 + e |x|) (e > 0), and with q = x^2 + d the numerator / x is t1 q + (t2 - d t1), whose second factor is linear
+      // in |x| like t2 — x^2 never exists by itself (kernel_lstm.hip: lrow::ratio)
+      constexpr float kA1 = (float)(2.45550750702956 - 2.44506634652299 * 0.821226666969744), kA0 = (float)(2.45550750702956 - 2.44506634652299 * 0.893229853513558);
       const float ax = __builtin_fabsf(x);
-      const float x2 = x * x;
+      const float q = __builtin_fmaf(ax, ax, 2.44506634652299f);
+      const float w = __builtin_fmaf(0.814642734961073f, ax, 1.0f);
       const float t1 = __builtin_fmaf(0.821226666969744f, ax, 0.893229853513558f);
-      const float t2 = __builtin_fmaf(2.45550750702956f, ax, 2.45550750702956f);
-      const float num = x * __builtin_fmaf(t1, x2, t2);
-      const float w = __builtin_fmaf(0.814642734961073f, x * ax, x);
-      const float den = __builtin_fmaf(2.44506634652299f + x2, __builtin_fabsf(w), 2.44506634652299f);
-      r[i] = num * __builtin_amdgcn_rcpf(den);
+      const float t2 = __builtin_fmaf(kA1, ax, kA0);
+      const float den = __builtin_fmaf(q, ax * w, 2.44506634652299f);
+      const float n = __builtin_fmaf(t1, q, t2);
+      r[i] = (n * __builtin_amdgcn_rcpf(den)) * x;
     }
     else
     {
@@ -286,21 +290,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       if (wall == 0)
       {
         // started right behind a stream-ordered doorbell on another hardware queue: look for it for a bounded time
-        unsigned long long v = ring_load(na);
-        if ((unsigned)(v >> 32) != na + 1 && a.p_grace > 0)
-        {
-          const long long t_end = (long long)wall_clock64() + a.p_grace;
-          do
-          {
-            __builtin_amdgcn_s_sleep(8);
-            v = ring_load(na);
-            // (a lingering session's launch: as below — a workgroup that is up to date stays for the commands to come, unless
-            // the host says that none will)
-            if (a.p_linger > 100 && (unsigned)(v >> 32) != na + 1
-                && (unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == na)
-              break;
-          } while ((unsigned)(v >> 32) != na + 1 && (long long)wall_clock64() < t_end);
-        }
+        unsigned long long v = session_wait_command<8>(a, ring_load, na + 1u, ring_load(na), (long long)a.p_grace);
         if (lane == 0)
         {
           flags[48] = (int)(unsigned)v;
@@ -317,6 +307,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
       // nothing to do (the doorbell this launch was started for has been consumed by its predecessor)
       if (wall == 0 && lane == 0)
       {
+        session_leaving(a);
         a.p_cons[blockIdx.x] = done;
         __hip_atomic_store(a.p_done + blockIdx.x, done | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -620,22 +611,13 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
           unsigned long long v = spec_cmd;
           if ((unsigned)(v >> 32) != tag)
           {
-            v = ring_load(tag - 1u);
-            const long long t_end = (long long)wall_clock64() + (a.p_linger > 0 ? a.p_linger : 100); // 1 us of the 100 MHz clock unless told otherwise
-            while ((unsigned)(v >> 32) != tag && (long long)wall_clock64() < t_end)
-            {
-              __builtin_amdgcn_s_sleep(16);
-              v = ring_load(tag - 1u);
-              // a launch that lingers (ticketed host buffers) leaves at once when the host says that nothing follows the
-              // commands this workgroup has consumed (nam_hip_api.cpp: kPRingTail)
-              if (a.p_linger > 100 && (unsigned)(v >> 32) != tag
-                  && (unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag - 1u)
-                break;
-            }
+            v = session_wait_command<16>(a, ring_load, tag, ring_load(tag - 1u), (long long)(a.p_linger > 0 ? a.p_linger : 100)); // (1 us unless the launch lingers)
           }
           // ONE view of the ring slot for the whole wave (lane 0's)
           const unsigned v_tag = (unsigned)uni((int)(unsigned)(v >> 32)), v_off = (unsigned)uni((int)(unsigned)v);
           have = v_tag == tag;
+          if (!have && lane == 0)
+            session_leaving(a); // (the others stop waiting for workgroups behind them: il_common.h)
           const unsigned next_off = v_off * 4u;
           na++;
           if (have)
@@ -971,6 +953,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
               // the last workgroup through command `done - 1`: every other one had its results acknowledged before it counted
               __hip_atomic_store(a.p_cmd_count + cslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_store(a.p_cmd_done + cslot, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_fetch_max(a.p_cmd_count + a.p_ring_mask + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (il_common.h: session_wait_command)
             }
             if (lane == 0 && (done & 15u) == 0u)
               __hip_atomic_store(a.p_prog + blockIdx.x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

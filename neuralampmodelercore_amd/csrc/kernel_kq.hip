@@ -335,21 +335,7 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
       if (wall == 0)
       {
         // started right behind a stream-ordered doorbell on another hardware queue: look for it for a bounded time
-        unsigned long long v = ring_load(na);
-        if ((unsigned)(v >> 32) != na + 1 && a.p_grace > 0)
-        {
-          const long long t_end = (long long)wall_clock64() + a.p_grace;
-          do
-          {
-            __builtin_amdgcn_s_sleep(8);
-            v = ring_load(na);
-            // (a lingering session's launch: as below — a workgroup that is up to date stays for the commands to come, unless
-            // the host says that none will)
-            if (a.p_linger > 100 && (unsigned)(v >> 32) != na + 1
-                && (unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == na)
-              break;
-          } while ((unsigned)(v >> 32) != na + 1 && (long long)wall_clock64() < t_end);
-        }
+        unsigned long long v = session_wait_command<8>(a, ring_load, na + 1u, ring_load(na), (long long)a.p_grace);
         if (lane == 0)
         {
           flags[48] = (int)(unsigned)v;
@@ -366,6 +352,7 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
       // nothing to do (the doorbell this launch was started for has been consumed by its predecessor)
       if (wall == 0 && lane == 0)
       {
+        session_leaving(a);
         a.p_cons[blockIdx.x] = done;
         __hip_atomic_store(a.p_done + blockIdx.x, done | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -673,6 +660,7 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
           {
             __hip_atomic_store(a.p_cmd_count + cslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.p_cmd_done + cslot, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_fetch_max(a.p_cmd_count + a.p_ring_mask + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (il_common.h: session_wait_command)
           }
           if (lane == 0 && (done & 15u) == 0u)
             __hip_atomic_store(a.p_prog + blockIdx.x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -691,23 +679,14 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
           {
             // the early look missed: look again; while the later stages still work, for a microsecond (bounded: the launch
             // never waits for a command)
-            v = ring_load(tag - 1u);
-            const long long t_end = (long long)wall_clock64() + (a.p_linger > 0 ? a.p_linger : 100); // 1 us of the 100 MHz clock unless told otherwise (kernel_a1_q.hip)
-            while ((unsigned)(v >> 32) != tag && (long long)wall_clock64() < t_end)
-            {
-              __builtin_amdgcn_s_sleep(16);
-              v = ring_load(tag - 1u);
-              // a launch that lingers (ticketed host buffers) leaves at once when the host says that nothing follows the
-              // commands this workgroup has consumed (nam_hip_api.cpp: kPRingTail)
-              if (a.p_linger > 100 && (unsigned)(v >> 32) != tag
-                  && (unsigned)__hip_atomic_load(a.p_ring + a.p_ring_mask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag - 1u)
-                break;
-            }
+            v = session_wait_command<16>(a, ring_load, tag, ring_load(tag - 1u), (long long)(a.p_linger > 0 ? a.p_linger : 100)); // (1 us unless the launch lingers)
           }
           // ONE view of the ring slot for the whole wave (lane 0's): the lanes' loads are separate memory requests, and a
           // command that lands between them would split the wave — some lanes leaving, some starting the next buffer
           const unsigned v_tag = (unsigned)uni((int)(unsigned)(v >> 32)), v_off = (unsigned)uni((int)(unsigned)v);
           have = v_tag == tag;
+          if (!have && lane == 0)
+            session_leaving(a); // (the others stop waiting for workgroups behind them: il_common.h)
           const unsigned next_off = v_off * 4u;
           na++;
           if (have)

@@ -787,14 +787,18 @@ __device__ __forceinline__ f2 tanh2(const f2 x)
 {
   if constexpr (FAST)
   {
+    // the rearranged rational of the gate-row kernel (lrow::ratio): q = x^2 + d, |x + e x |x|| = |x| (1 + e |x|), numerator / x =
+    // t1 q + (t2 - d t1) — eight packed instructions, two rcp, two abs
+    constexpr float a1 = (float)(2.45550750702956 - 2.44506634652299 * 0.821226666969744), a0 = (float)(2.45550750702956 - 2.44506634652299 * 0.893229853513558);
     const f2 ax = __builtin_elementwise_abs(x);
-    const f2 x2 = x * x;
-    const f2 k0 = f2{2.45550750702956f, 2.45550750702956f}, k1 = f2{0.893229853513558f, 0.893229853513558f},
-             k2 = f2{0.821226666969744f, 0.821226666969744f}, k3 = f2{2.44506634652299f, 2.44506634652299f},
-             k4 = f2{0.814642734961073f, 0.814642734961073f};
-    const f2 num = x * (__builtin_elementwise_fma(k0, ax, k0) + __builtin_elementwise_fma(k2, ax, k1) * x2);
-    const f2 den = __builtin_elementwise_fma(k3 + x2, __builtin_elementwise_abs(__builtin_elementwise_fma(k4 * x, ax, x)), k3);
-    return f2{num[0] * mf::rcp(den[0]), num[1] * mf::rcp(den[1])};
+    const f2 kd = f2{2.44506634652299f, 2.44506634652299f};
+    const f2 q = __builtin_elementwise_fma(ax, ax, kd);
+    const f2 w = __builtin_elementwise_fma(f2{0.814642734961073f, 0.814642734961073f}, ax, f2{1.0f, 1.0f});
+    const f2 t1 = __builtin_elementwise_fma(f2{0.821226666969744f, 0.821226666969744f}, ax, f2{0.893229853513558f, 0.893229853513558f});
+    const f2 t2 = __builtin_elementwise_fma(f2{a1, a1}, ax, f2{a0, a0});
+    const f2 den = __builtin_elementwise_fma(q, ax * w, kd);
+    const f2 n = __builtin_elementwise_fma(t1, q, t2);
+    return (n * f2{mf::rcp(den[0]), mf::rcp(den[1])}) * x;
   }
   else
   {

@@ -171,6 +171,7 @@ struct PersistSession
   // developer statistics (NAM_HIP_SESSION_STATS=1: printed when the batch is destroyed)
   unsigned long long n_launches = 0, n_host_doorbells = 0, n_stream_doorbells = 0, n_starts = 0, n_flush_relaunches = 0;
   double t_poll = 0, t_out = 0, t_in = 0, t_cmd = 0, t_poll_max = 0, t_out_max = 0, t_in_max = 0, t_cmd_max = 0; // us (NAM_HIP_SESSION_STATS)
+  long long *h_why = nullptr, *d_why = nullptr; // (NAM_HIP_SESSION_STATS) per workgroup: reason << 56 | grace loop << 48 | all-through count << 24 | own count
   unsigned long long n_waits = 0, n_polls = 0; // ticket waits, looks at the buffer's completion word
   unsigned epoch = 0; // counts session starts (a ticket of an earlier session is complete: sessions end flushed)
   bool prog_completes = false; // the running launch publishes its progress word behind every command's results (A1Args::p_out_host == 2)
@@ -701,6 +702,8 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
       a.n_frames = n_frames;
       a.act_p0 = p.a1.arr[0].act_p0; // uniform across arrays and layers for the A1 kernels (plan.cpp)
       a.dbg = b->dbg;
+      if (b->ps_launching && b->ps.h_why)
+        a.dbg = b->ps.d_why; // (NAM_HIP_SESSION_STATS: why a lingering workgroup left — il_common.h: session_wait_command)
       a.n_rings = p.a1.n_rings;
       a.head_scale = p.blob[(size_t)p.a1.head_scale_off];
       a.n_mjobs = a.tiles_off = a.consts_off = 0;
@@ -1079,7 +1082,11 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
     // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
     // linger and leave before the next launch could pick it up again
     if (ps.prog_completes && ps.host_store_ok && ps.n_wg <= b->n_cus)
+    {
       ps.grace = std::max(ps.grace, kTicketLinger);
+      // "a workgroup of this launch has left" (il_common.h: session_leaving; p_cmd_count[mask + 2] = [kPRing + 1]): none yet
+      NAM_HIP_CHECK(hipMemsetAsync(ps.d_cmd_count + kPRing + 1, 0, sizeof(unsigned), ps.kstream));
+    }
   }
   const int keep = b->kernel;
   if (ps.kind == PERSIST_A1_P2)
@@ -1123,6 +1130,16 @@ struct PersistWatch
 
 // Blocks until every submitted command has been consumed by every workgroup and its results are visible.
 // `caller`: the stream the doorbells were rung on.
+inline double stat_now_us()
+{
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool stats_on()
+{
+  static const bool on = [] { const char* e = std::getenv("NAM_HIP_SESSION_STATS"); return e && e[0] == '1'; }();
+  return on;
+}
+
 int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool whole);
 inline void push_out_host_stores();
 int persist_flush(nam_hip_batch* b, hipStream_t caller)
@@ -1208,6 +1225,35 @@ int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool who
       delivered = true;
     }
     ps.n_flush_relaunches++;
+    if (stats_on() && !whole && ps.n_flush_relaunches <= 6)
+    {
+      unsigned mn = ~0u, mx = 0u;
+      int behind = 0;
+      for (int w = 0; w < ps.n_wg; w++)
+      {
+        const unsigned d = ps.h_words[ps.done_off + w] & 0x7fffffffu;
+        mn = std::min(mn, d), mx = std::max(mx, d);
+        behind += (int)(d - target) < 0 ? 1 : 0;
+      }
+      std::fprintf(stderr, "nam_hip relaunch from a wait: target %u, submitted %u, workgroups' counts %u .. %u, %d behind the target\n", target, ps.seq, mn, mx, behind);
+      if (ps.h_why)
+      {
+        int hist[2][5] = {{0}};
+        long long ex[2] = {0, 0};
+        for (int w = 0; w < ps.n_wg; w++)
+        {
+          const long long y = ps.h_why[w];
+          const int grp = (int)((ps.h_words[ps.done_off + w] & 0x7fffffffu) - target) < 0 ? 0 : 1;
+          hist[grp][std::min<int>((int)(y >> 56) & 7, 4)]++;
+          ex[grp] = y;
+          ps.h_why[w] = 0;
+        }
+        for (int g = 0; g < 2; g++)
+          std::fprintf(stderr, "   %s the target: left without a reason recorded %d, leave word %d, cap %d, everybody through %d, somebody left %d; e.g. %s loop, all through %lld, own count %lld\n",
+                       g ? "at / beyond" : "behind", hist[g][0], hist[g][1], hist[g][2], hist[g][3], hist[g][4], ((ex[g] >> 48) & 1) ? "start" : "end-of-buffer",
+                       (ex[g] >> 24) & 0xffffff, ex[g] & 0xffffff);
+      }
+    }
     if (++relaunches > 64)
       return fail(NAM_HIP_ERR_DEVICE, "persistent session: submitted buffers were not consumed");
     const int rc = persist_launch(b, 0);
@@ -1241,11 +1287,17 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
       NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_ring), (kPRing + kPRingTail) * sizeof(unsigned long long)));
     }
     NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_cons), (size_t)b->n_streams * sizeof(unsigned)));
-    NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_cmd_count), kPRing * sizeof(unsigned)));
-    NAM_HIP_CHECK(hipMemset(ps.d_cmd_count, 0, kPRing * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ps.d_cmd_count), (kPRing + kPRingTail) * sizeof(unsigned))); // ([kPRing]: the highest command every workgroup is through)
+    NAM_HIP_CHECK(hipMemset(ps.d_cmd_count, 0, (kPRing + kPRingTail) * sizeof(unsigned)));
     NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_cmd_done), kPRing * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
     NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_cmd_done), ps.h_cmd_done, 0));
     std::memset(ps.h_cmd_done, 0, kPRing * sizeof(unsigned));
+    if (stats_on())
+    {
+      NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_why), (size_t)b->n_streams * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+      NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_why), ps.h_why, 0));
+      std::memset(ps.h_why, 0, (size_t)b->n_streams * sizeof(long long));
+    }
     NAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ps.h_words), 2 * (size_t)b->n_streams * sizeof(unsigned),
                                 hipHostMallocMapped | hipHostMallocCoherent));
     NAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ps.d_words), ps.h_words, 0));
@@ -1275,7 +1327,7 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     NAM_HIP_CHECK(hipMemset(ps.d_ring, 0, kPRing * sizeof(unsigned long long)));
     NAM_HIP_CHECK(hipMemset(ps.d_ring + kPRing, 0xff, kPRingTail * sizeof(unsigned long long))); // (the "leave" word: no count)
     NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
-    NAM_HIP_CHECK(hipMemset(ps.d_cmd_count, 0, kPRing * sizeof(unsigned)));
+    NAM_HIP_CHECK(hipMemset(ps.d_cmd_count, 0, (kPRing + kPRingTail) * sizeof(unsigned)));
     NAM_HIP_CHECK(hipDeviceSynchronize());
     std::memset(ps.h_cmd_done, 0, kPRing * sizeof(unsigned)); // (tags of the old numbering)
     for (int w = 0; w < b->n_streams; w++)
@@ -1474,6 +1526,8 @@ void persist_free(nam_hip_batch* b)
     (void)hipFree(ps.d_cmd_count);
   if (ps.h_cmd_done)
     (void)hipHostFree(ps.h_cmd_done);
+  if (ps.h_why)
+    (void)hipHostFree(ps.h_why);
   if (ps.h_words)
     (void)hipHostFree(ps.h_words);
   if (ps.kstream)
@@ -1723,16 +1777,6 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
         out_f64[r * n_frames + i] = (double)src[i];
   }
   return NAM_HIP_OK;
-}
-
-inline double stat_now_us()
-{
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-inline bool stats_on()
-{
-  static const bool on = [] { const char* e = std::getenv("NAM_HIP_SESSION_STATS"); return e && e[0] == '1'; }();
-  return on;
 }
 
 // ---- ticketed host buffers (include/nam_hip.h: nam_hip_batch_submit_f32 / nam_hip_batch_wait_f32) ----
