@@ -122,3 +122,58 @@ def test_ticket_rules(nam_lib):
     with pytest.raises(nam.NamHipError):
         b.submit(np.zeros((n, 1, frames + 1), dtype=np.float32))  # more than max_frames
     b.close()
+
+
+@pytest.mark.parametrize("case", ["a1_standard", "A2", "lstm", "a1_standard_no_session"])
+def test_tickets_mixed_with_everything_else(nam_lib, case):
+    """a seeded random walk over the entry points of one batch — submit (whole and ragged lengths), wait (any ticket in flight),
+    the blocking call, flush, synchronize, and a Reset now and then — against a second batch that renders the same audio with
+    blocking calls only: the buffers must come out the same whatever travelled as a ticket"""
+    nam = nam_lib
+    name = {"a1_standard": "wavenet_a1_standard", "A2": "A2", "lstm": "lstm", "a1_standard_no_session": "wavenet_a1_standard"}[case]
+    persistent = case != "a1_standard_no_session"
+    rng = np.random.default_rng(991 + len(case))
+    n, max_frames = 40, 256
+    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    ref_b = model.batch(n, max_frames)
+    ref_b.set_persistent(persistent)
+    ref_b.Reset(prewarm=True)
+    b = model.batch(n, max_frames)
+    b.set_persistent(persistent)
+    b.Reset(prewarm=True)
+    in_flight = {}  # ticket -> the reference rendering of its buffer
+    checked = submitted = 0
+
+    def check(got, want):
+        nonlocal checked
+        scale = max(1.0, float(np.abs(want).max()))
+        assert got.shape == want.shape and float(np.abs(got - want).max()) <= 2e-5 * scale
+        checked += 1
+
+    for step in range(400):
+        op = rng.choice(["submit", "submit", "submit", "wait", "wait", "process", "flush", "sync", "reset"], p=[0.22, 0.22, 0.1, 0.2, 0.1, 0.08, 0.03, 0.03, 0.02])
+        if op == "submit" and (submitted - nam.Batch.PIPE_SLOTS) not in in_flight:  # (ticket t + 16 takes the slot of ticket t)
+            submitted += 1
+            frames = int(rng.choice([64, 64, 128, 192, 256, 100, 37]))
+            x = stream_bank(n, frames, seed=int(rng.integers(1 << 30)))
+            want = ref_b.process(x)
+            in_flight[b.submit(x)] = want
+        elif op == "wait" and in_flight:
+            t = int(rng.choice(sorted(in_flight)))
+            check(b.wait(t), in_flight.pop(t))
+        elif op == "process":
+            frames = int(rng.choice([64, 128, 256, 90]))
+            x = stream_bank(n, frames, seed=int(rng.integers(1 << 30)))
+            check(b.process(x), ref_b.process(x))
+        elif op == "flush":
+            b.flush()
+        elif op == "sync":
+            b.synchronize()
+        elif op == "reset":
+            b.Reset(prewarm=True)  # (tickets in flight complete first and keep their outputs)
+            ref_b.Reset(prewarm=True)
+    for t in sorted(in_flight):
+        check(b.wait(t), in_flight[t])
+    assert checked > 100
+    b.close()
+    ref_b.close()
