@@ -436,11 +436,16 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
       kq_sb_store4(in0, rs, widx, 0, kq::ring_off(JI) * 4, WT && !PERSIST ? 17 : 0);
       kq_sb_store4(in1, rs, widx, 16, kq::ring_off(JI) * 4, WT && !PERSIST ? 17 : 0);
     }
+    unsigned old16 = 0; // resident ring: byte offset of the lane's OLDEST tap row, (position - T + frame) mod R; tap j is j d rows on
     if constexpr (T > kBlock)
     {
-      // the resident ring: row (position + frame) mod R, as the append to the HBM ring would have it
-      const unsigned v = (unsigned)(wpj + frame);
-      const unsigned cur16 = min(v, v - (unsigned)RL) * 16u;
+      int sb_ = wpj - T;
+      sb_ += sb_ < 0 ? RL : 0;
+      const unsigned v = (unsigned)(sb_ + frame);
+      old16 = min(v, v - (unsigned)RL) * 16u;
+      // this buffer's row: (position + frame) mod R, as the append to the HBM ring would have it = T rows on from the oldest tap
+      const unsigned c = old16 + (unsigned)(T * 16);
+      const unsigned cur16 = min(c, c - (unsigned)(RL * 16));
       lds_st4(lds, (unsigned)WB0 + cur16, in0);
       lds_st4(lds, (unsigned)WB1 + cur16, in1);
       asm volatile("" ::: "memory");
@@ -491,10 +496,9 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
           b0 = rows[F0 + kq::far_before(JI, j)].q0, b1 = rows[F0 + kq::far_before(JI, j)].q1;
         else if constexpr (T > kBlock)
         {
-          int sb_ = wpj - L;
-          sb_ += sb_ < 0 ? RL : 0;
-          const unsigned v = (unsigned)(sb_ + frame);
-          const unsigned a16 = min(v, v - (unsigned)RL) * 16u;
+          // (T - L) rows on from the oldest tap's row, wrapped once: three vector instructions, no scalar ones
+          const unsigned c = old16 + (unsigned)((T - L) * 16);
+          const unsigned a16 = L == T ? old16 : min(c, c - (unsigned)(RL * 16));
           b0 = lds_ld4(lds, (unsigned)WB0 + a16);
           b1 = lds_ld4(lds, (unsigned)WB1 + a16);
         }
