@@ -262,6 +262,9 @@ NAM_HIP_API int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream);
 #define NAM_HIP_PIPE_SLOTS 16
 NAM_HIP_API int nam_hip_batch_submit_f32(nam_hip_batch* batch, const float* in, int n_frames, int64_t* out_ticket);
 NAM_HIP_API int nam_hip_batch_wait_f32(nam_hip_batch* batch, int64_t ticket, float* out);
+/* The same for callers built with NAM_SAMPLE = double (NAM/dsp.h:18-22): cast in as NAM/wavenet/model.cpp:817, out as :896. */
+NAM_HIP_API int nam_hip_batch_submit_f64(nam_hip_batch* batch, const double* in, int n_frames, int64_t* out_ticket);
+NAM_HIP_API int nam_hip_batch_wait_f64(nam_hip_batch* batch, int64_t ticket, double* out);
 
 /* Wait for everything enqueued on the batch's own stream (and on the last caller-supplied one). Ends a persistent
  * session: afterwards nothing of the batch is running on the device (a device-wide hipDeviceSynchronize would

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "nam_hip_batch_reset", "nam_hip_batch_set_slimmable_size", "nam_hip_batch_process_f32",
     "nam_hip_batch_process_f64", "nam_hip_batch_process_device", "nam_hip_batch_render_f32", "nam_hip_batch_synchronize",
     "nam_hip_batch_set_kernel", "nam_hip_batch_get_kernel", "nam_hip_batch_n_streams", "nam_hip_batch_kernel_name",
-    "nam_hip_batch_set_persistent", "nam_hip_batch_flush", "nam_hip_batch_submit_f32", "nam_hip_batch_wait_f32",
+    "nam_hip_batch_set_persistent", "nam_hip_batch_flush", "nam_hip_batch_submit_f32", "nam_hip_batch_wait_f32", "nam_hip_batch_submit_f64", "nam_hip_batch_wait_f64",
     "nam_hip_batch_debug_timeline",
     "nam_hip_model_load_parts", "nam_hip_model_get_string", "nam_hip_model_get_weights", "nam_hip_sample_rate_from_nam",
     "nam_hip_batch_kernel_name_for", "nam_hip_version_support", "nam_hip_device_count",
@@ -138,6 +138,8 @@ def load_library():
     L.nam_hip_batch_render_f32.argtypes = [vp, vp, vp, vp]
     L.nam_hip_batch_submit_f32.argtypes = [vp, vp, ci, ctypes.POINTER(ctypes.c_int64)]
     L.nam_hip_batch_wait_f32.argtypes = [vp, ctypes.c_int64, vp]
+    L.nam_hip_batch_submit_f64.argtypes = [vp, vp, ci, ctypes.POINTER(ctypes.c_int64)]
+    L.nam_hip_batch_wait_f64.argtypes = [vp, ctypes.c_int64, vp]
     L.nam_hip_batch_synchronize.argtypes = [vp]
     L.nam_hip_batch_set_kernel.argtypes = [vp, ci]
     L.nam_hip_batch_get_kernel.argtypes = [vp]
@@ -373,24 +375,29 @@ class Batch:
             x = x[:, None, :]
         if x.shape[0] != self.n_streams or x.shape[1] != ic:
             raise ValueError(f"expected input [{self.n_streams}, {ic}, n], got {tuple(x.shape)}")
-        x = np.ascontiguousarray(x, dtype=np.float32)
+        f64 = x.dtype == np.float64  # (NAM_SAMPLE = double callers: wait() hands float64 back)
+        x = np.ascontiguousarray(x, dtype=np.float64 if f64 else np.float32)
         t = ctypes.c_int64(-1)
-        _check(self._L.nam_hip_batch_submit_f32(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[2], ctypes.byref(t)))
-        self._ticket_frames[t.value] = x.shape[2]
+        fn = self._L.nam_hip_batch_submit_f64 if f64 else self._L.nam_hip_batch_submit_f32
+        _check(fn(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[2], ctypes.byref(t)))
+        self._ticket_frames[t.value] = (x.shape[2], f64)
         return t.value
 
     def wait(self, ticket: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Blocks until the buffer behind `ticket` is rendered; returns [n_streams, out_channels, n] float32 (into `out` if given)."""
-        n = self._ticket_frames.get(ticket)
-        if n is None:  # (the library words the error)
+        entry = self._ticket_frames.get(ticket)
+        if entry is None:  # (the library words the error)
             _check(self._L.nam_hip_batch_wait_f32(self._h, int(ticket), None))
             raise ValueError(f"ticket {ticket} is not in flight")
+        n, f64 = entry
+        dt = np.float64 if f64 else np.float32
         oc = self.model.NumOutputChannels()
         if out is None:
-            out = np.empty((self.n_streams, oc, n), dtype=np.float32)
-        elif out.dtype != np.float32 or not out.flags.c_contiguous or out.size != self.n_streams * oc * n:
-            raise ValueError("out: a C-contiguous float32 array of n_streams x out_channels x n")
-        _check(self._L.nam_hip_batch_wait_f32(self._h, int(ticket), out.ctypes.data_as(ctypes.c_void_p)))
+            out = np.empty((self.n_streams, oc, n), dtype=dt)
+        elif out.dtype != dt or not out.flags.c_contiguous or out.size != self.n_streams * oc * n:
+            raise ValueError("out: a C-contiguous array of n_streams x out_channels x n in the submit's sample type")
+        fn = self._L.nam_hip_batch_wait_f64 if f64 else self._L.nam_hip_batch_wait_f32
+        _check(fn(self._h, int(ticket), out.ctypes.data_as(ctypes.c_void_p)))
         del self._ticket_frames[ticket]
         return out
 

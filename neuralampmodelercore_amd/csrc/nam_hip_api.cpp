@@ -220,6 +220,7 @@ struct nam_hip_batch
   long long pipe_next = 0; // the next ticket
   bool pipe_session = false; // the session serves ticketed buffers: its launches publish every command (PersistSession::prog_completes)
   float *pipe_h_in = nullptr, *pipe_h_out = nullptr, *pipe_d_in = nullptr, *pipe_d_out = nullptr; // staging of the copying form ([slot][row][max_frames])
+  std::vector<float> pipe_cvt; // the _f64 forms of submit / wait: one buffer of float32 on the way in / out
   int kernel = NAM_HIP_KERNEL_AUTO;
   long long* dbg = nullptr; // device buffer of the profiling instantiation (nam_hip_batch_debug_timeline)
   bool was_reset = false;
@@ -2474,6 +2475,44 @@ int nam_hip_batch_wait_f32(nam_hip_batch* batch, int64_t ticket, float* out)
   return guarded([&]() -> int {
     NAM_HIP_CHECK(hipSetDevice(batch->device));
     return pipe_wait(batch, sl, slot, out);
+  });
+}
+
+// NAM_SAMPLE = double callers (NAM/dsp.h:18-22): the casts of the blocking _f64 form (in: model.cpp:817, out: :896) around the float32 ticket
+int nam_hip_batch_submit_f64(nam_hip_batch* batch, const double* in, int n_frames, int64_t* out_ticket)
+{
+  if (!batch || !in || !out_ticket || n_frames <= 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_submit_f64: bad argument");
+  if (n_frames > batch->max_frames)
+    return fail(NAM_HIP_ERR_TOO_MANY_FRAMES, "nam_hip_batch_submit_f64: n_frames exceeds max_frames");
+  return guarded([&]() -> int {
+    const size_t n_in = (size_t)batch->n_streams * batch->model->spec->in_channels() * n_frames;
+    const size_t cap = (size_t)batch->n_streams * std::max(batch->model->spec->in_channels(), batch->model->spec->out_channels()) * batch->max_frames;
+    if (batch->pipe_cvt.size() < cap)
+      batch->pipe_cvt.resize(cap);
+    for (size_t i = 0; i < n_in; i++)
+      batch->pipe_cvt[i] = (float)in[i];
+    return nam_hip_batch_submit_f32(batch, batch->pipe_cvt.data(), n_frames, out_ticket);
+  });
+}
+
+int nam_hip_batch_wait_f64(nam_hip_batch* batch, int64_t ticket, double* out)
+{
+  if (!batch || ticket < 0)
+    return fail(NAM_HIP_ERR_INVALID_ARGUMENT, "nam_hip_batch_wait_f64: bad argument");
+  return guarded([&]() -> int {
+    const PipeSlot& sl = batch->pipe[(int)(ticket % NAM_HIP_PIPE_SLOTS)];
+    const int n_frames = sl.n_frames; // (of the ticket, if it is the one in flight: the f32 form checks that)
+    const size_t cap = (size_t)batch->n_streams * std::max(batch->model->spec->in_channels(), batch->model->spec->out_channels()) * batch->max_frames;
+    if (batch->pipe_cvt.size() < cap)
+      batch->pipe_cvt.resize(cap);
+    const int rc = nam_hip_batch_wait_f32(batch, ticket, out ? batch->pipe_cvt.data() : nullptr);
+    if (rc != NAM_HIP_OK || !out)
+      return rc;
+    const size_t n_out = (size_t)batch->n_streams * batch->model->spec->out_channels() * n_frames;
+    for (size_t i = 0; i < n_out; i++)
+      out[i] = (double)batch->pipe_cvt[i];
+    return NAM_HIP_OK;
   });
 }
 

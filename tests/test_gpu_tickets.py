@@ -177,3 +177,26 @@ def test_tickets_mixed_with_everything_else(nam_lib, case):
     assert checked > 100
     b.close()
     ref_b.close()
+
+
+def test_tickets_in_double_precision_buffers(nam_lib):
+    """NAM_SAMPLE = double callers (NAM/dsp.h:18-22): nam_hip_batch_submit_f64 / nam_hip_batch_wait_f64 against the blocking
+    _f64 call — the same casts in (model.cpp:817) and out (:896), so the same doubles"""
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    n, frames, nb = 20, 128, 10
+    x = stream_bank(n, nb * frames, seed=5).astype(np.float64)
+    ref_b = model.batch(n, frames)
+    ref_b.set_persistent(True)
+    ref_b.Reset(prewarm=True)
+    want = ref_b.process_stream(x, frames)
+    ref_b.close()
+    assert want.dtype == np.float64
+    b = model.batch(n, frames)
+    b.set_persistent(True)
+    b.Reset(prewarm=True)
+    got = _feed(b, x, frames, 4)
+    b.close()
+    assert got.dtype == np.float64 and got.shape == want.shape
+    assert float(np.abs(got - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+    assert np.array_equal(got, got.astype(np.float32).astype(np.float64))  # (float32 values widened, as the reference's cast out)

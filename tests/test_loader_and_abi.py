@@ -314,4 +314,8 @@ def test_ticket_entry_points_refuse_bad_arguments(nam_lib):
     assert b"nam_hip_batch_submit_f32" in L.nam_hip_last_error()
     assert L.nam_hip_batch_wait_f32(None, 0, x) == nam_lib.ERR_INVALID_ARGUMENT
     assert b"nam_hip_batch_wait_f32" in L.nam_hip_last_error()
+    xd = (ctypes.c_double * 64)()
+    assert L.nam_hip_batch_submit_f64(None, xd, 64, ctypes.byref(t)) == nam_lib.ERR_INVALID_ARGUMENT
+    assert L.nam_hip_batch_wait_f64(None, 0, xd) == nam_lib.ERR_INVALID_ARGUMENT
+    assert b"nam_hip_batch_wait_f64" in L.nam_hip_last_error()
     assert nam_lib.Batch.PIPE_SLOTS == int(re.search(r"#define NAM_HIP_PIPE_SLOTS (\d+)", open(os.path.join(ROOT, "include", "nam_hip.h")).read()).group(1))
