@@ -257,7 +257,8 @@ NAM_HIP_API int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream);
  * kernels' tickets complete when the launch has drained its ring. (The pipeline of nam_a1_q_kernel holds five to six
  * 64-frame buffers at a time: keep at least eight in flight at that size, four at 256 frames.) Outside persistent mode: pinned staging, copies and the
  * launch enqueued on the batch's stream, an event behind them. Control calls (Reset, SetSlimmableSize, set_kernel,
- * synchronize) complete the tickets in flight first; their outputs stay available to wait. The blocking process calls
+ * synchronize) complete the tickets in flight first; their outputs stay available to wait. A ticket session's launch
+ * looks for the next buffer for 200 us before it leaves (NAM_HIP_TICKET_LINGER_US; it holds its CUs meanwhile). The blocking process calls
  * may be mixed in (tickets in flight complete first). */
 #define NAM_HIP_PIPE_SLOTS 16
 NAM_HIP_API int nam_hip_batch_submit_f32(nam_hip_batch* batch, const float* in, int n_frames, int64_t* out_ticket);

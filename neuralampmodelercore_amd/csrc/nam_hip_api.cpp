@@ -128,8 +128,15 @@ constexpr unsigned kPRing = 1024; // commands in flight at most (power of two)
 // the host stores the session's command count there when it wants the launch gone (a flush, the end of the session): a
 // workgroup that has consumed exactly that many commands and finds no next one leaves at once instead of lingering
 constexpr unsigned kPRingTail = 8;
-constexpr int kTicketLinger = 20000; // 200 us of the 100 MHz clock: workgroups drift apart by up to NAM_HIP_PIPE_SLOTS buffers (16 x 5.3 us) —
+constexpr int kTicketLingerDefault = 20000; // 200 us of the 100 MHz clock: workgroups drift apart by up to NAM_HIP_PIPE_SLOTS buffers (16 x 5.3 us) —
                                      // the one in front must outwait the host, which hands the next buffer in when the LAST one has finished an old one
+// (NAM_HIP_TICKET_LINGER_US overrides it; 0 or 1: a ticket session's launch leaves as promptly as any other — for hosts that run several
+// sessions on one device, where a lingering launch of one holds the CUs the other's launch is waiting for)
+inline int ticket_linger_from_env() // (read when a batch is created, like the other switches)
+{
+  const char* e = std::getenv("NAM_HIP_TICKET_LINGER_US");
+  return e ? (int)std::min(std::max(std::atol(e), 0l), 100000l) * 100 : kTicketLingerDefault;
+}
 struct PersistSession
 {
   bool enabled = false; // the caller opted in
@@ -235,6 +242,7 @@ struct nam_hip_batch
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
   bool use_q = true; // the official 16 / 8 topology's pipeline runs nam_a1_q_kernel (kernel_a1_q.hip); NAM_HIP_A1Q=0: nam_a1_p4_kernel (A/B runs)
   bool use_kq = true; // the A2 topology's pipeline runs nam_kq_kernel (kernel_kq.hip) where it applies; NAM_HIP_KQ=0: nam_kp_kernel everywhere
+  int ticket_linger = kTicketLingerDefault; // ticks of the 100 MHz clock a ticket session's launch looks for the next buffer (NAM_HIP_TICKET_LINGER_US)
   int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
   bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
   PersistSession ps;
@@ -749,7 +757,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
-          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? kTicketLinger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
+          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -792,7 +800,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
-          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? kTicketLinger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
+          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -1084,7 +1092,7 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
     // linger and leave before the next launch could pick it up again
     if (ps.prog_completes && ps.host_store_ok && ps.n_wg <= b->n_cus)
     {
-      ps.grace = std::max(ps.grace, kTicketLinger);
+      ps.grace = std::max(ps.grace, b->ticket_linger);
       // "a workgroup of this launch has left" (il_common.h: session_leaving; p_cmd_count[mask + 2] = [kPRing + 1]): none yet
       NAM_HIP_CHECK(hipMemsetAsync(ps.d_cmd_count + kPRing + 1, 0, sizeof(unsigned), ps.kstream));
     }
@@ -2180,6 +2188,7 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
     b->il_generic = e && e[0] == '1';
     if (const char* e4 = std::getenv("NAM_HIP_WR_STAGES"))
       b->wr_max_stages = std::max(1, std::atoi(e4));
+    b->ticket_linger = ticket_linger_from_env();
     const char* e6 = std::getenv("NAM_HIP_A1Q");
     b->use_q = !(e6 && e6[0] == '0');
     const char* e5 = std::getenv("NAM_HIP_KQ");

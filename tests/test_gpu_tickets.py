@@ -200,3 +200,39 @@ def test_tickets_in_double_precision_buffers(nam_lib):
     assert got.dtype == np.float64 and got.shape == want.shape
     assert float(np.abs(got - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
     assert np.array_equal(got, got.astype(np.float32).astype(np.float64))  # (float32 values widened, as the reference's cast out)
+
+
+@pytest.mark.parametrize("linger_us", [None, "0"])
+def test_two_ticket_sessions_share_one_device(nam_lib, monkeypatch, linger_us):
+    """two batches with tickets in flight at the same time, more workgroups between them than the chip holds at once: each
+    session's launch has to make room for the other's (by default after its linger; NAM_HIP_TICKET_LINGER_US=0: at once) —
+    every buffer of both against the blocking call"""
+    nam = nam_lib
+    if linger_us is not None:
+        monkeypatch.setenv("NAM_HIP_TICKET_LINGER_US", linger_us)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    n, frames, nb = 200, 64, 16
+    xs = [stream_bank(n, nb * frames, seed=31 + i) for i in range(2)]
+    wants = []
+    for x in xs:
+        ref_b = model.batch(n, frames)
+        ref_b.set_persistent(True)
+        ref_b.Reset(prewarm=True)
+        wants.append(ref_b.process_stream(x, frames))
+        ref_b.close()
+    bs = [model.batch(n, frames) for _ in range(2)]
+    for b in bs:
+        b.set_persistent(True)
+        b.Reset(prewarm=True)
+    tickets, ys = [[], []], [[], []]
+    for k in range(nb):
+        for i, b in enumerate(bs):
+            if len(tickets[i]) == 4:
+                ys[i].append(b.wait(tickets[i].pop(0)))
+            tickets[i].append(b.submit(xs[i][:, k * frames:(k + 1) * frames]))
+    for i, b in enumerate(bs):
+        while tickets[i]:
+            ys[i].append(b.wait(tickets[i].pop(0)))
+        b.close()
+        got = np.concatenate(ys[i], axis=2)
+        assert float(np.abs(got - wants[i]).max()) <= 2e-5 * max(1.0, float(np.abs(wants[i]).max()))
