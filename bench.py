@@ -853,7 +853,8 @@ def main():
                 "floor_frac": None if floor_us is None else round(floor_us / (wall_launch_s * 1e6), 4),
                 "floor_frac_basis": "floor_us / wall time per step: floor_us = max over `floor_parts_us` — measured HBM bytes at 6.3 TB/s, "
                                     "algorithmic flops at 157.3 TFLOP/s, (fp32 MFMA pipe cycles + 4 x other vector instructions) per SIMD at "
-                                    "2.4 GHz (the matrix / vector issue port; the two never co-execute here) — from the PMC passes in profiles/",
+                                    "2.4 GHz (the matrix / vector issue port; the two never co-execute here; LDS, scalar and wait instructions are NOT counted, so "
+                                    "this part is a lower bound of the issue time: DESIGN 9) — from the PMC passes in profiles/",
                 "floor_parts_us": None if floor_parts is None else {k_: round(v_, 3) for k_, v_ in floor_parts.items()},
                 "bound": "hbm", "achieved": round(contract_gbs_wall, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(contract_gbs_wall / HBM_PEAK_GBS, 4),
