@@ -112,7 +112,8 @@ for e in entries:
 # round 4: scripts/gpu_prof_resident.sh writes counters_<tag>.json = {kernel, ns_per_step, per_step: {counter: value}} — a 300-step
 # resident launch of a later repetition (settled clocks), every counter divided by 300
 RESIDENT_R4 = [("r04", "counters_c2_q_resident.json", "nam_a1_q_kernel", "wavenet_a1_standard", 256),
-               ("r04", "counters_a2_kq_resident.json", "nam_kq_kernel", "A2", 256)]
+               ("r04", "counters_a2_kq_resident.json", "nam_kq_kernel", "A2", 256),
+               ("r04", "counters_c3_lstm_row_resident.json", "nam_lstm_row_kernel", "lstm", 1024)]
 for rnd, name, kernel, model, streams in RESIDENT_R4:
     path = os.path.join(ROOT, "profiles", rnd, name)
     if not os.path.exists(path):
