@@ -46,6 +46,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achi
 HBM_ACHIEVABLE_GBS = 6300.0
 LDS_PEAK_TBS = 150.0  # MI355X_MICROARCH.md, LDS: ~150 TB/s for ds_read_b64/b128 with every CU streaming at ~2.4 GHz
 LDS_CLOCK_HZ = 2.4e9
+# issue-port cycles per non-matrix vector instruction of a SIMD when an entry of profiles/traffic.json does not carry its own
+# figure: 3 waves per SIMD issue v_fma at 3.01 cycles per SIMD-instruction (profiles/r04/valu_rate_microbench.txt)
+ISSUE_CPI_DEFAULT = 3.0
 
 
 def wavenet_history_bytes_per_sample(cfg: dict) -> int:
@@ -290,7 +293,7 @@ def run_other_configs(args):
     for c in ("2_steady", 3, 4, 5, "A2"):
         sel = ["--model", "A2", "--streams", "256"] if c == "A2" else ["--config", "2" if c == "2_steady" else str(c)]
         cmd = [sys.executable, os.path.abspath(__file__)] + sel + ["--gpus", "1", "--steps", "500", "--warmup", "50",
-               "--brief", "--persistent", str(args.persistent), "--fast-tanh", str(args.fast_tanh)]
+               "--brief", "--full-line", "--persistent", str(args.persistent), "--fast-tanh", str(args.fast_tanh)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         t0 = time.perf_counter()
@@ -474,6 +477,86 @@ def percentile(sorted_vals, q):
     return sorted_vals[i]
 
 
+LINE_LIMIT = 6000  # bytes: the driver keeps an 8 KB tail of stdout and parses the last line out of it (round 4's 25 KB line was cut)
+
+
+def _brief_config(r):
+    """One other configuration of the default run, in a few numbers."""
+    if not isinstance(r, dict) or "value" not in r:
+        return {"error": str((r or {}).get("error", "no line"))[:120]}
+    rf = r.get("roofline") or {}
+    return {"value": r["value"], "ms_per_step": r.get("ms_per_step"), "kernel": (r.get("config") or {}).get("kernel"),
+            "bound": rf.get("bound"), "frac": rf.get("frac"), "floor_frac": rf.get("floor_frac"),
+            "max_abs_err_vs_oracle": r.get("max_abs_err_vs_oracle"),
+            "cpu_baseline": (r.get("cpu_baseline") or {}).get("value")}
+
+
+def compact_line(out: dict, full_path) -> dict:
+    """The ONE line the driver parses: contract keys, `roofline`, `cpu_baseline` and a handful of figures, numbers and short
+    names only. Everything else this file measures (every region's time, prose notes, the other configurations' own
+    rooflines, host_io by buffer size) is in the full record: `full_path` (gpurun_out/bench_full.json), or --full-line."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "finite", "max_abs_err_vs_oracle")
+    line = {k: out[k] for k in keep if k in out}
+    c = out.get("config") or {}
+    line["config"] = {k: c[k] for k in ("workload", "baseline_config", "streams_per_gpu", "block", "launch", "kernel",
+                                         "persistent_block_mode", "sharding") if k in c}
+    rf = out.get("roofline") or {}
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "floor_frac",
+                                                "floor_parts_us", "issue_cycles_per_valu_inst", "counter_hbm_frac", "source")}
+    if rf.get("hbm_contract"):
+        line["roofline"]["hbm_contract"] = {k: rf["hbm_contract"].get(k) for k in ("achieved", "unit", "frac", "label")}
+    if rf.get("lds"):
+        line["roofline"]["lds"] = {k: rf["lds"].get(k) for k in ("achieved", "peak", "frac", "array_busy_frac")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        for k in ("O2", "all_host_cores", "reference_sources_on_eigen_stand_in"):
+            if isinstance(cb.get(k), dict) and "value" in cb[k]:
+                line["cpu_baseline"][k] = {"value": cb[k]["value"], "cores": cb[k].get("cores")}
+    rep = out.get("repetitions") or {}
+    line["repetitions"] = {k: rep.get(k) for k in ("n", "untimed_in_front", "ms_per_step_min", "ms_per_step_max")}
+    if out.get("region_us"):
+        line["region_us"] = out["region_us"]
+    if out.get("latency_us"):
+        line["latency_us"] = {k: out["latency_us"].get(k) for k in ("min", "p50", "p99", "p99_9")}
+    if out.get("resident_launch"):
+        line["resident_launch"] = {k: out["resident_launch"].get(k) for k in ("value", "ms_per_step")}
+    for k in ("zeros_input", "fast_tanh_off", "fast_tanh_on"):
+        if isinstance(out.get(k), dict):
+            line[k] = {q: out[k].get(q) for q in ("value", "ms_per_step", "kernel", "max_abs_err_vs_oracle")}
+    if isinstance(out.get("steady_state"), dict):
+        line["steady_state"] = {k: out["steady_state"].get(k) for k in ("value", "ms_per_step", "steps_per_region", "floor_frac", "compute_frac")}
+    if isinstance(out.get("other_configs"), dict):
+        line["other_configs"] = {k: _brief_config(v) for k, v in out["other_configs"].items() if k != "2_steady"}
+    hio = out.get("host_io")
+    if isinstance(hio, dict):
+        line["host_io"] = ({"error": str(hio["error"])[:120]} if "error" in hio else
+                           {k: {m: v[m]["value"] for m in ("blocking", "tickets") if m in v} for k, v in hio.items() if isinstance(v, dict)})
+    line["full_record"] = full_path
+    # a guard, not a plan: shed the optional blocks (least important first) should the line ever outgrow the limit
+    for k in ("host_io", "zeros_input", "resident_launch", "latency_us", "region_us", "repetitions", "other_configs"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def write_full_record(out: dict):
+    """The whole record next to the profiles' scratch (gpurun_out/ travels back from a gpurun box); None if nowhere to write."""
+    for d in (os.path.join(ROOT, "gpurun_out"), "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_full.json")
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            return os.path.relpath(path, ROOT) if d.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2:])
@@ -511,6 +594,9 @@ def main():
     ap.add_argument("--brief", action="store_true",
                     help="a short run for the `other_configs` block of the default invocation: no latency pass / side runs / "
                          "resident comparison, a ~2 s CPU baseline")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole record as the line (default: a compact line of at most 6 KB, the whole record goes to "
+                         "gpurun_out/bench_full.json)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default invocation (config 2, one GPU): do not append brief runs of configs 3, 4 and 5")
     args = ap.parse_args()
@@ -735,11 +821,26 @@ def main():
     # side runs on rank 0 (N = 1): fast_tanh OFF and an all-zeros input (benchmodel's own input, tools/benchmodel.cpp:103-132)
     side = {}
     if rank == 0 and world == 1 and not args.no_side_runs and not args.dry_run:
-        def quick(engine2, xin):
+        def quick(engine2, xin, check_fast_tanh=None):
             # the headline's own protocol on another engine / input: the same launch mode (persistent block mode when the
             # headline runs it), warm-up steps, fence, a region of exactly K steps, fence; untimed regions of the same
             # shape in front (clocks settle under this duty cycle), the median of the timed ones
             engine2.bind(xin, y)
+            err = None
+            if check_fast_tanh is not None and args.check:
+                # a fresh engine (Reset + prewarm, nothing run yet): its first pass over the window against the oracle with the
+                # same activation setting — the session-mode instantiation of the kernel with libm tanh is CHECKED, not only timed
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import nam_oracle
+                engine2.run_steps(0, W + K, args.launch)
+                engine2.sync()
+                ref2 = nam_oracle.get_dsp(model_path, fast_tanh=check_fast_tanh)
+                if slim_mix:
+                    ref2.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[0]]])
+                ref2.Reset(SR, block)
+                sig2 = bank[mine[0], :n_chk]
+                r2 = ref2.process_stream(np.repeat(sig2[None, :], ic, axis=0) if ic > 1 else sig2, block)[0]
+                err = float(np.max(np.abs(r2 - y[0, 0, :n_chk].cpu().numpy())))
             ts = []
             n_pre, n_rep = min(P, 60), min(R, 21)
             for rep in range(-n_pre, n_rep):
@@ -753,13 +854,13 @@ def main():
             ts.sort()
             return {"value": round(n_streams * block * K / SR / ts[len(ts) // 2], 1), "ms_per_step": round(ts[len(ts) // 2] / K * 1e3, 6),
                     "kernel": engine2.kernel_name(), "persistent_block_mode": bool(getattr(engine2, "persistent", False)),
-                    "regions": len(ts), "untimed_in_front": n_pre}
+                    "regions": len(ts), "untimed_in_front": n_pre, "max_abs_err_vs_oracle": err}
         side["zeros_input"] = quick(engine, torch.zeros_like(x))
         engine.bind(x, y)
         m2 = nam.get_dsp(model_path, fast_tanh=not bool(args.fast_tanh))
         e2 = HipEngine(nam, torch, m2, n_streams, block, local_rank, args.kernel, local_classes,
                        persistent=bool(args.persistent) and args.launch == "block")
-        side["fast_tanh_off" if args.fast_tanh else "fast_tanh_on"] = quick(e2, x)
+        side["fast_tanh_off" if args.fast_tanh else "fast_tanh_on"] = quick(e2, x, check_fast_tanh=not bool(args.fast_tanh))
         e2.close()
 
     if rank == 0:
@@ -806,13 +907,64 @@ def main():
         # MFMA occupies the port for its pass count (SQ_VALU_MFMA_BUSY_CYCLES), every other vector instruction for one
         # quad-cycle, and the two never overlap on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every profile of this repo).
         floor_parts = None
+        issue_cpi = None
         if tr is not None:
             floor_parts = {"hbm_us": traffic_b / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6, "fp32_us": flops_per_launch / (FP32_PEAK_TFLOPS * 1e12) * 1e6}
             if tr.get("mfma_busy_cycles") is not None and tr.get("insts_per_launch", {}).get("VALU") is not None:
                 n_simd = 1024.0
                 other_valu = tr["insts_per_launch"]["VALU"] - tr.get("mfma_insts", 0.0)
-                floor_parts["issue_us"] = (tr["mfma_busy_cycles"] + 4.0 * other_valu) / n_simd / LDS_CLOCK_HZ * 1e6
+                # cycles of the issue port per non-matrix vector instruction of a SIMD: MEASURED (tools/src/valu_rate.hip at the
+                # kernel's waves per SIMD and instruction mix, profiles/r05/valu_rate_microbench.txt), recorded with the entry
+                issue_cpi = float(tr.get("issue_cycles_per_valu_inst", ISSUE_CPI_DEFAULT))
+                floor_parts["issue_us"] = (tr["mfma_busy_cycles"] + issue_cpi * other_valu) / n_simd / LDS_CLOCK_HZ * 1e6
         floor_us = None if floor_parts is None else round(max(floor_parts.values()), 3)
+        # Which roofline bounds the kernel = the largest part of the floor (HBM bytes / flops / issue port). The contract's
+        # vocabulary is "hbm" | "mfma": the flops and the issue port are both the matrix / vector pipe (fp32 MFMA peak == fp32
+        # vector peak, MI355X_MICROARCH.md), `bound_detail` says which. Without a PMC pass for this kernel: flops against the
+        # I/O bytes (8 B per stream-sample) decide.
+        io_floor_us = 4 * (ic + oc) * samples_per_launch / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6
+        parts_for_bound = floor_parts or {"hbm_us": io_floor_us, "fp32_us": flops_per_launch / (FP32_PEAK_TFLOPS * 1e12) * 1e6}
+        bound_detail = max(parts_for_bound, key=parts_for_bound.get)[:-3]
+        achieved_tf_wall = flops_per_launch / wall_launch_s / 1e12
+        contract_frac = contract_gbs_wall / HBM_PEAK_GBS
+        hbm_contract = {"achieved": round(contract_gbs_wall, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(contract_frac, 4) if contract_frac <= 1.0 else None,
+                        "label": ("SURVEY 8(d-ii) contract bytes / wall time per step" if contract_frac <= 1.0 else
+                                  "n/a (rings in LDS): the contract counts every tap read as memory traffic; above the HBM peak"),
+                        "bytes_per_stream_sample": bytes_per_sample}
+        if bound_detail == "hbm":
+            head = {"bound": "hbm", "achieved": round(contract_gbs_wall, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(min(contract_frac, 1.0), 4)}
+        else:
+            head = {"bound": "mfma", "achieved": round(achieved_tf_wall, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved_tf_wall / FP32_PEAK_TFLOPS, 4)}
+        roofline = dict(head)
+        roofline.update({
+            "bound_detail": bound_detail,
+            "traffic": traffic_b,
+            "kernel": kname,
+            "floor_frac": None if floor_us is None else round(floor_us / (wall_launch_s * 1e6), 4),
+            "floor_parts_us": None if floor_parts is None else {k_: round(v_, 3) for k_, v_ in floor_parts.items()},
+            "floor_us": floor_us,
+            "issue_cycles_per_valu_inst": issue_cpi if floor_parts and "issue_us" in floor_parts else None,
+            "counter_hbm_frac": counter_frac,
+            "source": (tr.get("source") if tr else None),
+            "basis": "achieved = algorithmic work of one step (SURVEY 8d: 2 x MACs, or the contract bytes) / the WALL ms_per_step of this line; "
+                     "floor_frac = max(floor_parts_us) / wall time per step: measured HBM bytes at 6.3 TB/s, algorithmic flops at 157.3 TFLOP/s, "
+                     "(fp32 MFMA pipe cycles + issue_cycles_per_valu_inst x other vector instructions) per SIMD at 2.4 GHz — the issue "
+                     "part counts matrix and vector instructions only (LDS, scalar, waits are not in it: a lower bound); counters from "
+                     "the PMC passes in profiles/ (`source`)",
+            "traffic_note": (tr["note"] if tr else "no PMC pass committed for this exact kernel / model / launch shape"),
+            "note": f"algorithmic {flops_per_sample} FLOP and {bytes_per_sample} B ({hist} history + {4 * (ic + oc)} I/O) per stream-sample x "
+                    f"{samples_per_launch} stream-samples per launch; avg launch {avg_launch_s * 1e6:.2f} us "
+                    + ("= results visible to the host / steps (persistent block mode: one resident launch consumes one doorbell per "
+                       "step; HIP events on the caller's stream would only bracket the doorbells)"
+                       if getattr(engine, "persistent", False) else "from HIP events on the launch stream (median region)"),
+            "hbm_contract": hbm_contract,
+            "lds": lds,
+            "compute": {"achieved": round(achieved_tf_wall, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved_tf_wall / FP32_PEAK_TFLOPS, 4), "kernel_time_frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4)},
+        })
         out = {
             "metric": f"real-time audio streams (xRT) at 48 kHz, {model_name}",
             "value": round(xrt, 1),
@@ -847,40 +999,7 @@ def main():
             "region_us": {"enqueued": round(med["enqueue_s"] * 1e6, 1),
                           "results_visible_to_host": None if med["flushed_s"] is None else round(med["flushed_s"] * 1e6, 1),
                           "after_device_synchronize": round(med["wall_s"] * 1e6, 1)},
-            # The WaveNet path is bound by history traffic through HBM / Infinity Cache (the per-stream state cannot stay
-            # in LDS): e.g. a1_standard 8 TB/s / 3,848 B / 48 kHz = 43 k xRT, below its fp32 ceiling of 123 k xRT.
-            "roofline": {
-                "floor_frac": None if floor_us is None else round(floor_us / (wall_launch_s * 1e6), 4),
-                "floor_frac_basis": "floor_us / wall time per step: floor_us = max over `floor_parts_us` — measured HBM bytes at 6.3 TB/s, "
-                                    "algorithmic flops at 157.3 TFLOP/s, (fp32 MFMA pipe cycles + 4 x other vector instructions) per SIMD at "
-                                    "2.4 GHz (the matrix / vector issue port; the two never co-execute here; LDS, scalar and wait instructions are NOT counted, so "
-                                    "this part is a lower bound of the issue time: DESIGN 9) — from the PMC passes in profiles/",
-                "floor_parts_us": None if floor_parts is None else {k_: round(v_, 3) for k_, v_ in floor_parts.items()},
-                "bound": "hbm", "achieved": round(contract_gbs_wall, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(contract_gbs_wall / HBM_PEAK_GBS, 4),
-                "frac_basis": "UPPER BOUND, not traffic: SURVEY 8(d-ii)'s algorithmic (contract) bytes per step / the wall ms_per_step of "
-                              "this line — most tap reads are served from LDS-resident rings; `traffic` / `counter_frac` are the measured bytes"
-                              + ("; above 1: the contract counts every tap read of every layer as memory traffic, most of them "
-                                 "are served from LDS / L2 here (`traffic` / `counter_frac` are the measured bytes)"
-                                 if contract_gbs_wall / HBM_PEAK_GBS > 1.0 else ""),
-                "kernel_time_frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                "kernel": kname,
-                "traffic": traffic_b,
-                "counter_frac": counter_frac,
-                "floor_us": floor_us,
-                "floor_note": "floor_us = max(floor_parts_us): the physical lower bound of one step; counter_frac = PMC traffic / wall "
-                              "time per step / 8 TB/s",
-                "traffic_note": (tr["note"] if tr else "no PMC pass committed for this exact kernel / model / launch shape"),
-                "note": f"algorithmic {bytes_per_sample} B/stream-sample ({hist} history + {4 * (ic + oc)} I/O) x "
-                        f"{samples_per_launch} stream-samples per launch; avg launch {avg_launch_s * 1e6:.2f} us "
-                        + ("= region wall time / steps (persistent block mode: one resident launch consumes one doorbell per "
-                           "step; HIP events on the caller's stream would only bracket the doorbells)"
-                           if getattr(engine, "persistent", False) else "from HIP events on the launch stream (median region)"),
-                "lds": lds,
-                "compute": {"achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
-                            "note": f"{flops_per_sample} FLOP/stream-sample; fp32 MFMA peak == fp32 vector peak"},
-            },
+            "roofline": roofline,
             "gpu_ms_total": round(gpu_s_med * 1e3, 3),
             "latency_us": latency,
             "resident_launch": (None if other is None else {
@@ -912,11 +1031,17 @@ def main():
             out["host_io"] = {"error": f"{type(e).__name__}: {e}"}
         st = out["other_configs"].get("2_steady") or {}
         out["steady_state"] = {"value": st.get("value"), "ms_per_step": st.get("ms_per_step"), "steps_per_region": 500,
+                               "floor_frac": (st.get("roofline") or {}).get("floor_frac"),
+                               "compute_frac": ((st.get("roofline") or {}).get("compute") or {}).get("frac"),
                                "note": "the same kernel, streams and session mode in regions of 500 steps (other_configs['2_steady']); "
                                        "`value` above is the driver's 20-step region, a third of which is launch, completion, prologue "
                                        "and the first buffer's way through the pipeline"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        else:
+            full_path = write_full_record(out) if world == 1 or rank == 0 else None
+            print(json.dumps(compact_line(out, full_path)), flush=True)
     if engine is not None:
         engine.close()
     if scratch is not None:

@@ -53,12 +53,44 @@ def test_bench_distributed_branch_world2_gloo(config, streams):
     outs = [p.communicate(timeout=150) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]  # only rank 0 prints the JSON line
-    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    last = outs[0][0].strip().splitlines()[-1]
+    assert len(last.encode()) < 6000  # the driver parses the line out of an 8 KB tail of stdout (round 4's 25 KB line was cut)
+    line = json.loads(last)
+    assert json.loads(json.dumps(line)) == line
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["finite"] is True and line["max_abs_err_vs_oracle"] == 0.0
-    assert line["repetitions"]["n"] == 3 and len(line["repetitions"]["ms_per_step_all"]) == 3
+    assert line["repetitions"]["n"] == 3 and line["repetitions"]["ms_per_step_min"] <= line["repetitions"]["ms_per_step_max"]
+    assert line["roofline"]["bound"] in ("hbm", "mfma") and line["roofline"]["frac"] is not None
     assert line["value"] > 0 and line["config"]["streams_per_gpu"] == streams
     assert line["data"].startswith("dry-run")
+
+
+def test_bench_line_stays_under_the_drivers_tail():
+    """The ONE line bench.py prints: every committed full record of a default run (the driver's command, one GPU: headline +
+    other configurations + host_io + side runs — profiles/r0N/bench_default_driver_shape*.json) compacts to < 6 KB with the
+    contract's keys in it; the whole record goes to gpurun_out/bench_full.json instead."""
+    import glob
+    sys.path.insert(0, ROOT)
+    import bench
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*", "bench_default_driver_shape*.json")))
+    assert recs
+    for path in recs:
+        with open(path) as f:
+            full = json.load(f)
+        if "other_configs" not in full:  # (a compact line committed as such)
+            continue
+        line = bench.compact_line(full, "gpurun_out/bench_full.json")
+        text = json.dumps(line)
+        assert len(text.encode()) < bench.LINE_LIMIT, (path, len(text))
+        assert json.loads(text) == line
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, (path, k)
+        assert "workload" in line["config"] and set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+        assert set(line["other_configs"]) >= {"3", "4", "5"}
+    # and a record blown up well past anything this file produces still comes out under the limit (optional blocks are shed)
+    full["other_configs"] = {str(i): dict(full["other_configs"]["3"]) for i in range(400)}
+    assert len(json.dumps(bench.compact_line(full, None)).encode()) < bench.LINE_LIMIT
 
 
 @pytest.mark.gpu
