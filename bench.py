@@ -47,8 +47,10 @@ HBM_ACHIEVABLE_GBS = 6300.0
 LDS_PEAK_TBS = 150.0  # MI355X_MICROARCH.md, LDS: ~150 TB/s for ds_read_b64/b128 with every CU streaming at ~2.4 GHz
 LDS_CLOCK_HZ = 2.4e9
 # issue-port cycles per non-matrix vector instruction of a SIMD when an entry of profiles/traffic.json does not carry its own
-# figure: 3 waves per SIMD issue v_fma at 3.01 cycles per SIMD-instruction (profiles/r04/valu_rate_microbench.txt)
-ISSUE_CPI_DEFAULT = 3.0
+# figure (`issue_cycles_per_valu_inst`, measured at the kernel's own occupancy and mix by tools/src/valu_rate.hip): a wave64
+# v_fma_f32 is 2.28 cycles at four waves per SIMD, 3.7 - 4.1 next to fp32 matrix instructions, 8.6 for a lone wave
+# (profiles/r05/valu_rate_microbench.txt; round 4's three-wave rows timed wave 0 only and read low)
+ISSUE_CPI_DEFAULT = 4.0
 
 
 def wavenet_history_bytes_per_sample(cfg: dict) -> int:

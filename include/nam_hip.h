@@ -129,10 +129,14 @@ typedef struct nam_hip_load_options
    * IVersionSupportChecker objects (NAM/get_dsp.h:19-25,60, get_dsp.cpp:92-128), which can only WIDEN what the core
    * checker accepts — so the library's built-in gate (0.5.0 <= version, minor <= 0.7) is skipped. */
   int32_t version_checked_by_caller;
-  /* sizeof(nam_hip_load_options) as the CALLER compiled it (NAM_HIP_LOAD_OPTIONS_INIT sets it). The struct has grown once
-   * (16 bytes in library version 0.1: fast_tanh, n_luts, luts): the library reads a field only if struct_size says the caller's
-   * struct holds it — 0 (a caller built against the old header, or one that zero-fills) means "the first 16 bytes only", so
-   * garbage behind an old caller's struct can never switch the version gate off. */
+  /* sizeof(nam_hip_load_options) as the CALLER compiled it (NAM_HIP_LOAD_OPTIONS_INIT sets it). The library reads a field behind
+   * the first 16 bytes (fast_tanh, n_luts, luts) only if struct_size says the caller's struct holds it.
+   * ABI NOTE (library 0.2.0): this field took the slot of 0.1's `reserved` (that header was 24 bytes: fast_tanh, n_luts, luts,
+   * version_checked_by_caller, reserved = 0). A binary built against the 0.1 header therefore passes struct_size = 0 and its
+   * version_checked_by_caller is IGNORED — the safe direction: the built-in version gate stays on, a widened file is rejected
+   * with the reference's message rather than loaded unchecked. Such callers must be rebuilt against this header
+   * (nam_hip_version() reports "0.2.x"); 0 also covers callers that zero-fill, so garbage behind a short struct can never
+   * switch the gate off. */
   int32_t struct_size;
 } nam_hip_load_options;
 #define NAM_HIP_LOAD_OPTIONS_INIT {0, 0, 0, 0, (int32_t)sizeof(nam_hip_load_options)}

@@ -97,14 +97,15 @@ struct A1Args
   unsigned long long* p_ring;
   int p_ring_mask;
   unsigned* p_cons; // device memory: commands consumed per workgroup (where its next launch resumes)
-  unsigned* p_prog; // host-mapped: progress (every 16 commands), completion count | exited bit
+  unsigned* p_prog; // host-mapped: progress, stored every 16 commands — the host's ring bookkeeping (back-pressure), NEVER a completion signal
+                    // (per-buffer completion: p_cmd_done below; the launch's own: p_done = count | exited bit)
   unsigned* p_done;
   long long p_seq0; // >= 0: every workgroup has consumed exactly this many commands (p_cons is not read) ...
   unsigned long long p_cmd0; // ... and this is the next command (the ring is not read for it)
   int p_grace; // ticks (100 MHz) a fresh launch looks for its first doorbell before it leaves again
   int p_out_host; // the session's output window is HOST memory (nam_a1_p4_kernel: kOutHost — plain result stores, ring
                   // appends written through, one system-scope release fence before the completion word). 2 (nam_a1_q_kernel,
-                  // nam_kq_kernel): ticketed host buffers — results written through and p_prog published after EVERY command,
+                  // nam_kq_kernel): ticketed host buffers — results written through and p_cmd_done stored after EVERY command,
                   // behind the results: the host takes a buffer's output while the launch runs on (nam_hip_batch_wait_f32)
   int p_linger; // ticks (100 MHz) the launch looks for the NEXT command when it finds the ring empty, before it leaves (nam_a1_q_kernel,
                 // nam_kq_kernel; 0 = 1 us, the other kernels' constant): a ticket session's host hands a buffer in every 5 - 15 us

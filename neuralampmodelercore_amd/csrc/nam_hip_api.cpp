@@ -181,7 +181,7 @@ struct PersistSession
   long long *h_why = nullptr, *d_why = nullptr; // (NAM_HIP_SESSION_STATS) per workgroup: reason << 56 | grace loop << 48 | all-through count << 24 | own count
   unsigned long long n_waits = 0, n_polls = 0; // ticket waits, looks at the buffer's completion word
   unsigned epoch = 0; // counts session starts (a ticket of an earlier session is complete: sessions end flushed)
-  bool prog_completes = false; // the running launch publishes its progress word behind every command's results (A1Args::p_out_host == 2)
+  bool cmd_done_published = false; // the running launch stores p_cmd_done behind every command's results (A1Args::p_out_host == 2); p_prog stays ring bookkeeping every 16 commands
 };
 
 // One buffer in flight between nam_hip_batch_submit_f32 and nam_hip_batch_wait_f32
@@ -225,7 +225,7 @@ struct nam_hip_batch
   bool pipe_map_failed = false;
   PipeSlot pipe[NAM_HIP_PIPE_SLOTS];
   long long pipe_next = 0; // the next ticket
-  bool pipe_session = false; // the session serves ticketed buffers: its launches publish every command (PersistSession::prog_completes)
+  bool pipe_session = false; // the session serves ticketed buffers: its launches publish every command (PersistSession::cmd_done_published)
   float *pipe_h_in = nullptr, *pipe_h_out = nullptr, *pipe_d_in = nullptr, *pipe_d_out = nullptr; // staging of the copying form ([slot][row][max_frames])
   std::vector<float> pipe_cvt; // the _f64 forms of submit / wait: one buffer of float32 on the way in / out
   int kernel = NAM_HIP_KERNEL_AUTO;
@@ -756,8 +756,8 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_prog = b->ps.d_words;
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
-          a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
-          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
+          a.p_out_host = b->ps.out_is_host ? (b->ps.cmd_done_published ? 2 : 1) : 0;
+          a.p_linger = (b->ps.cmd_done_published && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -799,8 +799,8 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_prog = b->ps.d_words;
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
-          a.p_out_host = b->ps.out_is_host ? (b->ps.prog_completes ? 2 : 1) : 0;
-          a.p_linger = (b->ps.prog_completes && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
+          a.p_out_host = b->ps.out_is_host ? (b->ps.cmd_done_published ? 2 : 1) : 0;
+          a.p_linger = (b->ps.cmd_done_published && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -1081,16 +1081,17 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   for (int w = 0; w < ps.n_wg; w++)
     __atomic_and_fetch(&ps.h_words[ps.done_off + w], 0x7fffffffu, __ATOMIC_RELAXED);
   ps.outstanding = true;
-  // ticketed host buffers: nam_a1_q_kernel / nam_kq_kernel publish their progress word behind every command's results
-  // (the other kernels' progress words are bookkeeping only: their tickets complete when the launch has left)
+  // ticketed host buffers: nam_a1_q_kernel / nam_kq_kernel store the per-buffer completion word (p_cmd_done) behind every
+  // command's results (their p_prog, like every kernel's, is ring bookkeeping every 16 commands — never a completion signal;
+  // the other kernels' tickets complete when the launch has left)
   {
     const Plan& p = *g.plan;
-    ps.prog_completes = b->pipe_session && ps.out_is_host && !b->no_pipe
+    ps.cmd_done_published = b->pipe_session && ps.out_is_host && !b->no_pipe
                         && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || (ps.kind == PERSIST_KP && kq_runs(b, p)));
     // ... and linger: a workgroup that finds itself up to date when a launch starts (another one's backlog was the reason for
     // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
     // linger and leave before the next launch could pick it up again
-    if (ps.prog_completes && ps.host_store_ok && ps.n_wg <= b->n_cus)
+    if (ps.cmd_done_published && ps.host_store_ok && ps.n_wg <= b->n_cus)
     {
       ps.grace = std::max(ps.grace, b->ticket_linger);
       // "a workgroup of this launch has left" (il_common.h: session_leaving; p_cmd_count[mask + 2] = [kPRing + 1]): none yet
@@ -1157,17 +1158,19 @@ int persist_flush(nam_hip_batch* b, hipStream_t caller)
 }
 
 // `whole`: every submitted command (target == seq) and the launch gone. Otherwise: the first `target` commands of the
-// session rendered and visible — the launch may run on (its progress words count then, if it publishes them per command).
+// session rendered and visible — the launch may run on (the per-buffer completion word p_cmd_done counts then, if the launch publishes it).
 int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool whole)
 {
   PersistSession& ps = b->ps;
   if (!ps.active)
     return NAM_HIP_OK;
-  if (whole && ps.outstanding && ps.prog_completes && ps.host_store_ok && ps.n_wg <= b->n_cus)
+  bool told_leave = false;
+  if (whole && ps.outstanding && ps.cmd_done_published && ps.host_store_ok && ps.n_wg <= b->n_cus)
   {
     // a lingering launch: tell it that nothing follows command `seq` (kPRingTail)
     __atomic_store_n(&ps.d_ring[kPRing], (unsigned long long)ps.seq, __ATOMIC_RELEASE);
     push_out_host_stores();
+    told_leave = true;
   }
   PersistWatch watch;
   bool ended = false; // the stream reported the launch complete: its words are final
@@ -1178,7 +1181,7 @@ int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool who
   int relaunches = 0;
   for (;;)
   {
-    if (!whole && ps.prog_completes)
+    if (!whole && ps.cmd_done_published)
     {
       // ONE word: stored by the last workgroup through the last command of the buffer, behind everybody's results
       // (A1Args::p_cmd_done). A short spin on it between looks at the launch itself (the 2 n_wg words below, which the
@@ -1222,6 +1225,13 @@ int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool who
     {
       ps.flushed = ps.seq;
       ps.flushed_valid = true;
+      if (told_leave)
+      {
+        // the session goes on after a flush: the "leave" word must not stay at this count, or a later launch whose workgroups
+        // stand exactly there would leave at once instead of lingering (il_common.h: session_wait_command, `leave == tag - 1`)
+        __atomic_store_n(&ps.d_ring[kPRing], ~0ull, __ATOMIC_RELEASE);
+        push_out_host_stores();
+      }
       return NAM_HIP_OK;
     }
     // no launch running, buffers outstanding: either the commands have not all been delivered yet or a workgroup
@@ -1733,14 +1743,6 @@ inline void push_out_host_stores()
 #else
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
 #endif
-}
-
-bool pipe_busy(const nam_hip_batch* b)
-{
-  for (const PipeSlot& sl : b->pipe)
-    if (sl.in_flight)
-      return true;
-  return false;
 }
 
 // Returns 0 when the buffer went through the session, 1 when the mode does not apply (not enabled / not eligible /

@@ -3,7 +3,7 @@ replay / restart behaviour of its fused path (tools/test/test_a2_fast.cpp:272-36
 implementations, block after block, and again after a Reset); here: a persistent session of >= 200 buffers of real signal —
 a flush in the middle, a pause long enough for the resident launch to leave and be started again, more workgroups than the
 chip holds at once ("turns") — against ONE ordinary launch of the un-pipelined kernel of the family on the same audio, every
-stream and every frame, and stream 0 against the CPU oracle. (Round 3's split-wave bug of nam_kq_kernel only showed in
+stream and every frame, and ten streams (first, last, middle, seeded picks) against the CPU oracle. (Round 3's split-wave bug of nam_kq_kernel only showed in
 exactly this kind of run: tools/persist_soak.py, now a test.)"""
 import os
 import time
@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "a1_standard_q": ("wavenet_a1_standard", 256, 240, {}, "nam_a1_q_kernel"),
     "a1_standard_q_turns": ("wavenet_a1_standard", 500, 200, {}, "nam_a1_q_kernel"),
+    # libm tanh: the ACT_TANH instantiations (session and plain launch) of the headline kernel, tools/render.cpp's setting
+    "a1_standard_q_libm_tanh": ("wavenet_a1_standard", 256, 200, {}, "nam_a1_q_kernel", False),
     "a1_standard_p4": ("wavenet_a1_standard", 256, 200, {"NAM_HIP_A1Q": "0"}, "nam_a1_p4_kernel"),
     "a1_feather_p4_turns": ("synth_a1_feather", 500, 200, {}, "nam_a1_p4_kernel"),
     "a2_full_kq": ("A2", 256, 240, {}, "nam_kq_kernel"),
@@ -33,10 +35,11 @@ CASES = {
 def test_long_session_against_one_launch(nam_lib, oracle, monkeypatch, case):
     torch = pytest.importorskip("torch")
     nam = nam_lib
-    name, n_streams, nb, env, kname = CASES[case]
+    name, n_streams, nb, env, kname = CASES[case][:5]
+    fast_tanh = CASES[case][5] if len(CASES[case]) > 5 else True
     block = 64
     x = stream_bank(n_streams, nb * block, seed=4100 + len(case))
-    model = nam.get_dsp(model_path(name), fast_tanh=True)
+    model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
     xd = torch.from_numpy(x[:, None, :]).cuda()
     # the reference rendering: one launch of the un-pipelined kernel (a fresh batch: its own state)
     monkeypatch.setenv("NAM_HIP_NO_PIPE", "1")
@@ -73,8 +76,14 @@ def test_long_session_against_one_launch(nam_lib, oracle, monkeypatch, case):
         raise AssertionError(f"{case}: {len(ids)} streams differ from the one-launch rendering; first bad frames {first} "
                              f"(buffers {[f // block for f in first]}) of streams {ids[:8].tolist()}; max {float(d.max()):.3e}")
     assert bool(torch.isfinite(yd).all())
-    ref = oracle.get_dsp(model_path(name), fast_tanh=True)
-    ref.Reset(48000.0, block)
-    r = ref.process_stream(x[0], block)[0]
-    y0 = yd[0, 0].cpu().numpy()
-    assert float(np.max(np.abs(r - y0))) <= 5e-5 * max(1.0, float(np.max(np.abs(r))))
+    # against the CPU oracle: the first and last stream, the middle ones and a few picked by the case's seed — a stream map wrong
+    # in BOTH kernels (they share the host side) would pass the comparison above
+    rng = np.random.default_rng(len(case))
+    picks = sorted({0, 1, n_streams // 2, n_streams - 1, *rng.integers(0, n_streams, size=6).tolist()})
+    tol = 5e-5 if fast_tanh else 1e-4
+    for s in picks:
+        ref = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)
+        ref.Reset(48000.0, block)
+        r = ref.process_stream(x[s], block)[0]
+        ys = yd[s, 0].cpu().numpy()
+        assert float(np.max(np.abs(r - ys))) <= tol * max(1.0, float(np.max(np.abs(r)))), (case, s)

@@ -123,8 +123,13 @@ __global__ __launch_bounds__(1024) void k(float* p, long long* cyc, int iters)
   for (int i = 0; i < 8; i++)
     s += a[i] + q[i][0] + q[i][1];
   p[threadIdx.x & 63] = s + acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
-  if (threadIdx.x == 0)
-    cyc[0] = t1 - t0;
+  // every wave's own start and end: the SIMD's time is the span over ITS waves (the arbiter favours the oldest wave: wave 0's
+  // own time undercounts — round 4's three-wave rows did, e.g. 21 cycles per fp32 16x16x4 MFMA, which takes 32)
+  if ((threadIdx.x & 63) == 0)
+  {
+    cyc[2 * (threadIdx.x >> 6)] = t0;
+    cyc[2 * (threadIdx.x >> 6) + 1] = t1;
+  }
 }
 template <int MODE>
 void run(const char* name, float* d, long long* dc, int waves_per_simd, double per_iter)
@@ -132,8 +137,16 @@ void run(const char* name, float* d, long long* dc, int waves_per_simd, double p
   const int iters = 512;
   for (int rep = 0; rep < 2; rep++)
     hipLaunchKernelGGL((k<MODE>), dim3(1), dim3(256 * waves_per_simd), 0, 0, d, dc, iters);
-  long long c;
-  hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+  long long cs[32];
+  hipMemcpy(cs, dc, sizeof(cs), hipMemcpyDeviceToHost);
+  // SIMD 0 holds waves 0, 4, 8, 12 (tools/src/simd_map.hip): its span
+  long long lo = cs[0], hi = cs[1];
+  for (int w = 0; w < 4 * waves_per_simd; w += 4)
+  {
+    lo = cs[2 * w] < lo ? cs[2 * w] : lo;
+    hi = cs[2 * w + 1] > hi ? cs[2 * w + 1] : hi;
+  }
+  const long long c = hi - lo;
   printf("%-46s %d wave(s)/SIMD: %7.2f cycles per iteration per SIMD (%5.2f per instruction of one wave, %5.2f per SIMD-instruction)\n", name,
          waves_per_simd, (double)c / iters, (double)c / iters / per_iter, (double)c / iters / per_iter / waves_per_simd);
 }
@@ -142,7 +155,7 @@ int main()
   float* d;
   long long* dc;
   hipMalloc(&d, 4096);
-  hipMalloc(&dc, 8);
+  hipMalloc(&dc, 32 * 8);
   hipMemset(d, 0, 4096);
   for (int w = 1; w <= 4; w++)
   {
