@@ -292,9 +292,13 @@ def run_other_configs(args):
     # "2_steady": the headline configuration itself in this protocol (regions of 500 steps: what a session that lives longer
     # than the driver's 20-step regions sustains — a region pays launch, prologue and the first buffer's way through the
     # pipeline once)
-    for c in ("2_steady", 3, 4, 5, "A2"):
-        sel = ["--model", "A2", "--streams", "256"] if c == "A2" else ["--config", "2" if c == "2_steady" else str(c)]
-        cmd = [sys.executable, os.path.abspath(__file__)] + sel + ["--gpus", "1", "--steps", "500", "--warmup", "50",
+    # "3_long": config 3 with a long block ("block 64, and a long-block variant, e.g. 4,096, since offline re-amping allows
+    # it"): ONE launch walks 4,096 frames of every stream (`--launch resident --steps 64`)
+    for c in ("2_steady", 3, "3_long", 4, 5, "A2"):
+        sel = (["--model", "A2", "--streams", "256"] if c == "A2" else ["--config", "3", "--launch", "resident"] if c == "3_long"
+               else ["--config", "2" if c == "2_steady" else str(c)])
+        steps, warm = ("64", "64") if c == "3_long" else ("500", "50")
+        cmd = [sys.executable, os.path.abspath(__file__)] + sel + ["--gpus", "1", "--steps", steps, "--warmup", warm,
                "--brief", "--full-line", "--persistent", str(args.persistent), "--fast-tanh", str(args.fast_tanh)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
@@ -308,7 +312,8 @@ def run_other_configs(args):
             j = json.loads(line[-1])
             r = {k: j.get(k) for k in keep}
             r["workload"] = ("A2.nam (A2-Full), 256 streams, buffer 64" if c == "A2" else
-                             CONFIGS[2]["name"] + ", regions of 500 steps" if c == "2_steady" else CONFIGS[c]["name"])
+                             CONFIGS[2]["name"] + ", regions of 500 steps" if c == "2_steady" else
+                             CONFIGS[3]["name"] + ", one launch per 4,096-frame block" if c == "3_long" else CONFIGS[c]["name"])
             r["run_s"] = round(time.perf_counter() - t0, 1)
             res[str(c)] = r
         except Exception as e:  # noqa: BLE001
@@ -487,10 +492,10 @@ def _brief_config(r):
     if not isinstance(r, dict) or "value" not in r:
         return {"error": str((r or {}).get("error", "no line"))[:120]}
     rf = r.get("roofline") or {}
-    return {"value": r["value"], "ms_per_step": r.get("ms_per_step"), "kernel": (r.get("config") or {}).get("kernel"),
+    return {"value": r["value"], "ms_per_step": r.get("ms_per_step"), "kernel": (r.get("config") or {}).get("kernel") or r.get("kernel"),
             "bound": rf.get("bound"), "frac": rf.get("frac"), "floor_frac": rf.get("floor_frac"),
             "max_abs_err_vs_oracle": r.get("max_abs_err_vs_oracle"),
-            "cpu_baseline": (r.get("cpu_baseline") or {}).get("value")}
+            "cpu_baseline": (r["cpu_baseline"].get("value") if isinstance(r.get("cpu_baseline"), dict) else r.get("cpu_baseline"))}
 
 
 def compact_line(out: dict, full_path) -> dict:

@@ -58,10 +58,11 @@ extern "C" {
                                     sizes (A2) -> K-tap kernel (4 waves per stream). Narrower submodels of a container
                                     that neither can run use NAM_HIP_KERNEL_A1 */
 
-#define NAM_HIP_KERNEL_A1_IL 4 /* interleaved-frame fp32-MFMA kernel (kernel size 3): compute wave w owns frames 4j + w, so
-                                  dilations 4..32 are DPP row shifts inside the wave and dilations >= 64 are the lane's own
-                                  ring rows — 4 workgroup barriers per block for wavenet_a1_standard instead of 20; one
-                                  loader wave stages the weights in LDS. Falls back to NAM_HIP_KERNEL_A1_MFMA */
+#define NAM_HIP_KERNEL_A1_IL 4 /* interleaved-frame fp32-MFMA kernels of the official WaveNet sizes (two arrays of ten layers,
+                                  kernel size 3, dilations 1..512; 16/8, 12/8, 8/4 channels): compute wave w owns frames 4j + w,
+                                  so dilations 4..32 are DPP row shifts inside the wave and dilations >= 64 the lane's own ring
+                                  rows; launches of more than one buffer run the pipelined forms. Any other topology falls
+                                  back to NAM_HIP_KERNEL_A1_MFMA */
 #define NAM_HIP_KERNEL_WN_REG 5 /* register-resident WaveNet kernel for narrow, feature-rich models (FiLMs, gating, grouped
                                    1x1s, head1x1, a nested condition_dsp — example_models/wavenet_a2_max.nam): one wavefront
                                    per stream, lane = frame, a layer = one unrolled function per instantiated shape; every
@@ -88,8 +89,8 @@ typedef struct nam_hip_model_info
   double output_level; /* DSP::GetOutputLevel dsp.h:133 */
   int64_t num_weights;
   int32_t fast_tanh; /* load-time switch replacing the global Activation::enable_fast_tanh (activations.cpp:168) */
-  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: one of the A1 MFMA kernels can; bit 2: the
-                            interleaved-frame MFMA kernel can; bit 3: in its compile-time-topology form (official sizes);
+  int32_t has_a1_kernel; /* bit 0: the A1 VALU kernel can run this model; bit 1: one of the A1 MFMA kernels can; bits 2 and 3
+                            (always equal since 0.2.1): the interleaved-frame MFMA kernels can — the official WaveNet sizes, job tables compiled in;
                             bit 4: nam_wn_reg_kernel can; bit 5: the model asked for nam_wn_reg_kernel compiled for its own layer
                             shapes and that compile was not available here (no compiler / sources / private cache directory:
                             a line on stderr and NAM_HIP_FIELD_DESCRIPTION say why) — it runs, on a slower form */
@@ -227,7 +228,7 @@ NAM_HIP_API int nam_hip_batch_process_device(nam_hip_batch* batch, const float* 
 NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* const* in, float* const* out,
                                          const int64_t* n_frames);
 
-/* Persistent block mode (opt-in; nam_a1_p4_kernel, nam_kq_kernel / nam_kp_kernel, nam_wn_reg_kernel — mixed slimmable widths included — and
+/* Persistent block mode (opt-in; nam_a1_q_kernel / nam_a1_p4_kernel, nam_kq_kernel, nam_wn_reg_kernel — mixed slimmable widths included — and
  * the small LSTM kernels): instead of one kernel launch per nam_hip_batch_process_device call, a SESSION launch consumes
  * every call of a multiple of 64 frames (up to 2,048; n_frames / 64 commands) — a command is a 64-bit word in a
  * device-memory ring, stored by the host itself when the call's stream is idle, else by hipStreamWriteValue64 on that
@@ -241,7 +242,7 @@ NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* cons
  * transparently. The blocking *_f32 / *_f64 entry points stay inside the session (host-mapped staging).
  * Outputs are NOT ordered on the caller's stream: call nam_hip_batch_flush (or nam_hip_batch_synchronize, or use the
  * blocking *_f32 / *_f64 entry points, which do it) before consuming them.
- * Eligible: one width group on nam_a1_p4_kernel / nam_kq_kernel (nam_kp_kernel) up to 8 streams per CU (beyond one per CU the workgroups
+ * Eligible: one width group on nam_a1_q_kernel / nam_a1_p4_kernel / nam_kq_kernel up to 8 streams per CU (beyond one per CU the workgroups
  * take turns on the chip); every group on nam_wn_reg_kernel up to 8 x min(4, 160 KB / LDS image) streams per CU (in turns too); small LSTMs.
  * Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual). */
 NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);

@@ -1,5 +1,6 @@
-// il_common.h — helpers shared by the interleaved-frame kernels (kernel_a1_il.hip: descriptor-driven,
-// kernel_a1_p2.hip: compile-time topology).
+// il_common.h — helpers shared by the interleaved-frame kernels (kernel_a1_p2.hip and the pipelines built on its lane layout and
+// session protocol: kernel_a1_p4.hip, kernel_a1_q.hip, kernel_kq.hip). The descriptor-driven form of the mapping,
+// nam_a1_il_kernel, was retired in round 5: topologies outside the compile-time tables run nam_a1_mfma_kernel.
 #pragma once
 #include "device_common.h"
 

@@ -6,8 +6,8 @@ namespace namhip
 {
 
 // ================================================================================================
-// nam_a1_p2_kernel<C0, C1> — nam_a1_il_kernel (kernel_a1_il.hip: frames t = 4 j + w per compute wave, DPP / ring /
-// exchange jobs, loader wave, request slots; read its header first) for ONE topology: two arrays of ten layers, kernel
+// nam_a1_p2_kernel<C0, C1> — the interleaved-frame mapping (plan.h, "Interleaved-frame MFMA kernel": frames t = 4 j + w per
+// compute wave, DPP / ring / exchange jobs, request slots) for ONE topology: two arrays of ten layers, kernel
 // size 3, dilations 1 ... 512 — every official WaveNet size (standard 16 / 8 channels, lite 12 / 6 -> 8, feather
 // 8 / 4). The job table is plan.h's constexpr p2::desc / p2::fetch evaluated at compile time (plan.cpp only selects
 // this kernel when those functions reproduce the model's run-time tables bit for bit), so a block is twenty
@@ -485,7 +485,7 @@ hipError_t launch_p2_inst(const A1Args& a, int n_blocks, hipStream_t stream)
   const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>), p2::kLdsBytes);
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(256), p2::kLdsBytes, stream, a.blob, a);
+  nam_launch((nam_a1_p2_kernel<C0, C1, ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(256), p2::kLdsBytes, stream, a.blob, a);
   return hipGetLastError();
 }
 template <int C0, int C1>

@@ -725,7 +725,7 @@ hipError_t launch_p4_inst(const A1Args& a, int n_blocks, hipStream_t stream)
   const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_p4_kernel<C0, C1, ACT_T, WT, PERSIST, kP4Stages>), lds_bytes);
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((nam_a1_p4_kernel<C0, C1, ACT_T, WT, PERSIST, kP4Stages>), dim3(n_blocks), dim3(kP4Stages * 256), lds_bytes, stream,
+  nam_launch((nam_a1_p4_kernel<C0, C1, ACT_T, WT, PERSIST, kP4Stages>), dim3(n_blocks), dim3(kP4Stages * 256), lds_bytes, stream,
                      a.blob, a);
   return hipGetLastError();
 }

@@ -1028,7 +1028,7 @@ hipError_t launch_q_inst(const A1Args& a, int n_blocks, hipStream_t stream)
   const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_q_kernel<ACT_T, WT, PERSIST>), aq::kLdsBytes);
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((nam_a1_q_kernel<ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(aq::kNst * 64), aq::kLdsBytes, stream, a.blob, a);
+  nam_launch((nam_a1_q_kernel<ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(aq::kNst * 64), aq::kLdsBytes, stream, a.blob, a);
   return hipGetLastError();
 }
 template <int ACT_T>

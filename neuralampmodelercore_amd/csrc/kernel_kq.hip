@@ -8,18 +8,21 @@ namespace namhip
 {
 
 // ================================================================================================
-// nam_kp_kernel (kernel_kp.hip; read its header first) spends half of its matrix cycles on padding — at 8 channels rows
-// 8 .. 15 of every 16 x 16 x 4 tile are zero — and, with a wave owning 16 frames, four waves' worth of instructions per
-// layer plus a stage barrier. An fp32 MFMA and a vector instruction never execute at the same time on this chip
-// (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so both halves of that cost add up. This kernel keeps the pipeline, the state (rings,
-// write positions: it alternates freely with nam_kt_mfma_kernel / nam_kp_kernel on one stream) and the session protocol,
-// and changes the shape of the work:
+// nam_kt_mfma_kernel (kernel_kt_mfma.hip) runs A2-Full — 8 channels, 23 layers of 6 or 15 taps at dilations up to 239, a 16-tap
+// head rechannel: the shape of the reference's own fused path, NAM/wavenet/a2_fast.cpp — with one wavefront per SIMD from a
+// run-time chunk table: ~340 instructions around every 12 matrix instructions and every latency exposed (35 us per 64-frame
+// buffer at 256 streams). At 8 channels rows 8 .. 15 of every 16 x 16 x 4 tile are zero, and an fp32 MFMA and a vector
+// instruction never execute at the same time on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0): both halves of that cost add up.
+// (Round 3's first answer, a pipeline of three four-wave sets on the same tiles — nam_kp_kernel, 13.1 us per buffer — was
+// retired in round 5: this kernel took over its activations.) This kernel is compiled for the topology (kp_table.h; plan.cpp:
+// build_a1_kp checks a model against it), keeps the K-tap kernel's state (rings, write positions: the two alternate freely on
+// one stream) and the session protocol of the A1 pipelines, and changes the shape of the work:
 //   * lane t of a wave = frame t of the buffer; the lane holds the layer's 8 input channels (x), the head accumulator and
 //     the sums in registers. v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4 x 4 blocks: block = four frames,
 //     A = W[4 h + lane % 4][c] (the same four values in every block), B = the lane's own x[c], D[e] = output channel
 //     4 h + e of the lane's frame. A tap is 16 instructions (2 halves x 8 input channels, ~8.6 cycles each), a layer of
-//     six taps + 1x1 is 112 against nam_kp_kernel's 4 waves x 14 x 32 cycles: half the matrix cycles, a quarter of the
-//     other instructions;
+//     six taps + 1x1 is 112 against 4 waves x 14 x 32 cycles of the padded 16 x 16 x 4 form: half the matrix cycles, a quarter
+//     of the other instructions;
 //   * NST = 12 stages of ONE wave each (kq::first_job: jobs cut so that three stages per SIMD balance, kq::stage_of_wave),
 //     stage s on buffer n - s, one-slot LDS queues between them (x, head accumulator, input sample, token);
 //   * a tap's operand: lookback 0 = the registers; 0 < L <= T = the layer's LDS WINDOW [tail: the last T rows in front
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(kq::kNst * 64) void nam_kq_kernel(const float* __re
     wp[U] = wpn;
   };
 
-  // ---- the stage loops (kernel_kp.hip: run; one wave per stage: its decisions are its own) ----
+  // ---- the stage loops (one wave per stage: its decisions are its own) ----
   auto run = [&](auto s_tag) {
     constexpr int SS = decltype(s_tag)::value;
     constexpr int J0 = kq::first_job(SS), NJS = kq::first_job(SS + 1) - J0;
@@ -815,7 +818,7 @@ hipError_t launch_kq_inst(const A1Args& a, int n_blocks, hipStream_t stream)
   const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_kq_kernel<ACT_T, WT, PERSIST>), kq::kLdsBytes);
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((nam_kq_kernel<ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(kq::kNst * 64), kq::kLdsBytes, stream, a.blob, a);
+  nam_launch((nam_kq_kernel<ACT_T, WT, PERSIST>), dim3(n_blocks), dim3(kq::kNst * 64), kq::kLdsBytes, stream, a.blob, a);
   return hipGetLastError();
 }
 template <int ACT_T>
@@ -829,16 +832,27 @@ hipError_t launch_kq_act(const A1Args& a, int n_blocks, hipStream_t stream)
 } // namespace
 
 // a.tiles_off: blob offset (floats) of the kernel's weight block (plan.cpp: build_a1_kp — tiles | constants | rechannel column).
-// Only the A2 activation is instantiated (LeakyReLU with a slope <= 1, as max(v, slope v)): the run-time-dispatch form
-// does not fit 168 registers; the caller keeps nam_kp_kernel for anything else.
+// Instantiated: the A2 activation (LeakyReLU with a slope <= 1, as max(v, slope v) — ReLU is its slope 0), Tanh and Fasttanh
+// (NAM/activations.h:59-98). The run-time-dispatch form does not fit 168 registers: any other activation on this topology runs
+// nam_kt_mfma_kernel, one launch per buffer (the reference's own fused path takes LeakyReLU(0.01) only: a2_fast.cpp:617).
 bool kq_takes(int act, float act_p0)
 {
-  return act == ACT_LEAKYRELU && act_p0 <= 1.0f;
+  return (act == ACT_LEAKYRELU && act_p0 <= 1.0f) || act == ACT_RELU || act == ACT_TANH || act == ACT_FASTTANH;
 }
 hipError_t launch_kq(const A1Args& a, int n_blocks, int act, hipStream_t stream)
 {
   if (!kq_takes(act, a.act_p0))
     return hipErrorInvalidValue;
+  if (act == ACT_TANH)
+    return launch_kq_act<ACT_TANH>(a, n_blocks, stream);
+  if (act == ACT_FASTTANH)
+    return launch_kq_act<ACT_FASTTANH>(a, n_blocks, stream);
+  if (act == ACT_RELU)
+  {
+    A1Args r = a;
+    r.act_p0 = 0.0f; // max(v, 0 v): -0 where ReLU gives +0 — equal in every sum and product behind it
+    return launch_kq_act<kq::kActLeakyMax>(r, n_blocks, stream);
+  }
   return launch_kq_act<kq::kActLeakyMax>(a, n_blocks, stream);
 }
 

@@ -1104,9 +1104,9 @@ hipError_t launch_lstm_row(const LSTMArgs& a, hipStream_t stream)
   const int lds_bytes = (4 * a.hidden * 65 + 128) * (int)sizeof(float); // h history of the block + the dump slots
 #define NAM_LSTM_ROW_H(NL, NI, NH) \
   if (a.fast) \
-    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, NH, true>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a); \
+    nam_launch((nam_lstm_row_kernel<NL, NI, NH, true>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a); \
   else \
-    hipLaunchKernelGGL((nam_lstm_row_kernel<NL, NI, NH, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a)
+    nam_launch((nam_lstm_row_kernel<NL, NI, NH, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, a.blob, a)
 #define NAM_LSTM_ROW(NL, NI) \
   switch (a.hidden) \
   { \
@@ -1141,9 +1141,9 @@ hipError_t launch_lstm_wide(const LSTMArgs& a, hipStream_t stream)
   const int lds_bytes = (kBlock * (nh + 4) + a.out_ch * nh + a.out_ch) * (int)sizeof(float);
 #define NAM_LSTM_WIDE_H(NL, NI, NH) \
   if (a.fast) \
-    hipLaunchKernelGGL((nam_lstm_wide_kernel<NL, NI, NH, true>), dim3(a.n_streams), dim3(64), lds_bytes, stream, a.blob, a); \
+    nam_launch((nam_lstm_wide_kernel<NL, NI, NH, true>), dim3(a.n_streams), dim3(64), lds_bytes, stream, a.blob, a); \
   else \
-    hipLaunchKernelGGL((nam_lstm_wide_kernel<NL, NI, NH, false>), dim3(a.n_streams), dim3(64), lds_bytes, stream, a.blob, a)
+    nam_launch((nam_lstm_wide_kernel<NL, NI, NH, false>), dim3(a.n_streams), dim3(64), lds_bytes, stream, a.blob, a)
 #define NAM_LSTM_WIDE(NL, NI) \
   switch (nh) \
   { \

@@ -1297,6 +1297,9 @@ hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int ld
   WrArgs args = a;
   size_t size = sizeof(args);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  if (tl_session_stop_event) // (kernels.h: nam_launch; the Ext form takes the grid in work-items)
+    return hipExtModuleLaunchKernel(reinterpret_cast<hipFunction_t>(fn), (unsigned)n_workgroups * 64u * (unsigned)stages, 1, 1, 64u * (unsigned)stages, 1, 1,
+                                    (size_t)lds_bytes, stream, nullptr, config, nullptr, tl_session_stop_event, 0);
   return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(fn), (unsigned)n_workgroups, 1, 1, 64u * (unsigned)stages, 1, 1,
                                (unsigned)lds_bytes, stream, nullptr, config);
 }
@@ -1316,7 +1319,7 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
         if (e != hipSuccess)
           return e;
       }
-      hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(64 * stages), lds_bytes, stream, a);
+      nam_launch(kernel, dim3(n_workgroups), dim3(64 * stages), (unsigned)lds_bytes, stream, a);
       return hipGetLastError();
     };
     const int set = ((layers && runs) || rt_layers) ? 2 : runs ? 1 : 0;
@@ -1334,7 +1337,7 @@ hipError_t launch_wn_reg(const WrArgs& a, int n_workgroups, int lds_bytes, bool 
       if (e != hipSuccess)
         return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(n_workgroups), dim3(64), lds_bytes, stream, a);
+    nam_launch(kernel, dim3(n_workgroups), dim3(64), (unsigned)lds_bytes, stream, a);
     return hipGetLastError();
   };
   if ((layers && runs) || rt_layers)

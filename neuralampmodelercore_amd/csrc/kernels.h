@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "plan.h"
 
@@ -30,6 +31,22 @@ struct DynamicLdsLimit
     return e;
   }
 };
+
+// A session's resident launch carries its own completion signal: persist_launch (nam_hip_api.cpp) sets this thread's stop event
+// around the launch call, and the launch sites of the session-capable kernels go through nam_launch — hipExtLaunchKernelGGL puts
+// the event's signal on the dispatch packet itself, so the host's wait for "the launch has retired" (nam_hip_batch_flush,
+// synchronize, the end of a session) is a wait on that signal: ~1.4 us behind the last workgroup instead of the ~11 us a
+// stream / device synchronize takes to push a marker packet through the queue behind a plain launch
+// (tools/src/sync_tail.hip, profiles/r05/sync_tail.txt). nullptr (every other launch): a plain launch.
+extern thread_local hipEvent_t tl_session_stop_event;
+template <typename F, typename... Args>
+inline void nam_launch(F kernel, dim3 grid, dim3 block, unsigned lds_bytes, hipStream_t stream, Args... args)
+{
+  if (tl_session_stop_event)
+    hipExtLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, nullptr, tl_session_stop_event, 0, args...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, args...);
+}
 
 // Persistent session of a one-wavefront-per-workgroup kernel (persist_wave.h); ring == nullptr: an ordinary launch
 struct PersistArgs
@@ -177,7 +194,6 @@ hipError_t launch_wn_reg_jit(void* fn, const WrArgs& a, int n_workgroups, int ld
 hipError_t launch_generic(const GenericArgs& a, int n_blocks, int lds_bytes, hipStream_t stream);
 hipError_t launch_a1(const A1Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t stream);
-hipError_t launch_a1_il(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
 // nam_a1_p4_kernel: the same models as a pipeline of wave sets decoupled through LDS (kernel_a1_p4.hip)
 hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
@@ -185,11 +201,9 @@ hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, 
 // rings; a.tiles_off = the plan's q weight block (A1Plan::q_w_off), a.consts_off = the FULL-layout tile area (ws_tiles_off)
 bool a1_q_takes(int act); // the activations it is compiled for (Fasttanh, Tanh)
 hipError_t launch_a1_q(const A1Args& a, int n_blocks, int act, hipStream_t stream);
-// nam_kp_kernel (kernel_kp.hip): the A2 topology (kp_table.h) as a pipeline of wave sets; a.tiles_off / consts_off / r1_off =
-// blob offsets of the K-tap kernel's tap tiles, LDS block and rechannel column
-hipError_t launch_kp(const A1Args& a, int n_blocks, int act, hipStream_t stream);
-// nam_kq_kernel (kernel_kq.hip): the same topology, state and session protocol with one lane per frame; a.tiles_off = the
-// plan's kq weight block (A1Plan::kq_w_off); kq_takes: the activations it is compiled for
+// nam_kq_kernel (kernel_kq.hip): the A2 topology (kp_table.h) as a pipeline of twelve one-wave stages, one lane per frame, on
+// nam_kt_mfma_kernel's stream state; a.tiles_off = the plan's kq weight block (A1Plan::kq_w_off); kq_takes: the activations it
+// is compiled for (LeakyReLU with a slope <= 1, ReLU, Tanh, Fasttanh)
 bool kq_takes(int act, float act_p0);
 hipError_t launch_kq(const A1Args& a, int n_blocks, int act, hipStream_t stream);
 hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, int lds_aux_floats, int act,

@@ -1,4 +1,4 @@
-// kp_table.h — the topology nam_kp_kernel (kernel_kp.hip) is compiled for, shared with the planner, which checks a model
+// kp_table.h — the topology nam_kq_kernel (kernel_kq.hip) is compiled for, shared with the planner, which checks a model
 // against it layer by layer before the kernel may run it (plan.cpp: build_a1_kp).
 //
 // Default: the A2 architecture — one layer array of 8 channels, 23 layers with kernel sizes 6 / 15 and the dilation

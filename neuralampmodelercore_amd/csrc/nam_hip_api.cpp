@@ -26,6 +26,11 @@
 
 using namespace namhip;
 
+namespace namhip
+{
+thread_local hipEvent_t tl_session_stop_event = nullptr; // (kernels.h: nam_launch)
+}
+
 namespace
 {
 
@@ -181,6 +186,7 @@ struct PersistSession
   long long *h_why = nullptr, *d_why = nullptr; // (NAM_HIP_SESSION_STATS) per workgroup: reason << 56 | grace loop << 48 | all-through count << 24 | own count
   unsigned long long n_waits = 0, n_polls = 0; // ticket waits, looks at the buffer's completion word
   unsigned epoch = 0; // counts session starts (a ticket of an earlier session is complete: sessions end flushed)
+  hipEvent_t retired = nullptr; // the completion signal of the session's latest launch (kernels.h: nam_launch), recorded by the dispatch itself
   bool cmd_done_published = false; // the running launch stores p_cmd_done behind every command's results (A1Args::p_out_host == 2); p_prog stays ring bookkeeping every 16 commands
 };
 
@@ -235,16 +241,17 @@ struct nam_hip_batch
   // the caller-supplied stream of the last nam_hip_batch_process_device: control calls that free or rewrite device
   // memory (Reset, SetSlimmableSize, destroy) wait for it as well as for the batch's own stream
   hipStream_t last_ext_stream = nullptr;
-  bool il_generic = false; // developer switch (NAM_HIP_IL_GENERIC=1): descriptor-driven kernel even for the official topology
   bool short_blocking_call = false; // a blocking host call of up to four buffers is being served: the caller waits for it, so the FIRST buffer's
                                     // latency is what counts — nam_a1_p4_kernel (four waves per layer: ~6 us through the model) rather than
                                     // nam_a1_q_kernel (one wave per layer: ~30 us; faster only once buffers overlap)
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
-  bool use_q = true; // the official 16 / 8 topology's pipeline runs nam_a1_q_kernel (kernel_a1_q.hip); NAM_HIP_A1Q=0: nam_a1_p4_kernel (A/B runs)
-  bool use_kq = true; // the A2 topology's pipeline runs nam_kq_kernel (kernel_kq.hip) where it applies; NAM_HIP_KQ=0: nam_kp_kernel everywhere
   int ticket_linger = kTicketLingerDefault; // ticks of the 100 MHz clock a ticket session's launch looks for the next buffer (NAM_HIP_TICKET_LINGER_US)
-  int wr_max_stages = 4; // developer switch (NAM_HIP_WR_STAGES=1/2/4): the most wavefronts per stream nam_wn_reg_kernel is started with
-  bool no_pipe = false; // developer switch (NAM_HIP_NO_PIPE=1): nam_a1_p2_kernel where nam_a1_p4_kernel would run (A/B runs)
+  // NAM_HIP_MAX_STAGES = 1 / 2 / 4 (developer switch; default: no cap): the most pipeline stages a stream is spread over.
+  // 1 = no pipelines at all (`no_pipe`: nam_a1_p2_kernel where nam_a1_p4 / q would run, nam_kt_mfma_kernel instead of nam_kq_kernel,
+  // nam_wn_reg_kernel as one wavefront per stream — the A/B and reference renderings of the tests); 2 / 4 cap nam_wn_reg_kernel's
+  // wavefronts per stream (the compile-time pipelines have fixed stage counts)
+  int wr_max_stages = 4;
+  bool no_pipe = false;
   PersistSession ps;
   bool ps_launching = false; // launch_group is starting the session's resident launch
   int n_cus = 0; // compute units of the device
@@ -348,7 +355,7 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 {
   const bool a1 = g.plan->a1.valid && g.d_a1;
   const bool mfma = a1 && (g.plan->a1.ws_ok || g.plan->a1.kt_ok);
-  const bool il = a1 && g.plan->a1.il_ok;
+  const bool il = a1 && g.plan->a1.il_ok && g.plan->a1.p2_ok; // the interleaved-frame kernels: the official topologies (compile-time job tables)
   const bool wr = g.plan->wr.ok && g.d_wr_blob;
   // a model no A1 kernel takes (FiLMs, gating, a nested condition_dsp ...) runs with its activations in registers when
   // its layers are among the instantiated shapes, else through the op interpreter
@@ -396,7 +403,7 @@ enum PersistKind : int
   PERSIST_WN_REG = 1, // nam_wn_reg_kernel: one wavefront per stream
   PERSIST_LSTM_ROW = 2, // nam_lstm_row_kernel: one wavefront per four streams
   PERSIST_LSTM_WIDE = 3, // nam_lstm_wide_kernel: one wavefront per stream
-  PERSIST_KP = 4 // nam_kp_kernel (the A2 topology): one workgroup (most of a CU's LDS) per stream, as PERSIST_A1_P2
+  PERSIST_KQ = 4 // nam_kq_kernel (the A2 topology): one workgroup (most of a CU's LDS) per stream, as PERSIST_A1_P2
 };
 int persist_kind(const nam_hip_batch* b);
 int persist_family(const nam_hip_batch* b, const WidthGroup& g);
@@ -414,17 +421,18 @@ inline bool use_pipeline(const nam_hip_batch* b, int n_frames)
   return !b->no_pipe && (b->ps_launching || n_frames > kBlock);
 }
 
-// the official 16 / 8 topology's pipeline: nam_a1_q_kernel (one-wave stages, LDS-resident rings) unless switched off
-inline bool q_runs(const nam_hip_batch* b, const Plan& p)
+// the official 16 / 8 topology's pipeline: nam_a1_q_kernel (one-wave stages, LDS-resident rings) for the activations it is compiled
+// for, nam_a1_p4_kernel otherwise (and for the other official sizes)
+inline bool q_runs(const nam_hip_batch*, const Plan& p)
 {
-  return b->use_q && p.a1.q_ok && !b->il_generic && a1_q_takes(p.a1.arr[0].act);
+  return p.a1.q_ok && a1_q_takes(p.a1.arr[0].act);
 }
 
-// the A2 topology's pipeline: nam_kq_kernel (one lane per frame, 4x4x1 matrix instructions) for the activation it is
-// compiled for, nam_kp_kernel otherwise
-inline bool kq_runs(const nam_hip_batch* b, const Plan& p)
+// the A2 topology's pipeline: nam_kq_kernel (one lane per frame, 4x4x1 matrix instructions) for the activations it is compiled
+// for (kernel_kq.hip: kq_takes); any other activation on that topology has no pipeline: nam_kt_mfma_kernel, a launch per buffer
+inline bool kq_runs(const nam_hip_batch*, const Plan& p)
 {
-  return b->use_kq && kq_takes(p.a1.arr[0].act, p.a1.arr[0].act_p0);
+  return p.a1.kp_ok && kq_takes(p.a1.arr[0].act, p.a1.arr[0].act_p0);
 }
 
 // `n_frames`: the launch length the question is about (under AUTO a launch of four or more blocks runs another kernel
@@ -436,7 +444,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
     switch (persist_kind(b)) // persistent block mode
     {
       case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : q_runs(b, p) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel";
-      case PERSIST_KP: return kq_runs(b, p) ? "nam_kq_kernel" : "nam_kp_kernel";
+      case PERSIST_KQ: return "nam_kq_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
       case PERSIST_LSTM_WIDE: return "nam_lstm_wide_kernel";
@@ -450,10 +458,9 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
       case NAM_HIP_KERNEL_WN_REG: return "nam_wn_reg_kernel";
       case NAM_HIP_KERNEL_A1: return "nam_a1_kernel";
       case NAM_HIP_KERNEL_A1_IL:
-        return (p.a1.p2_ok && !b->il_generic) ? ((!b->no_pipe && n_frames > kBlock) ? (q_runs(b, p) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel") : "nam_a1_p2_kernel")
-                                               : "nam_a1_il_kernel";
+        return (!b->no_pipe && n_frames > kBlock) ? (q_runs(b, p) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel") : "nam_a1_p2_kernel";
       default:
-        return p.a1.ws_ok ? "nam_a1_mfma_kernel" : (p.a1.kp_ok && !b->no_pipe && n_frames > kBlock) ? (kq_runs(b, p) ? "nam_kq_kernel" : "nam_kp_kernel") : "nam_kt_mfma_kernel";
+        return p.a1.ws_ok ? "nam_a1_mfma_kernel" : (kq_runs(b, p) && !b->no_pipe && n_frames > kBlock) ? "nam_kq_kernel" : "nam_kt_mfma_kernel";
     }
   }
   const LSTMPlan& L = p.lstm;
@@ -666,7 +673,7 @@ int launch_wr_all(nam_hip_batch* b, const WrGroupList& gs, const float* d_in, fl
 int kernel_for_launch(const nam_hip_batch* b, const WidthGroup& g, int n_frames)
 {
   const int kernel = pick_kernel(b, g);
-  if (b->kernel == NAM_HIP_KERNEL_AUTO && kernel == NAM_HIP_KERNEL_A1_MFMA && g.plan->a1.ws_ok && g.plan->a1.il_ok
+  if (b->kernel == NAM_HIP_KERNEL_AUTO && kernel == NAM_HIP_KERNEL_A1_MFMA && g.plan->a1.ws_ok && g.plan->a1.il_ok && g.plan->a1.p2_ok
       && n_frames >= 4 * kBlock)
     return NAM_HIP_KERNEL_A1_IL;
   return kernel;
@@ -763,7 +770,9 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames) && q_runs(b, p) && !b->short_blocking_call)
+        if (!p.a1.p2_ok) // (pick_kernel: the interleaved-frame kernels exist for the official topologies' compile-time tables only)
+          return fail(NAM_HIP_ERR_UNSUPPORTED, "NAM_HIP_KERNEL_A1_IL: not one of the official topologies");
+        if (use_pipeline(b, n_frames) && q_runs(b, p) && !b->short_blocking_call)
         {
           // the 16 / 8 topology as twelve one-wave stages, most rings resident in LDS (kernel_a1_q.hip): its own weight block
           // + the FULL-layout tiles of array 0 (kept in registers)
@@ -771,22 +780,20 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.tiles_off = p.a1.q_w_off;
           NAM_HIP_CHECK(launch_a1_q(a, n, act, s));
         }
-        else if (p.a1.p2_ok && !b->il_generic && use_pipeline(b, n_frames))
+        else if (use_pipeline(b, n_frames))
           // ... as a pipeline of wave sets (three wavefronts per SIMD) across consecutive buffers
           NAM_HIP_CHECK(launch_a1_p4(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
-        else if (p.a1.p2_ok && !b->il_generic) // the official topology: job table compiled in
+        else // one buffer: the four-wave kernel, job table compiled in
           NAM_HIP_CHECK(launch_a1_p2(a, n, p.a1.p2_c0, p.a1.p2_c1, act, s));
-        else
-          NAM_HIP_CHECK(launch_a1_il(a, n, act, s));
       }
       else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && n_frames > (1 << 28))
         // the K-tap kernel addresses the launch's input through a 32-bit buffer descriptor (1 GiB of float32 audio per
         // stream and launch): longer launches take the VALU kernel, same state layout
         NAM_HIP_CHECK(launch_a1(a, n, s));
-      else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && p.a1.kp_ok && use_pipeline(b, n_frames))
+      else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok && kq_runs(b, p) && use_pipeline(b, n_frames))
       {
-        // the A2 topology with more than one buffer in the launch (a session, a render, a prewarm): the pipeline of wave
-        // sets compiled for it (kernel_kp.hip); same state, tiles and constants as the K-tap kernel below
+        // the A2 topology with more than one buffer in the launch (a session, a render, a prewarm): the pipeline of one-wave
+        // stages compiled for it (kernel_kq.hip); same state as the K-tap kernel below
         a.tiles_off = p.a1.kt_desc[0].tile_off;
         a.consts_off = p.a1.kt_lds_src_off;
         a.r1_off = p.a1.kt_rech_off;
@@ -806,13 +813,8 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_seq0 = b->ps.seq0;
           a.p_cmd0 = b->ps.cmd0;
         }
-        if (kq_runs(b, p))
-        {
-          a.tiles_off = p.a1.kq_w_off;
-          NAM_HIP_CHECK(launch_kq(a, n, p.a1.arr[0].act, s));
-        }
-        else
-          NAM_HIP_CHECK(launch_kp(a, n, p.a1.arr[0].act, s));
+        a.tiles_off = p.a1.kq_w_off;
+        NAM_HIP_CHECK(launch_kq(a, n, p.a1.arr[0].act, s));
       }
       else if (kernel == NAM_HIP_KERNEL_A1_MFMA && !p.a1.ws_ok)
         // single-array models with other kernel sizes than 3 (A2): the K-tap MFMA kernel
@@ -1036,12 +1038,12 @@ int persist_kind(const nam_hip_batch* b)
     // leave, the next ones start behind them and consume the same commands (every workgroup resumes from its own
     // count) — in as many turns as it takes; bounded so that the completion words stay a short scan for the host.
     const int wg_limit = kPersistTurns * cus;
-    if (!b->il_generic && g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= wg_limit
+    if (g.plan->a1.valid && g.plan->a1.il_ok && g.plan->a1.p2_ok && b->n_streams <= wg_limit
         && (b->kernel == NAM_HIP_KERNEL_AUTO || b->kernel == NAM_HIP_KERNEL_A1_IL))
       return PERSIST_A1_P2;
-    if (!b->no_pipe && g.plan->a1.valid && g.plan->a1.kp_ok && !g.plan->a1.ws_ok && b->n_streams <= wg_limit
+    if (!b->no_pipe && g.plan->a1.valid && kq_runs(b, *g.plan) && !g.plan->a1.ws_ok && b->n_streams <= wg_limit
         && pick_kernel(b, g) == NAM_HIP_KERNEL_A1_MFMA)
-      return PERSIST_KP;
+      return PERSIST_KQ;
     return PERSIST_NONE;
   }
   if (g.plan->arch == ARCH_LSTM && b->kernel == NAM_HIP_KERNEL_AUTO)
@@ -1087,7 +1089,7 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   {
     const Plan& p = *g.plan;
     ps.cmd_done_published = b->pipe_session && ps.out_is_host && !b->no_pipe
-                        && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || (ps.kind == PERSIST_KP && kq_runs(b, p)));
+                        && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || ps.kind == PERSIST_KQ);
     // ... and linger: a workgroup that finds itself up to date when a launch starts (another one's backlog was the reason for
     // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
     // linger and leave before the next launch could pick it up again
@@ -1102,9 +1104,11 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   if (ps.kind == PERSIST_A1_P2)
     b->kernel = NAM_HIP_KERNEL_A1_IL;
   b->ps_launching = true;
+  namhip::tl_session_stop_event = ps.retired; // (the launch's own completion signal: persist_wait waits on it, not on the stream)
   const int rc = ps.kind == PERSIST_WN_REG
                    ? launch_wr_all(b, wr_groups(b), ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream)
                    : launch_group(b, g, nullptr, b->n_streams, ps.in_base, ps.out_base, kBlock, ps.stride, ps.kstream);
+  namhip::tl_session_stop_event = nullptr;
   b->ps_launching = false;
   b->kernel = keep;
   return rc;
@@ -1225,6 +1229,12 @@ int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool who
     {
       ps.flushed = ps.seq;
       ps.flushed_valid = true;
+      // every workgroup has published and left; the launch itself retires a moment later (end-of-kernel release). Waiting on the
+      // dispatch's own signal costs ~1.4 us and leaves nothing pending on the session's stream: a device-wide synchronize behind
+      // this flush (a host that fences per burst: bench.py's timed regions) finds the queue empty instead of pushing a marker
+      // through it (~11 us)
+      if (whole && ps.retired && ps.n_launches > 0)
+        NAM_HIP_CHECK(hipEventSynchronize(ps.retired));
       if (told_leave)
       {
         // the session goes on after a flush: the "leave" word must not stay at this count, or a later launch whose workgroups
@@ -1287,7 +1297,10 @@ int persist_stop(nam_hip_batch* b)
   if (!ps.active)
     return NAM_HIP_OK;
   const int rc = persist_flush(b, ps.last_caller ? ps.last_caller : b->stream);
-  NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream)); // the state is the caller's again only when the launch has gone
+  // the state is the caller's again only when the launch has gone: a successful whole flush has waited on the launch's own
+  // completion signal (persist_wait; 1.4 us — a stream synchronize pushes a marker through the queue, 11 us: profiles/r05/sync_tail.txt)
+  if (rc != NAM_HIP_OK || !ps.retired)
+    NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
   ps.active = false;
   return rc;
 }
@@ -1327,6 +1340,7 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     NAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     NAM_HIP_CHECK(hipStreamCreateWithPriority(&ps.kstream, hipStreamNonBlocking, prio_hi));
     NAM_HIP_CHECK(hipEventCreateWithFlags(&ps.order, hipEventDisableTiming));
+    NAM_HIP_CHECK(hipEventCreateWithFlags(&ps.retired, hipEventDisableTiming));
     NAM_HIP_CHECK(hipMemset(ps.d_ring, 0, kPRing * sizeof(unsigned long long)));
     NAM_HIP_CHECK(hipMemset(ps.d_ring + kPRing, 0xff, kPRingTail * sizeof(unsigned long long))); // (the "leave" word: no count)
     NAM_HIP_CHECK(hipDeviceSynchronize());
@@ -1553,6 +1567,8 @@ void persist_free(nam_hip_batch* b)
     (void)hipStreamDestroy(ps.kstream);
   if (ps.order)
     (void)hipEventDestroy(ps.order);
+  if (ps.retired)
+    (void)hipEventDestroy(ps.retired);
   ps = PersistSession();
 }
 
@@ -2145,7 +2161,7 @@ int nam_hip_model_get_info(const nam_hip_model* model, nam_hip_model_info* info)
                                              : 0; // a container has no weights of its own
   info->fast_tanh = s.fast_tanh ? 1 : 0;
   info->has_a1_kernel = (p.a1.valid ? 1 : 0) | ((p.a1.valid && (p.a1.ws_ok || p.a1.kt_ok)) ? 2 : 0)
-                        | ((p.a1.valid && p.a1.il_ok) ? 4 : 0) | ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? 8 : 0)
+                        | ((p.a1.valid && p.a1.il_ok && p.a1.p2_ok) ? 4 | 8 : 0)
                         | (p.wr.ok ? 16 : 0) | (p.wr.jit_failed.empty() ? 0 : 32);
   info->state_bytes_per_stream = (int64_t)p.state_floats * (int64_t)sizeof(float);
   std::strncpy(info->version, s.version.c_str(), sizeof(info->version) - 1);
@@ -2186,17 +2202,16 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   b->device = device;
   (void)hipDeviceGetAttribute(&b->n_cus, hipDeviceAttributeMultiprocessorCount, device);
   {
-    const char* e = std::getenv("NAM_HIP_IL_GENERIC");
-    b->il_generic = e && e[0] == '1';
-    if (const char* e4 = std::getenv("NAM_HIP_WR_STAGES"))
-      b->wr_max_stages = std::max(1, std::atoi(e4));
     b->ticket_linger = ticket_linger_from_env();
-    const char* e6 = std::getenv("NAM_HIP_A1Q");
-    b->use_q = !(e6 && e6[0] == '0');
-    const char* e5 = std::getenv("NAM_HIP_KQ");
-    b->use_kq = !(e5 && e5[0] == '0');
-    const char* e3 = std::getenv("NAM_HIP_NO_PIPE");
-    b->no_pipe = e3 && e3[0] == '1';
+    if (const char* e = std::getenv("NAM_HIP_MAX_STAGES"))
+    {
+      const int v = std::atoi(e);
+      if (v >= 1)
+      {
+        b->wr_max_stages = v;
+        b->no_pipe = v == 1;
+      }
+    }
   }
   b->n_streams = n_streams;
   b->max_frames = max_frames;
@@ -2634,12 +2649,6 @@ int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable)
     const int rc = persist_stop(batch);
     if (rc != NAM_HIP_OK)
       return rc;
-  }
-  if (enable)
-  {
-    const char* e = std::getenv("NAM_HIP_NO_PERSISTENT"); // developer switch (A/B runs of callers that opt in themselves)
-    if (e && e[0] == '1')
-      enable = 0;
   }
   batch->ps.enabled = enable != 0;
   return (batch->ps.enabled && persist_eligible(batch)) ? 1 : 0;

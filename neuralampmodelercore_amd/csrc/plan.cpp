@@ -710,7 +710,7 @@ void build_a1_ws(const WaveNetSpec& wn, Plan& plan)
   a1.ws_ok = 1;
 }
 
-// Job table of nam_a1_il_kernel (plan.h: IlDesc / IlFetch). Built from the finished A1 plan: same eligibility, tiles,
+// Job table of the interleaved-frame mapping (plan.h: IlDesc / IlFetch; nam_a1_p2_kernel's compile-time tables are checked against it). Built from the finished A1 plan: same eligibility, tiles,
 // constants and per-job flags as nam_a1_mfma_kernel; ring offsets are final (write-position table included).
 void build_a1_il(Plan& plan)
 {
@@ -1137,7 +1137,7 @@ void build_a1_kt(Plan& plan)
   a1.kt_ok = 1;
 }
 
-// nam_kp_kernel (kernel_kp.hip) is compiled for ONE topology (kp_table.h: by default the A2 stack the reference's fused
+// nam_kq_kernel (kernel_kq.hip) is compiled for ONE topology (kp_table.h: by default the A2 stack the reference's fused
 // path is written for, a2_fast.cpp:57-764): it may run a model only when the K-tap kernel's plan of that model is, layer by
 // layer, what the kernel's compile-time tables say — kernel sizes, dilations, ring geometry and offsets, chunk and tile
 // offsets, the LDS block.
@@ -1318,12 +1318,35 @@ void build_a1_q(Plan& plan)
 // Zero-padding such arrays to the next multiple (weights, biases, mixin, rechannels all zero for the extra channels)
 // is exact on the real channels: the padded ones carry f(0) through the activations and meet zero weights everywhere.
 // Returns false when the model is not a plain kernel-size-3 WaveNet that padding would help.
+//
+// The official topology — two arrays of ten layers, kernel size 3, dilations 1 .. 512, Tanh — at the smaller official widths
+// (lite 12 / 6, feather 8 / 4; NAM's "standard" is 16 / 8) is padded all the way to 16 / 8: nam_a1_q_kernel (kernel_a1_q.hip,
+// compiled for that one shape) then takes it, and its 6.8 us per buffer at 256 streams beats what the narrower shapes reach on
+// nam_a1_p4_kernel (lite 8.2, feather 7.1: profiles/r05/official_sizes_256.txt) — the matrix pipe does not care about rows of
+// zeros as much as the pipeline cares about LDS-resident rings. (nano, 4 / 2, stays on nam_wn_reg_kernel: 5.7 us.)
+bool official_standard_topology(const WaveNetSpec& wn)
+{
+  if (wn.arrays.size() != 2)
+    return false;
+  for (const LayerArraySpec& A : wn.arrays)
+  {
+    if (A.num_layers() != 10)
+      return false;
+    for (int l = 0; l < 10; l++)
+      if (A.dilations[(size_t)l] != (1 << l) || (A.activations[(size_t)l].type != ACT_TANH && A.activations[(size_t)l].type != ACT_FASTTANH)
+          || A.activations[(size_t)l].type != wn.arrays[0].activations[0].type)
+        return false;
+  }
+  const int c0 = wn.arrays[0].channels, c1 = wn.arrays[1].channels;
+  return c0 >= 8 && c0 <= 16 && c1 >= 4 && c1 <= 8 && !(c0 == 16 && c1 == 8);
+}
 bool pad_channels_for_mfma(const WaveNetSpec& wn, WaveNetSpec& out)
 {
   if (wn.condition_dsp || wn.with_head || wn.in_channels != 1 || wn.slimmable || wn.arrays.empty())
     return false;
-  auto up4 = [](int c) { return (c + 3) / 4 * 4; };
-  bool any = false;
+  const bool to_standard = official_standard_topology(wn);
+  auto padw = [&](size_t array, int c) { return to_standard ? (array == 0 ? 16 : 8) : (c + 3) / 4 * 4; }; // padded width of an array
+  bool any = to_standard;
   for (const LayerArraySpec& A : wn.arrays)
   {
     // (1-3 channels stay as they are: for models that small the VALU kernel is the better one once the chip is full)
@@ -1352,9 +1375,9 @@ bool pad_channels_for_mfma(const WaveNetSpec& wn, WaveNetSpec& out)
   {
     const LayerArraySpec& A = wn.arrays[ai];
     LayerArraySpec& P = out.arrays[ai];
-    const int C = A.channels, Cp = up4(C);
-    const int in = A.input_size, inp = ai == 0 ? in : up4(wn.arrays[ai - 1].channels);
-    const int H = A.head_size, Hp = ai + 1 < n_arr ? up4(wn.arrays[ai + 1].channels) : H;
+    const int C = A.channels, Cp = padw(ai, C);
+    const int in = A.input_size, inp = ai == 0 ? in : padw(ai - 1, wn.arrays[ai - 1].channels);
+    const int H = A.head_size, Hp = ai + 1 < n_arr ? padw(ai + 1, wn.arrays[ai + 1].channels) : H;
     if (ai > 0 && in != wn.arrays[ai - 1].channels)
       return false;
     if (ai + 1 < n_arr && H != wn.arrays[ai + 1].channels)

@@ -169,7 +169,7 @@ struct VDesc // 16 x int32, one s_load_dwordx16
 };
 static_assert(sizeof(CDesc) == 32 && sizeof(VDesc) == 64, "descriptor sizes are part of the kernel ABI");
 
-// ---- Interleaved-frame MFMA kernel (nam_a1_il_kernel): same models, tiles and constants as nam_a1_mfma_kernel ----
+// ---- Interleaved-frame MFMA kernel (nam_a1_p2_kernel and its pipelines): same models, tiles and constants as nam_a1_mfma_kernel ----
 // Compute wave w of a stream's workgroup owns frames t = 4 j + w (j = lane & 15) of the 64-frame block instead of 16
 // consecutive ones. A dilated tap (t - L) then lives
 //   * L >= 64            : in an earlier block — the lane fetches it from the history ring itself (IL_HIST);
@@ -359,7 +359,7 @@ struct A1Plan
   int32_t kt_rech_off = 0; // blob float offset: rechannel column in the lane layout (16 floats)
   int32_t kt_lds_src_off = 0, kt_lds_floats = 0; // blob region copied to LDS at kernel start: 1x1 tiles | constants
   KtDesc kt_desc[kKtChunkMax];
-  int32_t kp_ok = 0; // nam_kp_kernel can run this model too: it IS the topology of kp_table.h (plan.cpp: build_a1_kp)
+  int32_t kp_ok = 0; // nam_kq_kernel can run this model: it IS the topology of kp_table.h (plan.cpp: build_a1_kp)
   int32_t kq_w_off = 0; // blob float offset of nam_kq_kernel's weight block (tiles | constants | rechannel column; kernel_kq.hip)
   int32_t q_ok = 0; // nam_a1_q_kernel runs this model: it IS the topology of aq_table.h (plan.cpp: build_a1_q)
   int32_t q_w_off = 0; // blob float offset of its weight block (aq_table.h: kWrOff .. kBlockFloats)

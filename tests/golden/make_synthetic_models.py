@@ -33,6 +33,10 @@ SPECS = {
     # the third instantiation of the compile-time-topology kernel (nam_a1_p2_kernel<8, 4>)
     "synth_a1_feather": dict(arrays=[(8, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
                                      (4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=17),
+    # the feather shape with another activation: nam_a1_q_kernel is compiled for Tanh / Fasttanh, so this one keeps its own
+    # width (no padding to 16 / 8: plan.cpp: official_standard_topology) and its pipeline is nam_a1_p4_kernel<8, 4>
+    "synth_a1_feather_relu": dict(arrays=[(8, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "ReLU", False),
+                                          (4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "ReLU", True)], seed=27),
     # the official "nano" shape: 4 -> 2 channels, ten layers each. Too narrow for the matrix-core kernels (2 channels):
     # nam_wn_reg_kernel's plain-layer runs, 68 KB of LDS-resident rings per stream
     "synth_a1_nano": dict(arrays=[(4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),

@@ -794,32 +794,28 @@ def test_generic_and_padded_a1_kernels_do_not_share_state(nam_lib, oracle, name)
 
 @pytest.mark.parametrize("name", ["wavenet_a1_standard"] + SYNTH_A1)
 @pytest.mark.parametrize("fast_tanh", [True, False])
-@pytest.mark.parametrize("generic", [False, True])
-def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, monkeypatch, name, fast_tanh, generic):
-    """nam_a1_il_kernel (frames 4j + w per wave): exchange / DPP / ring-only jobs, idle padding jobs (13, 12, 15 layers),
-    full / half / partial-quad layouts, padded channel counts, run-time activation dispatch — one launch per buffer with
-    a ragged tail, one multi-block launch (requests prefetched across block boundaries), and alternating with the
-    wave-specialised MFMA kernel and the VALU kernel on the same state between buffers."""
+def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, name, fast_tanh):
+    """NAM_HIP_KERNEL_A1_IL — the interleaved-frame kernels (frames 4j + w per wave: exchange / DPP / ring-only jobs) exist for the
+    official topologies (standard, lite = 12 / 6 padded to 12 / 8, feather), their job tables compiled in: nam_a1_p2_kernel for a
+    buffer, the pipelines for longer launches; every other K = 3 topology (13, 12, 15 layers, other dilations: the descriptor-driven
+    form was retired in round 5) falls back to the wave-specialised nam_a1_mfma_kernel. One launch per buffer with a ragged
+    tail, one multi-block launch, and alternating with the wave-specialised MFMA kernel and the VALU kernel on the same
+    state between buffers."""
     nam = nam_lib
     n_streams, block, n = 3, 64, 64 * 6 + 17
     x = stream_bank(n_streams, n, seed=131)
     model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
-    assert model.info.has_a1_kernel & 4, "fixture must be eligible for the interleaved-frame kernel"
-    # the official topology (standard, lite, feather) runs nam_a1_p2_kernel, its job table compiled in; `generic` forces
-    # the descriptor-driven nam_a1_il_kernel on the same model (for other topologies the two runs are the same kernel)
     p2 = bool(model.info.has_a1_kernel & 8)
     assert p2 == (name in ("wavenet_a1_standard", "synth_a1_lite", "synth_a1_feather"))
-    if generic and not p2:
-        pytest.skip("not the official topology: already covered by the generic=False run")
-    monkeypatch.setenv("NAM_HIP_IL_GENERIC", "1" if generic else "0")
-    want_name = "nam_a1_p2_kernel" if (p2 and not generic) else "nam_a1_il_kernel"
+    want_name = "nam_a1_p2_kernel" if p2 else "nam_a1_mfma_kernel"
+    generic = False
     for mode, max_frames in (("blocks", block), ("one_launch", 512)):
         refs = [_oracle_run(oracle, name, x[s], max_frames, fast_tanh) for s in range(n_streams)]
         b = model.batch(n_streams, max_frames)
         b.set_kernel(nam.KERNEL_A1_IL)
-        assert b.get_kernel() == nam.KERNEL_A1_IL and b.kernel_name() == want_name
-        if p2 and not generic:  # launches of more than one block: the two-wave-set form of the same kernel
-            assert b.kernel_name(512) == ("nam_a1_q_kernel" if name == "wavenet_a1_standard" else "nam_a1_p4_kernel")
+        assert b.get_kernel() == (nam.KERNEL_A1_IL if p2 else nam.KERNEL_A1_MFMA) and b.kernel_name() == want_name
+        if p2 and not generic:  # launches of more than one block: the pipelined forms
+            assert b.kernel_name(512) == "nam_a1_q_kernel"  # (lite and feather: zero-padded to 16 / 8 for it)
         b.Reset(prewarm=True)
         y = b.process_stream(x, max_frames)
         b.close()
@@ -842,7 +838,7 @@ def test_interleaved_mfma_kernel_matches_oracle(nam_lib, oracle, monkeypatch, na
 
 
 def test_interleaved_mfma_kernel_headline_shape_and_determinism(nam_lib, oracle):
-    """256 streams x 8 buffers on nam_a1_il_kernel, every stream against the oracle; the same audio as block launches and
+    """256 streams x 8 buffers on nam_a1_p2_kernel, every stream against the oracle; the same audio as block launches and
     as one resident launch (twice each) is bit-identical: any unsynchronised hand-off (loader progress word, LDS
     exchange windows, ring rows read back across blocks) would show up as run-to-run differences; 700 streams = more
     workgroups than CUs."""
@@ -886,7 +882,7 @@ def test_persistent_block_mode_matches_oracle(nam_lib, oracle):
     # the kernels that speak the session protocol: nam_a1_p2_kernel (a workgroup per stream), nam_wn_reg_kernel (a
     # wavefront per stream), nam_lstm_row_kernel (a wavefront per four streams: 7 streams = a ragged last workgroup),
     # nam_lstm_wide_kernel (a wavefront per stream)
-    for name, kname in (("wavenet_a1_standard", "nam_a1_q_kernel"), ("synth_a1_feather", "nam_a1_p4_kernel"), ("synth_a1_lite", "nam_a1_p4_kernel"),
+    for name, kname in (("wavenet_a1_standard", "nam_a1_q_kernel"), ("synth_a1_feather_relu", "nam_a1_p4_kernel"), ("synth_a1_lite", "nam_a1_q_kernel"),
                         ("wavenet_a2_max", "nam_wn_reg_kernel"), ("lstm", "nam_lstm_row_kernel"),
                         ("synth_lstm_h4x2", "nam_lstm_row_kernel"), ("synth_lstm_h18x2", "nam_lstm_wide_kernel")):
         model = nam.get_dsp(model_path(name), fast_tanh=True)

@@ -3,7 +3,7 @@ replay / restart behaviour of its fused path (tools/test/test_a2_fast.cpp:272-36
 implementations, block after block, and again after a Reset); here: a persistent session of >= 200 buffers of real signal —
 a flush in the middle, a pause long enough for the resident launch to leave and be started again, more workgroups than the
 chip holds at once ("turns") — against ONE ordinary launch of the un-pipelined kernel of the family on the same audio, every
-stream and every frame, and ten streams (first, last, middle, seeded picks) against the CPU oracle. (Round 3's split-wave bug of nam_kq_kernel only showed in
+stream and every frame, and six streams (first, last, middle, seeded picks) against the CPU oracle. (Round 3's split-wave bug of nam_kq_kernel only showed in
 exactly this kind of run: tools/persist_soak.py, now a test.)"""
 import os
 import time
@@ -22,12 +22,12 @@ CASES = {
     "a1_standard_q_turns": ("wavenet_a1_standard", 500, 200, {}, "nam_a1_q_kernel"),
     # libm tanh: the ACT_TANH instantiations (session and plain launch) of the headline kernel, tools/render.cpp's setting
     "a1_standard_q_libm_tanh": ("wavenet_a1_standard", 256, 200, {}, "nam_a1_q_kernel", False),
-    "a1_standard_p4": ("wavenet_a1_standard", 256, 200, {"NAM_HIP_A1Q": "0"}, "nam_a1_p4_kernel"),
-    "a1_feather_p4_turns": ("synth_a1_feather", 500, 200, {}, "nam_a1_p4_kernel"),
+    "a1_lite_q_padded": ("synth_a1_lite", 256, 200, {}, "nam_a1_q_kernel"),  # 12 / 6 zero-padded to the kernel's 16 / 8
+    "a1_feather_relu_p4_turns": ("synth_a1_feather_relu", 500, 200, {}, "nam_a1_p4_kernel"),
     "a2_full_kq": ("A2", 256, 240, {}, "nam_kq_kernel"),
     "a2_full_kq_turns": ("A2", 500, 200, {}, "nam_kq_kernel"),
-    "a2_max_wn_reg_2_stages": ("wavenet_a2_max", 512, 200, {"NAM_HIP_WR_STAGES": "2"}, "nam_wn_reg_kernel"),
-    "a2_max_wn_reg_4_stages": ("wavenet_a2_max", 512, 200, {"NAM_HIP_WR_STAGES": "4"}, "nam_wn_reg_kernel"),
+    "a2_max_wn_reg_2_stages": ("wavenet_a2_max", 512, 200, {"NAM_HIP_MAX_STAGES": "2"}, "nam_wn_reg_kernel"),
+    "a2_max_wn_reg_4_stages": ("wavenet_a2_max", 512, 200, {"NAM_HIP_MAX_STAGES": "4"}, "nam_wn_reg_kernel"),
 }
 
 
@@ -42,7 +42,7 @@ def test_long_session_against_one_launch(nam_lib, oracle, monkeypatch, case):
     model = nam.get_dsp(model_path(name), fast_tanh=fast_tanh)
     xd = torch.from_numpy(x[:, None, :]).cuda()
     # the reference rendering: one launch of the un-pipelined kernel (a fresh batch: its own state)
-    monkeypatch.setenv("NAM_HIP_NO_PIPE", "1")
+    monkeypatch.setenv("NAM_HIP_MAX_STAGES", "1")  # no pipelines: the un-pipelined kernel of the family
     ref_b = model.batch(n_streams, nb * block)
     ref_b.Reset(prewarm=True)
     yr = torch.zeros_like(xd)
@@ -50,7 +50,7 @@ def test_long_session_against_one_launch(nam_lib, oracle, monkeypatch, case):
     ref_b.synchronize()
     ref_name = ref_b.kernel_name(nb * block)
     ref_b.close()
-    monkeypatch.setenv("NAM_HIP_NO_PIPE", "0")
+    monkeypatch.setenv("NAM_HIP_MAX_STAGES", "0")  # (no cap)
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
     b = model.batch(n_streams, block)
@@ -79,7 +79,7 @@ def test_long_session_against_one_launch(nam_lib, oracle, monkeypatch, case):
     # against the CPU oracle: the first and last stream, the middle ones and a few picked by the case's seed — a stream map wrong
     # in BOTH kernels (they share the host side) would pass the comparison above
     rng = np.random.default_rng(len(case))
-    picks = sorted({0, 1, n_streams // 2, n_streams - 1, *rng.integers(0, n_streams, size=6).tolist()})
+    picks = sorted({0, n_streams // 2, n_streams - 1, *rng.integers(0, n_streams, size=3).tolist()})
     tol = 5e-5 if fast_tanh else 1e-4
     for s in picks:
         ref = oracle.get_dsp(model_path(name), fast_tanh=fast_tanh)

@@ -43,10 +43,10 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
 @pytest.mark.parametrize("name,bits", [
     ("wavenet_a1_standard", 15), ("A2", 3), ("synth_kt_c8", 3), ("synth_kt_c16", 3), ("synth_kt_c12", 3),
     ("synth_kt_c4", 19),  # (4 channels, 2 taps per layer: small enough for nam_wn_reg_kernel compiled for its shapes; AUTO keeps the matrix cores)
-    ("synth_a1_mixed", 7),  # kernel size 3 everywhere, several arrays: the wave-specialised + interleaved MFMA kernels
+    ("synth_a1_mixed", 3),  # kernel size 3 everywhere, several arrays: the wave-specialised MFMA kernel (the interleaved-frame ones: official sizes only)
     ("synth_a1_nano", 17),  # 4 -> 2 channels: VALU kernel, and nam_wn_reg_kernel's plain-layer runs (68 KB of LDS rings)
-    ("synth_a1_lite", 15), ("synth_a1_c14", 7),
-    ("synth_a1_feather", 31),  # (8 -> 4 channels also fit nam_wn_reg_kernel: 129 KB of LDS rings; AUTO keeps the matrix cores)  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
+    ("synth_a1_lite", 15), ("synth_a1_c14", 3),
+    ("synth_a1_feather_relu", 31), ("synth_a1_feather", 31),  # (8 -> 4 channels also fit nam_wn_reg_kernel: 129 KB of LDS rings; AUTO keeps the matrix cores)  # 6 / 14 / 10 channels: zero-padded to a multiple of 4 for them
     ("slimmable_wavenet", 17),  # 3 channels: VALU kernel, and (dilations up to 512 in LDS-resident rings) nam_wn_reg_kernel
     # FiLMs / gating / nested condition_dsp / multi-channel: the register-resident kernel (bit 4) where every layer is
     # one of its instantiated shapes, else the op interpreter alone (a post-stack head)
@@ -61,7 +61,7 @@ def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
 
 
 def test_the_a2_pipeline_kernel_is_offered_to_the_a2_topology_only(nam_lib):
-    """nam_kp_kernel is compiled for ONE topology (csrc/kp_table.h: the A2 stack of the reference's fused path,
+    """nam_kq_kernel is compiled for ONE topology (csrc/kp_table.h: the A2 stack of the reference's fused path,
     wavenet/a2_fast.cpp): plan.cpp: build_a1_kp checks a model against the table layer by layer — kernel sizes, dilations,
     ring geometry, chunk and tile offsets — and only A2.nam's 8-channel submodel passes; other K-tap models keep the
     descriptor-driven kernel (kt_mfma=1, kp=0); A2-Lite (3 channels) runs on nam_wn_reg_kernel."""

@@ -6,6 +6,7 @@
 //   stream     ... hipStreamSynchronize of that stream only
 //   ext_event  hipExtLaunchKernelGGL with a stop event (a completion signal on the dispatch itself), hipEventSynchronize
 //   query      ... spinning on hipStreamQuery
+//   + DeviceSync / StreamSync behind the event wait: what is left for a caller that synchronizes the device anyway
 //   hipcc --offload-arch=gfx950 -O2 -o /tmp/sync_tail tools/src/sync_tail.hip && /tmp/sync_tail
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -42,7 +43,7 @@ int main()
   hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   unsigned tag = 0;
   for (int mb : {0, 20})
-    for (int mode = 0; mode < 4; mode++)
+    for (int mode = 0; mode < 6; mode++)
     {
       std::vector<double> seen, done;
       for (int rep = 0; rep < 60; rep++)
@@ -69,8 +70,18 @@ int main()
           hipStreamSynchronize(s);
         else if (mode == 2)
           hipEventSynchronize(ev);
-        else
+        else if (mode == 3)
           while (hipStreamQuery(s) == hipErrorNotReady) {}
+        else if (mode == 4)
+        {
+          hipEventSynchronize(ev);
+          hipDeviceSynchronize(); // what a host that fences per burst does behind nam_hip_batch_flush
+        }
+        else
+        {
+          hipEventSynchronize(ev);
+          hipStreamSynchronize(s);
+        }
         const double t2 = now_us();
         if (rep >= 10)
         {
@@ -80,7 +91,8 @@ int main()
       }
       std::sort(seen.begin(), seen.end());
       std::sort(done.begin(), done.end());
-      const char* names[4] = {"plain + hipDeviceSynchronize", "plain + hipStreamSynchronize", "ext stop event + hipEventSynchronize", "ext stop event + hipStreamQuery spin"};
+      const char* names[6] = {"plain + hipDeviceSynchronize", "plain + hipStreamSynchronize", "ext stop event + hipEventSynchronize", "ext stop event + hipStreamQuery spin",
+                              "ext stop event + EventSync + DeviceSync", "ext stop event + EventSync + StreamSync"};
       printf("%2d MB dirtied, %-40s launch -> flags visible %7.2f us (median), flags visible -> synchronized %6.2f us (median; min %5.2f, p90 %5.2f)\n", mb, names[mode],
              seen[seen.size() / 2], done[done.size() / 2], done[0], done[done.size() * 9 / 10]);
     }
