@@ -284,7 +284,7 @@ def run_other_configs(args):
     """Brief runs of BASELINE.json configs 3, 4, 5 (+ A2-Full) for the default line (`other_configs`): one subprocess each (a failure
     of one cannot take the headline with it), `--brief`: 500 timed steps x 11 regions, no side runs, ~2 s CPU baseline."""
     import subprocess
-    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "max_abs_err_vs_oracle", "cpu_baseline",
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "max_abs_err_vs_oracle", "parity_detail", "cpu_baseline",
             "finite", "region_us")
     res = {}
     # "A2": not a BASELINE.json config — the reference's own flagship shape (A2.nam's A2-Full submodel, what its fused
@@ -534,13 +534,15 @@ def compact_line(out: dict, full_path) -> dict:
         if isinstance(out.get(k), dict):
             line[k] = {q: out[k].get(q) for q in ("value", "ms_per_step", "kernel", "max_abs_err_vs_oracle")}
     if isinstance(out.get("steady_state"), dict):
-        line["steady_state"] = {k: out["steady_state"].get(k) for k in ("value", "ms_per_step", "steps_per_region", "floor_frac", "compute_frac")}
+        line["steady_state"] = {k: out["steady_state"].get(k) for k in ("value", "ms_per_step", "steps_per_region", "max_abs_err_vs_oracle", "floor_frac", "compute_frac")}
     if isinstance(out.get("other_configs"), dict):
         line["other_configs"] = {k: _brief_config(v) for k, v in out["other_configs"].items() if k != "2_steady"}
     hio = out.get("host_io")
     if isinstance(hio, dict):
         line["host_io"] = ({"error": str(hio["error"])[:120]} if "error" in hio else
                            {k: {m: v[m]["value"] for m in ("blocking", "tickets") if m in v} for k, v in hio.items() if isinstance(v, dict)})
+    if out.get("parity_detail"):
+        line["parity_detail"] = out["parity_detail"]
     line["full_record"] = full_path
     # a guard, not a plan: shed the optional blocks (least important first) should the line ever outgrow the limit
     for k in ("host_io", "zeros_input", "resident_launch", "latency_us", "region_us", "repetitions", "other_configs"):
@@ -812,6 +814,7 @@ def main():
     gathered_ok = gathered is None or tuple(gathered.shape) == (n_total, oc, block)
 
     parity = None
+    parity_detail = None
     if rank == 0 and args.check and not args.dry_run:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nam_oracle
@@ -821,7 +824,16 @@ def main():
         ref.Reset(SR, block)
         sig = bank[mine[0], :n_chk]
         r = ref.process_stream(np.repeat(sig[None, :], ic, axis=0) if ic > 1 else sig, block)[0]  # (every input channel carries the signal)
-        parity = float(np.max(np.abs(r - got_dev.cpu().numpy())))
+        got_np = got_dev.cpu().numpy()
+        parity = float(np.max(np.abs(r - got_np)))
+        if parity > 1e-3:
+            # a wrong result is a finding, not a number: say where (which frames of the checked stream, whole buffers of zeros?)
+            bad = np.nonzero(np.abs(r - got_np) > 1e-3)[0]
+            blocks = sorted(set((bad // block).tolist()))
+            parity_detail = {"bad_frames": int(bad.size), "first": int(bad[0]), "last": int(bad[-1]), "blocks": blocks[:16],
+                             "n_blocks": len(blocks),
+                             "zero_blocks": [int(b_) for b_ in blocks[:16] if not np.any(got_np[b_ * block:(b_ + 1) * block])]}
+            print("bench.py: PARITY FAILURE " + json.dumps(parity_detail), file=sys.stderr, flush=True)
     elif rank == 0 and args.dry_run:
         parity = float(torch.max(torch.abs(got_dev - 0.5 * x[0, 0, :n_chk])))
 
@@ -1015,6 +1027,8 @@ def main():
             "finite": finite and gathered_ok,
             "max_abs_err_vs_oracle": parity,
         }
+        if parity_detail is not None:
+            out["parity_detail"] = parity_detail
         out.update(side)
         if args.dry_run:
             out["data"] = "dry-run (stub compute on CPU tensors over gloo): plumbing only, not a measurement"
@@ -1038,6 +1052,7 @@ def main():
             out["host_io"] = {"error": f"{type(e).__name__}: {e}"}
         st = out["other_configs"].get("2_steady") or {}
         out["steady_state"] = {"value": st.get("value"), "ms_per_step": st.get("ms_per_step"), "steps_per_region": 500,
+                               "max_abs_err_vs_oracle": st.get("max_abs_err_vs_oracle"),
                                "floor_frac": (st.get("roofline") or {}).get("floor_frac"),
                                "compute_frac": ((st.get("roofline") or {}).get("compute") or {}).get("frac"),
                                "note": "the same kernel, streams and session mode in regions of 500 steps (other_configs['2_steady']); "

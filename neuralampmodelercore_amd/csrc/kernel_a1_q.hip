@@ -4,6 +4,12 @@
 #include "il_common.h"
 #include "aq_table.h"
 
+#ifndef NAM_AQ_SLEEP
+#define NAM_AQ_SLEEP 1 // s_sleep between two looks at a hand-over word (x 64 cycles); 0 and 2 measured level (profiles/r05/a1q_variants.txt)
+#endif
+#define NAM_AQ_STR2(x) #x
+#define NAM_AQ_STR(x) NAM_AQ_STR2(x)
+
 namespace namhip
 {
 
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     int tmp, stmp;
     want = uni(want);
     asm volatile("1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_sub_i32 %1, %1, %3\n\t"
-                 "s_cmp_lt_i32 %1, 0\n\ts_cbranch_scc0 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 "s_cmp_lt_i32 %1, 0\n\ts_cbranch_scc0 2f\n\ts_sleep " NAM_AQ_STR(NAM_AQ_SLEEP) "\n\ts_branch 1b\n2:"
                  : "=&v"(tmp), "=&s"(stmp)
                  : "v"(byte_addr), "s"(want)
                  : "scc");

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 5: A/B of the libraries under variants/ against the shipped one: driver shape + 500-step regions, two passes, any bench args
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export NAM_HIP_PERSIST_TIMEOUT_MS=8000
+cp neuralampmodelercore_amd/lib/libnam_hip.so /tmp/libnam_hip.main.so
+Q() { python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  ', '$1', j['config']['kernel'], round(j['ms_per_step']*1e3,3), 'us/step', j['value'], j.get('region_us'), 'err', j['max_abs_err_vs_oracle'])
+"; }
+B="python3 bench.py --gpus 1 --no-other-configs --no-side-runs --no-cpu-baseline $@"
+for rep in 1 2; do
+for v in /tmp/libnam_hip.main.so variants/*.so; do
+  cp "$v" neuralampmodelercore_amd/lib/libnam_hip.so
+  t=$(basename $v .so)
+  timeout 200 $B --steps 20 --warmup 5 2>/dev/null | Q "$t driver"
+  timeout 200 $B --steps 500 --warmup 50 --brief 2>/dev/null | Q "$t steady"
+done
+done
+cp /tmp/libnam_hip.main.so neuralampmodelercore_amd/lib/libnam_hip.so
