@@ -706,7 +706,7 @@ def main():
         # Spin-up, right in front of the repetitions: continuous untimed GPU work on a SCRATCH batch (the measured batch's
         # state is not touched; the output window is zeroed again afterwards). The device takes tens of milliseconds of
         # load to reach its sustained clocks, and the driver-shaped run (--steps 20 --warmup 5: 0.3 ms per repetition)
-        # would otherwise be measured entirely inside that ramp (tools/persist_region_probe.py: the same 20-step region
+        # would otherwise be measured entirely inside that ramp (docs/DESIGN_HISTORY.md §6: the same 20-step region
         # 246 us at the start of a process, 226 us 20 ms later).
         scratch.bind(x, y)
         t_end = time.perf_counter() + args.spinup_ms / 1e3

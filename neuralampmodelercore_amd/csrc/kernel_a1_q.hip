@@ -1,4 +1,4 @@
-// kernel_a1_q.hip — nam_a1_q_kernel: the official A1 "standard" topology (aq_table.h) as a pipeline of TWELVE ONE-WAVE STAGES
+// kernel_a1_q.hip — nam_a1_q_kernel: the official A1 "standard" topology (aq_table.h) as a pipeline of SIXTEEN ONE-WAVE STAGES
 // whose hand-over medium is the next layer's history ring itself, most rings resident in LDS for the whole launch.
 #include "device_common.h"
 #include "il_common.h"
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   }
 }
 
-#ifdef NAM_AQ_PROBE // developer builds (tools/isa_regions.py): one instantiation only
+#ifdef NAM_AQ_PROBE // developer builds (ISA inspection): one instantiation only
 template __global__ void nam_a1_q_kernel<ACT_FASTTANH, false, true>(const float* __restrict__, const A1Args);
 #else
 namespace

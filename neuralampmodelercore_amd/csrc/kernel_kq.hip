@@ -46,7 +46,7 @@ constexpr int kRows = 1 << 20; // num_records of the ring descriptor (rows)
 constexpr int kActLeakyMax = 100; // ACT_T of the LeakyReLU instantiation (slope <= 1)
 // stage s = jobs [kFirst[s], kFirst[s + 1]); wave i of the workgroup runs stage kStageOfWave[i] — waves i, i + 4, i + 8 share a
 // SIMD, and the three stages of every SIMD carry (nearly) the same number of matrix instructions + per-job overhead
-// (7 % above the mean for the heaviest; found by exhaustive search over the cuts, tools note in DESIGN.md)
+// (7 % above the mean for the heaviest; found by exhaustive search over the cuts, tools note in docs/DESIGN_HISTORY.md §4.2d)
 constexpr int kFirst[kNst + 1] = {0, 2, 4, 6, 8, 10, 12, 14, 15, 17, 20, 22, 24};
 constexpr int kStageOfWave[kNst] = {4, 3, 2, 0, 7, 8, 6, 1, 9, 10, 11, 5};
 static_assert(kFirst[kNst] == kJobs, "kq stage table");

@@ -1,5 +1,5 @@
 #!/bin/bash
-# hunting an intermittent parity failure of the 500-step regions (max_abs_err 0.562 in 3 of ~14 runs of scripts/gpu_r5_ab.sh)
+# hunting an intermittent parity failure of the 500-step regions (max_abs_err 0.562 in 3 of ~14 runs of scripts/gpu_ab_variants.sh)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export NAM_HIP_PERSIST_TIMEOUT_MS=8000
 B="python3 bench.py --gpus 1 --no-other-configs --no-side-runs --no-cpu-baseline $@"
 cp neuralampmodelercore_amd/lib/libnam_hip.so /tmp/libnam_hip.main.so

@@ -1,6 +1,6 @@
 """Developer tool: a long persistent session of a model (default: the headline model) — N streams x B buffers, repeated R
 times with random pauses (the launch leaves and restarts) — against the same audio rendered by ONE ordinary multi-block
-launch of the un-pipelined kernel of the family (NAM_HIP_NO_PIPE=1 in a fresh batch); every stream, every frame.
+launch of the un-pipelined kernel of the family (NAM_HIP_MAX_STAGES=1 in a fresh batch); every stream, every frame.
 Usage: persist_soak.py streams buffers reps [model fixture name]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,14 +16,14 @@ name = sys.argv[4] if len(sys.argv) > 4 else "wavenet_a1_standard"
 model = nam.get_dsp(os.path.join(ROOT, f"tests/golden/models/{name}.nam"), fast_tanh=True)
 x = stream_bank(n_streams, nb * block, seed=99)
 xd = torch.from_numpy(x[:, None, :]).cuda()
-os.environ["NAM_HIP_NO_PIPE"] = "1"
+os.environ["NAM_HIP_MAX_STAGES"] = "1"
 ref_b = model.batch(n_streams, nb * block)
 ref_b.Reset(prewarm=True)
 yr = torch.zeros_like(xd)
 ref_b.process_device(xd.data_ptr(), yr.data_ptr(), nb * block, nb * block)
 ref_b.synchronize()
 ref_b.close()
-os.environ["NAM_HIP_NO_PIPE"] = "0"
+os.environ["NAM_HIP_MAX_STAGES"] = "0"
 rng = np.random.default_rng(5)
 worst = 0.0
 for rep in range(reps):
