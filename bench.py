@@ -737,7 +737,13 @@ def main():
             engine.run_steps(W, K, args.launch)
             fence(engine)
             if rep == -P:
-                got_dev = y[0, 0, :n_chk].clone()  # parity sample: blocks 0..W+K of the FIRST pass over the window
+                # parity sample: the first buffers of the FIRST pass over the window. The copy runs on torch's stream, the next
+                # repetition's session launch on its own: WAIT for the copy, or a slow first launch of the copy kernel (module
+                # load on some boxes) lets the second pass overwrite what it is about to read (round 5: three runs in seventy
+                # read max-abs 0.562 = exactly |first pass - second pass| of the checked stream)
+                got_dev = y[0, 0, :n_chk].clone()
+                if not args.dry_run:
+                    torch.cuda.synchronize(dev)
             continue
         engine.run_steps(0, W, args.launch)
         fence(engine)
@@ -755,6 +761,8 @@ def main():
         raw.append((wall, gpu_s, t_enq))
         if rep == 0 and P == 0:
             got_dev = y[0, 0, :n_chk].clone()  # parity sample: blocks 0..W+K of the FIRST pass over the window
+            if not args.dry_run:
+                torch.cuda.synchronize(dev)  # (see above: the copy must not race the next repetition)
     red = reduce_max([v for r_ in raw for v in r_[:2]])
     regions = [{"wall_s": red[2 * i], "gpu_s": red[2 * i + 1], "enqueue_s": raw[i][2],
                 "flushed_s": raw[i][1] if pers else None} for i in range(R)]
