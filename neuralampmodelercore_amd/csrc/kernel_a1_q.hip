@@ -190,7 +190,17 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
 
   constexpr bool kOutHost = PERSIST && WT; // (kernel_a1_p4.hip: a session whose results go to host memory)
   constexpr int kInAux = PERSIST ? 17 : 0; // session inputs bypass the caches (the caller may rewrite the buffer between commands)
-  constexpr int kAppAux = WT && !PERSIST ? 17 : 0; // ring appends of a short launch are written through
+  // Ring appends of a short launch and of a session, and the resident rings' way back into the state when a session's launch
+  // leaves, are written through (sc0 sc1): nothing of them is left dirty in the L2 for the end-of-kernel release, which is on the
+  // host's critical path when it synchronizes behind a burst (driver-shaped 20-buffer regions 7.85 -> 7.79 us per step in four
+  // same-box passes, 500-step regions level: profiles/r05/a1q_variants.txt; NAM_AQ_NO_WT restores round 4's plain stores)
+#ifdef NAM_AQ_NO_WT
+  constexpr int kAppAux = WT && !PERSIST ? 17 : 0;
+  constexpr int kWbAux = 0;
+#else
+  constexpr int kAppAux = (WT || PERSIST) ? 17 : 0;
+  constexpr int kWbAux = PERSIST ? 17 : 0;
+#endif
   auto ring_load = [&](unsigned s_) {
     return __hip_atomic_load(a.p_ring + (s_ & (unsigned)a.p_ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     for (int i = 0; i < NI; i++)
     {
       const int row = i * per + rl;
-      aq_sb_store4(t[i], wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, 0);
+      aq_sb_store4(t[i], wide ? rs16 : rs8, row < R ? row : aq::kNoRow, (int)(pl * 16u), ring_off_f * 4, kWbAux);
     }
   };
 

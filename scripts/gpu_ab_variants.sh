@@ -8,7 +8,7 @@ j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  ', '$1', j['config']['kernel'], round(j['ms_per_step']*1e3,3), 'us/step', j['value'], j.get('region_us'), 'err', j['max_abs_err_vs_oracle'])
 "; }
 B="python3 bench.py --gpus 1 --no-other-configs --no-side-runs --no-cpu-baseline $@"
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in /tmp/libnam_hip.main.so variants/*.so; do
   cp "$v" neuralampmodelercore_amd/lib/libnam_hip.so
   t=$(basename $v .so)
