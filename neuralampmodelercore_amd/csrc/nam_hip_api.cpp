@@ -1423,6 +1423,23 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
   // (longer calls — an offline render of a whole file — are one resident launch of their own: same kernel, no commands)
   if (n_frames <= 0 || n_frames % kBlock != 0 || n_frames > kPersistMaxFrames)
     return 1;
+  {
+    // A buffer is never split across sessions: whether this one still fits the session — its sequence numbers below the
+    // rebase mark, its LAST command inside the 2 GB window the kernels address — is decided once, here, not command by
+    // command (a session that ended between two commands of a buffer restarted with the slot pointer as its base: the next
+    // slot then lay below it and forced another restart — correct, and silently slow)
+    PersistSession& ps = b->ps;
+    if (ps.active)
+    {
+      const long off_last = (d_in + (n_frames - kBlock)) - ps.in_base;
+      if (ps.seq + (unsigned)(n_frames / kBlock) >= ps.rebase_at || off_last > 0x1fff0000l)
+      {
+        const int rc = persist_stop(b);
+        if (rc != NAM_HIP_OK)
+          return rc;
+      }
+    }
+  }
   for (int f = 0; f < n_frames; f += kBlock)
   {
     const int rc = persist_submit_block(b, d_in + f, d_out + f, stride, caller);
@@ -1694,6 +1711,17 @@ bool host_windows(nam_hip_batch* b, int slots, float*& in_bar, float*& h_out_map
     return true;
   const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
   const size_t pitch = (size_t)b->n_streams * std::max(ic, oc) * b->max_frames; // (one slot; the same for both windows: a command carries ONE offset)
+  if (pitch * (size_t)slots > (size_t)0x1fff0000)
+  {
+    // the kernels address a session's window through one 2 GB buffer descriptor: windows beyond it would make every buffer a
+    // session of its own (stop, start, launch). Said once; the copying path (staging + launches on the batch's stream) serves
+    // such batches
+    std::fprintf(stderr, "nam_hip: %d streams x %d frames x %d host-buffer slots exceed the 2 GB session window: host buffers of this "
+                         "batch go through staging copies instead of the mapped windows (smaller max_frames or fewer streams per batch avoid this)\n",
+                 b->n_streams, b->max_frames, slots);
+    failed = true;
+    return false;
+  }
   if (hipExtMallocWithFlags(reinterpret_cast<void**>(&in_bar), pitch * slots * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess)
   {
     (void)hipGetLastError();

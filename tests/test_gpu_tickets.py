@@ -236,3 +236,50 @@ def test_two_ticket_sessions_share_one_device(nam_lib, monkeypatch, linger_us):
         b.close()
         got = np.concatenate(ys[i], axis=2)
         assert float(np.abs(got - wants[i]).max()) <= 2e-5 * max(1.0, float(np.abs(wants[i]).max()))
+
+
+def test_tickets_survive_control_calls_outside_persistent_mode(nam_lib):
+    """Outside persistent mode a ticket is staging + copies + a launch on the batch's stream with an event behind them
+    (include/nam_hip.h: control calls complete the tickets in flight first). A ticket submitted BEFORE set_kernel /
+    SetSlimmableSize and waited for AFTER it must hold what the blocking call renders for the same buffer."""
+    nam = nam_lib
+    frames = 64
+    # set_kernel between submit and wait (the A1 kernels and the op program share one state layout on this model)
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    x = stream_bank(6, 4 * frames, seed=31)
+    ref_b = model.batch(6, frames)
+    ref_b.Reset(prewarm=True)
+    want = ref_b.process_stream(x, frames)
+    ref_b.close()
+    b = model.batch(6, frames)
+    b.Reset(prewarm=True)
+    t0 = b.submit(x[:, :frames])
+    t1 = b.submit(x[:, frames:2 * frames])
+    b.set_kernel(nam.KERNEL_A1)  # quiesces: both launches have run, their results are kept for the waits
+    y1 = b.wait(t1)
+    y0 = b.wait(t0)
+    y2 = b.process(x[:, 2 * frames:3 * frames])  # the VALU kernel carries on from the same state
+    b.set_kernel(nam.KERNEL_AUTO)
+    t3 = b.submit(x[:, 3 * frames:])
+    y3 = b.wait(t3)
+    b.close()
+    got = np.concatenate([y0, y1, y2, y3], axis=2)
+    assert float(np.abs(got - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+    # SetSlimmableSize between submit and wait: the ticket holds the OLD width's rendering, the next buffer the new width's
+    # from the reset state of that width (slimmable.cpp:489-498)
+    model = nam.get_dsp(model_path("slimmable_wavenet"), fast_tanh=True)
+    x = stream_bank(5, 2 * frames, seed=32)
+    b = model.batch(5, frames)
+    b.Reset(prewarm=True)
+    ref_b = model.batch(5, frames)
+    ref_b.Reset(prewarm=True)
+    want0 = ref_b.process(x[:, :frames])
+    ref_b.SetSlimmableSize(0.0)
+    want1 = ref_b.process(x[:, frames:])
+    ref_b.close()
+    t0 = b.submit(x[:, :frames])
+    b.SetSlimmableSize(0.0)
+    y0 = b.wait(t0)
+    y1 = b.process(x[:, frames:])
+    b.close()
+    assert float(np.abs(y0 - want0).max()) <= 1e-6 and float(np.abs(y1 - want1).max()) <= 1e-6
