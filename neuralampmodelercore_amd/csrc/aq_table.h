@@ -30,7 +30,11 @@ constexpr int kNst = 16;
 // port cycles per buffer: a big layer 2.65 k, a pair of small layers 1.5 k -> per SIMD {L0, L1, L2, M9 + head} 8.85 k |
 // {L3, L4, L5, T + M0} 9.25 k | {L6, L7, M1-2, M3-4} 8.3 k | {L8, L9, M5-6, M7-8} 8.35 k
 constexpr int kFirst[kNst + 1] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 22};
+#ifdef NAM_AQ_SOW // (A/B builds: another stage -> wave table, profiles/r05/a1q_variants.txt)
+constexpr int kStageOfWave[kNst] = {NAM_AQ_SOW};
+#else
 constexpr int kStageOfWave[kNst] = {0, 3, 6, 8, 1, 4, 7, 9, 2, 5, 11, 13, 15, 10, 12, 14};
+#endif
 static_assert(kFirst[kNst] == kJobs, "aq stage table");
 
 constexpr bool is_big(int job) { return job < kLayers; }
