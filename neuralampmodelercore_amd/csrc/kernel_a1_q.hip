@@ -79,6 +79,26 @@ __device__ __forceinline__ mf::f4 aq_act4(const mf::f4& v)
   return r;
 }
 
+// A stage's priority once the launch's first buffer is through it: 0 for every stage (measured: profiles/r05/a1q_variants.txt;
+// NAM_AQ_STEADY_PRIO = sixteen values 0 .. 3 for A/B builds)
+#ifdef NAM_AQ_STEADY_PRIO
+constexpr int kAqSteadyPrio[aq::kNst] = {NAM_AQ_STEADY_PRIO};
+#else
+constexpr int kAqSteadyPrio[aq::kNst] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+template <int SS>
+__device__ __forceinline__ void aq_steady_prio()
+{
+  if constexpr (kAqSteadyPrio[SS] == 3)
+    __builtin_amdgcn_s_setprio((short)3);
+  else if constexpr (kAqSteadyPrio[SS] == 2)
+    __builtin_amdgcn_s_setprio((short)2);
+  else if constexpr (kAqSteadyPrio[SS] == 1)
+    __builtin_amdgcn_s_setprio((short)1);
+  else
+    __builtin_amdgcn_s_setprio((short)0);
+}
+
 namespace aq
 {
 constexpr int kNoRow = 1 << 26; // a ring row index no descriptor holds: the access is dropped / returns 0
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         }
       }
       if (k == 0)
-        __builtin_amdgcn_s_setprio((short)0); // (the launch's first buffer is through this stage)
+        aq_steady_prio<SS>(); // (the launch's first buffer is through this stage)
       // the rings move on by the buffer's frames (scalar unit)
 #pragma unroll
       for (int u = 0; u < NJS; u++)
@@ -913,7 +933,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         dbg_t[7] = k + 1;
       }
       if (k == 0)
-        __builtin_amdgcn_s_setprio((short)0); // (the launch's first buffer is through this stage's layers)
+        aq_steady_prio<SS>(); // (the launch's first buffer is through this stage's layers)
       if constexpr (!LAST)
       {
         constexpr int RN = aq::ring_len(JN);
