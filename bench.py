@@ -435,9 +435,14 @@ def host_io(model_path: str, n_streams: int, fast_tanh: bool, budget_s: float = 
         yp = [y.ctypes.data_as(ctypes.c_void_p) for y in ys]
         h = b._h
         entry = {}
-        for mode in ("blocking", "tickets"):
+        for mode in ("blocking", "tickets", "tickets_depth_1"):
             def run(n):
-                if mode == "blocking":
+                if mode == "tickets_depth_1":  # submit, wait at once: what a blocking call routed through the ticket path would cost
+                    t1 = ctypes.c_int64(-1)
+                    for i in range(n):
+                        if L.nam_hip_batch_submit_f32(h, xp[i % D], frames, ctypes.byref(t1)) != 0 or L.nam_hip_batch_wait_f32(h, t1, yp[i % D]) != 0:
+                            raise RuntimeError(L.nam_hip_last_error().decode())
+                elif mode == "blocking":
                     for i in range(n):
                         if L.nam_hip_batch_process_f32(h, xp[i % D], yp[i % D], frames) != 0:
                             raise RuntimeError(L.nam_hip_last_error().decode())
