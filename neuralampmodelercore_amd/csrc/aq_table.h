@@ -69,7 +69,16 @@ constexpr bool starts_stage(int job) { return kFirst[stage_of(job)] == job; }
 // (or that has none: the transition) takes its input through a small area: two sub-blocks (32 rows) for a big layer, one
 // buffer (64 rows) for the transition and for a small layer.
 constexpr bool takes_area(int job) { return job > 0 && job < kJobHead && starts_stage(job) && !res(job); }
-constexpr int in_rows(int job) { return res(job) ? ring_len(job) : takes_area(job) ? (is_big(job) ? 32 : kBlockF) : 0; }
+// How many sub-blocks the hand-over INTO a big stage holds (its slot, and its input area when it has one): two — a resident ring of
+// 2 d + 64 rows has room for the consumer's sub-block, its 2 d of history and at most three sub-blocks ahead of it, and the words
+// count modulo a power of two — except into the stages whose first ring is in HBM (L7, L8, L9: they take their rows through an area
+// of their own, which may be as deep as LDS allows): four with NAM_AQ_DEEP_Q (A/B: profiles/r05/a1q_variants.txt)
+#ifdef NAM_AQ_DEEP_Q
+constexpr int depth_in(int job) { return (is_big(job) && !res(job)) ? 4 : 2; }
+#else
+constexpr int depth_in(int) { return 2; }
+#endif
+constexpr int in_rows(int job) { return res(job) ? ring_len(job) : takes_area(job) ? (is_big(job) ? 16 * depth_in(job) : kBlockF) : 0; }
 constexpr int plane_b(int job) { return (in_rows(job) * 16 + 255) / 256 * 256; }
 constexpr int in_bytes(int job) { return plane_b(job) * (chans(job) / 4); }
 
@@ -95,7 +104,7 @@ constexpr int kSlotB0 = kFlagB + 256;
 // Into a big stage: two sub-blocks deep ([4 planes][32 rows] | input sample [32] | token); into the transition: a whole
 // buffer of sub-blocks ([4 planes][64 rows] | [64] | token); between small stages: one buffer ([2 planes][64 rows] | [64] | token)
 constexpr int kSubSlot = 2 * 1024 + 128 + 16, kBigSlot = 4 * 1024 + 256 + 16, kSmallSlot = 2 * 1024 + 256 + 16;
-constexpr int slot_bytes(int b) { return is_big(kFirst[b + 1]) ? kSubSlot : kFirst[b + 1] == kJobT ? kBigSlot : kSmallSlot; }
+constexpr int slot_bytes(int b) { return is_big(kFirst[b + 1]) ? (depth_in(kFirst[b + 1]) == 4 ? kBigSlot : kSubSlot) : kFirst[b + 1] == kJobT ? kBigSlot : kSmallSlot; }
 constexpr int slot_b(int b)
 {
   int o = kSlotB0;

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     constexpr int NFAR = aq::far_jobs_before(SS, JN);
     // how many sub-blocks the slot (and a non-resident input area) holds: two into a big stage, the whole buffer into the
     // transition, which takes it at once
-    constexpr int DIN = 2, DOUT = JN == aq::kJobT ? 4 : 2;
+    constexpr int DIN = aq::depth_in(J0), DOUT = JN == aq::kJobT ? 4 : aq::depth_in(JN);
     static_assert(aq::is_big(JN) || JN == aq::kJobT, "aq: array 0's last stage hands over to the transition");
     // ---- this stage's weights: registers for the whole launch. Tile q of job j (plan.cpp: build_a1_ws, FULL layout):
     // lane (g, i) holds W[out = i][in = 4 g + s], s = 0 .. 3 — the A operand of k-step s ----
