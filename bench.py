@@ -532,7 +532,7 @@ def compact_line(out: dict, full_path) -> dict:
     if out.get("region_us"):
         line["region_us"] = out["region_us"]
     if out.get("latency_us"):
-        line["latency_us"] = {k: out["latency_us"].get(k) for k in ("min", "p50", "p99", "p99_9")}
+        line["latency_us"] = {k: out["latency_us"].get(k) for k in ("kernel", "min", "p50", "p99", "p99_9")}
     if out.get("resident_launch"):
         line["resident_launch"] = {k: out["resident_launch"].get(k) for k in ("value", "ms_per_step")}
     for k in ("zeros_input", "fast_tanh_off", "fast_tanh_on"):
@@ -771,6 +771,9 @@ def main():
     red = reduce_max([v for r_ in raw for v in r_[:2]])
     regions = [{"wall_s": red[2 * i], "gpu_s": red[2 * i + 1], "enqueue_s": raw[i][2],
                 "flushed_s": raw[i][1] if pers else None} for i in range(R)]
+    # the kernel the timed regions ran (asked now: a session that sees bursts of a few buffers — the latency pass below — starts
+    # the low-latency form of the headline kernel from then on, include/nam_hip.h: nam_hip_batch_set_persistent)
+    kname_timed = engine.kernel_name()
     order = sorted(range(R), key=lambda i: regions[i]["wall_s"])
     med = regions[order[R // 2]]
     wall_med, gpu_s_med = med["wall_s"], med["gpu_s"]
@@ -795,8 +798,9 @@ def main():
         if getattr(engine, "persistent", False):
             # persistent block mode: what a real-time host sees per buffer — ring the doorbell, wait until every workgroup
             # has published the buffer (the session stays alive between buffers)
-            engine.run_steps(W, 1, "block")
-            engine.batch.flush(engine.stream.cuda_stream)
+            for _ in range(8):  # (untimed: the session learns the pattern — one-buffer bursts — before the samples are taken)
+                engine.run_steps(W, 1, "block")
+                engine.batch.flush(engine.stream.cuda_stream)
             d = []
             for s in range(n_lat):
                 t_a = time.perf_counter()
@@ -804,7 +808,8 @@ def main():
                 engine.batch.flush(engine.stream.cuda_stream)
                 d.append((time.perf_counter() - t_a) * 1e6)
             d.sort()
-            note = "us per buffer, host clock: doorbell -> all workgroups done -> host (persistent block mode, session alive)"
+            note = ("us per buffer, host clock: doorbell -> all workgroups done -> host (persistent block mode, session alive); "
+                    "kernel of these one-buffer bursts: " + engine.kernel_name())
         else:
             evs = [engine.event()]
             for s in range(n_lat):
@@ -814,7 +819,7 @@ def main():
             d = sorted(engine.elapsed_ms(evs[i], evs[i + 1]) * 1e3 for i in range(n_lat))
             note = "us between consecutive HIP events on the launch stream, one launch per step (event overhead included)"
         fence_local()
-        latency = {"launches": n_lat, "min": round(d[0], 2), "p50": round(percentile(d, 0.5), 2),
+        latency = {"launches": n_lat, "kernel": engine.kernel_name(), "min": round(d[0], 2), "p50": round(percentile(d, 0.5), 2),
                    "p99": round(percentile(d, 0.99), 2), "p99_9": round(percentile(d, 0.999), 2), "max": round(d[-1], 2),
                    "note": note}
     if distributed:
@@ -910,7 +915,7 @@ def main():
         hist = wavenet_history_bytes_per_sample(mj["config"]) if mj["architecture"] == "WaveNet" else 0
         bytes_per_sample = hist + 4 * (ic + oc)
         achieved_gbs = bytes_per_sample * samples_per_launch / avg_launch_s / 1e9
-        kname = engine.kernel_name()
+        kname = kname_timed
         tr = measured_traffic(kname, model_name, n_streams, block, args.launch)
         lds = None
         if tr and tr.get("lds_idx_active_cycles") is not None and tr.get("rocprof_avg_launch_us"):

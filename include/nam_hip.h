@@ -244,7 +244,14 @@ NAM_HIP_API int nam_hip_batch_render_f32(nam_hip_batch* batch, const float* cons
  * blocking *_f32 / *_f64 entry points, which do it) before consuming them.
  * Eligible: one width group on nam_a1_q_kernel / nam_a1_p4_kernel / nam_kq_kernel up to 8 streams per CU (beyond one per CU the workgroups
  * take turns on the chip); every group on nam_wn_reg_kernel up to 8 x min(4, 160 KB / LDS image) streams per CU (in turns too); small LSTMs.
- * Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual). */
+ * Returns 1 if the batch will use the mode, 0 if it is not eligible (the calls then launch as usual).
+ * Allocation: this call and nam_hip_batch_reset — the non-real-time side of the reference's contract (NAM/dsp.h:163) — allocate
+ * everything a session needs (command ring, completion words, its stream and events, the host windows of the blocking entry points);
+ * no process / submit / wait / flush call allocates.
+ * First-buffer latency: a session of the official 16 / 8 WaveNet topology whose caller has flushed after at most four buffers three
+ * times in a row starts its next launches as nam_a1_p4_kernel (four waves per layer: the first buffer of a launch is through in a
+ * few microseconds) instead of nam_a1_q_kernel (sixteen one-wave stages: higher throughput once buffers overlap), and goes back after
+ * a longer burst; both work on the same stream state. nam_hip_batch_kernel_name reports what the next launch starts as. */
 NAM_HIP_API int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable);
 /* Blocks until every buffer submitted so far has been rendered and is visible (hip_stream: the stream the process
  * calls were issued on; NULL = the batch's own). No-op outside persistent mode. */

@@ -717,12 +717,18 @@ namespace
 #endif
 constexpr int kP4Stages = NAM_P4_STAGES;
 
+// the instantiation's code object on the device and its dynamic-LDS limit raised (what the first launch would otherwise pay: ~1.6 ms)
+template <int C0, int C1, int ACT_T, bool WT, bool PERSIST>
+hipError_t p4_ready()
+{
+  static DynamicLdsLimit lds_limit; // per instantiation, tracked per device (kernels.h)
+  return lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_p4_kernel<C0, C1, ACT_T, WT, PERSIST, kP4Stages>), p4::lds_bytes(kP4Stages));
+}
 template <int C0, int C1, int ACT_T, bool WT, bool PERSIST = false>
 hipError_t launch_p4_inst(const A1Args& a, int n_blocks, hipStream_t stream)
 {
-  static DynamicLdsLimit lds_limit; // per instantiation, tracked per device (kernels.h)
   constexpr int lds_bytes = p4::lds_bytes(kP4Stages);
-  const hipError_t e = lds_limit.ensure(reinterpret_cast<const void*>(&nam_a1_p4_kernel<C0, C1, ACT_T, WT, PERSIST, kP4Stages>), lds_bytes);
+  const hipError_t e = p4_ready<C0, C1, ACT_T, WT, PERSIST>();
   if (e != hipSuccess)
     return e;
   nam_launch((nam_a1_p4_kernel<C0, C1, ACT_T, WT, PERSIST, kP4Stages>), dim3(n_blocks), dim3(kP4Stages * 256), lds_bytes, stream,
@@ -749,6 +755,19 @@ hipError_t launch_p4_shape(const A1Args& a, int n_blocks, int act, hipStream_t s
   return wt ? launch_p4_inst<C0, C1, -1, true>(a, n_blocks, stream) : launch_p4_inst<C0, C1, -1, false>(a, n_blocks, stream);
 }
 } // namespace
+
+// A session of the 16 / 8 topology may switch to this kernel in the middle of a caller's real-time loop (nam_hip_api.cpp:
+// PersistSession::short_bursts): its session instantiation is made ready when the session starts, not at the switch.
+hipError_t preload_a1_p4_session(int c0, int c1, int act, bool out_host)
+{
+  if (c0 != 16 || c1 != 8)
+    return hipSuccess;
+  if (act == ACT_FASTTANH)
+    return out_host ? p4_ready<16, 8, ACT_FASTTANH, true, true>() : p4_ready<16, 8, ACT_FASTTANH, false, true>();
+  if (act == ACT_TANH)
+    return out_host ? p4_ready<16, 8, ACT_TANH, true, true>() : p4_ready<16, 8, ACT_TANH, false, true>();
+  return hipSuccess;
+}
 
 hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream)
 {

@@ -197,6 +197,7 @@ hipError_t launch_a1_mfma(const A1Args& a, int n_blocks, int act, hipStream_t st
 hipError_t launch_a1_p2(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
 // nam_a1_p4_kernel: the same models as a pipeline of wave sets decoupled through LDS (kernel_a1_p4.hip)
 hipError_t launch_a1_p4(const A1Args& a, int n_blocks, int c0, int c1, int act, hipStream_t stream);
+hipError_t preload_a1_p4_session(int c0, int c1, int act, bool out_host); // (kernel_a1_p4.hip)
 // nam_a1_q_kernel (kernel_a1_q.hip): the 16 / 8 official topology (aq_table.h) as twelve one-wave stages with LDS-resident
 // rings; a.tiles_off = the plan's q weight block (A1Plan::q_w_off), a.consts_off = the FULL-layout tile area (ws_tiles_off)
 bool a1_q_takes(int act); // the activations it is compiled for (Fasttanh, Tanh)

@@ -186,6 +186,14 @@ struct PersistSession
   long long *h_why = nullptr, *d_why = nullptr; // (NAM_HIP_SESSION_STATS) per workgroup: reason << 56 | grace loop << 48 | all-through count << 24 | own count
   unsigned long long n_waits = 0, n_polls = 0; // ticket waits, looks at the buffer's completion word
   unsigned epoch = 0; // counts session starts (a ticket of an earlier session is complete: sessions end flushed)
+  // Burst lengths (commands between two whole flushes) of this session, newest first; ~0u = not seen yet. A host that flushes after
+  // every buffer or two (a device-resident real-time chain: process_device + flush per 64 .. 256 frames) waits for the FIRST buffer of
+  // every launch: the official 16 / 8 topology then starts as nam_a1_p4_kernel (four waves per layer: the first buffer is through in
+  // ~6 us) instead of nam_a1_q_kernel (one wave per layer: ~27 us, faster only once buffers overlap) — the rule of the blocking host
+  // calls (short_blocking_call), learnt from the caller's own pattern: three bursts in a row of at most four buffers
+  unsigned bursts[3] = {~0u, ~0u, ~0u};
+  unsigned burst_start = 0; // `seq` at the last whole flush
+  bool short_bursts() const { return bursts[0] <= 4u && bursts[1] <= 4u && bursts[2] <= 4u; }
   hipEvent_t retired = nullptr; // the completion signal of the session's latest launch (kernels.h: nam_launch), recorded by the dispatch itself
   bool cmd_done_published = false; // the running launch stores p_cmd_done behind every command's results (A1Args::p_out_host == 2); p_prog stays ring bookkeeping every 16 commands
 };
@@ -443,7 +451,8 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
   if (b->ps.enabled && n_frames == kBlock)
     switch (persist_kind(b)) // persistent block mode
     {
-      case PERSIST_A1_P2: return b->no_pipe ? "nam_a1_p2_kernel" : q_runs(b, p) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel";
+      case PERSIST_A1_P2: // (what the NEXT launch of the session starts: PersistSession::short_bursts)
+        return b->no_pipe ? "nam_a1_p2_kernel" : (q_runs(b, p) && !(b->ps.active && !b->pipe_session && b->ps.short_bursts())) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel";
       case PERSIST_KQ: return "nam_kq_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
@@ -772,7 +781,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
         }
         if (!p.a1.p2_ok) // (pick_kernel: the interleaved-frame kernels exist for the official topologies' compile-time tables only)
           return fail(NAM_HIP_ERR_UNSUPPORTED, "NAM_HIP_KERNEL_A1_IL: not one of the official topologies");
-        if (use_pipeline(b, n_frames) && q_runs(b, p) && !b->short_blocking_call)
+        if (use_pipeline(b, n_frames) && q_runs(b, p) && !b->short_blocking_call && !(b->ps_launching && !b->pipe_session && b->ps.short_bursts()))
         {
           // the 16 / 8 topology as twelve one-wave stages, most rings resident in LDS (kernel_a1_q.hip): its own weight block
           // + the FULL-layout tiles of array 0 (kept in registers)
@@ -1089,7 +1098,7 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   {
     const Plan& p = *g.plan;
     ps.cmd_done_published = b->pipe_session && ps.out_is_host && !b->no_pipe
-                        && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || ps.kind == PERSIST_KQ);
+                        && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || ps.kind == PERSIST_KQ); // (pipe_session: never the short-burst rule)
     // ... and linger: a workgroup that finds itself up to date when a launch starts (another one's backlog was the reason for
     // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
     // linger and leave before the next launch could pick it up again
@@ -1229,6 +1238,13 @@ int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool who
     {
       ps.flushed = ps.seq;
       ps.flushed_valid = true;
+      if (whole && ps.seq != ps.burst_start)
+      {
+        ps.bursts[2] = ps.bursts[1];
+        ps.bursts[1] = ps.bursts[0];
+        ps.bursts[0] = ps.seq - ps.burst_start;
+        ps.burst_start = ps.seq;
+      }
       // every workgroup has published and left; the launch itself retires a moment later (end-of-kernel release). Waiting on the
       // dispatch's own signal costs ~1.4 us and leaves nothing pending on the session's stream: a device-wide synchronize behind
       // this flush (a host that fences per burst: bench.py's timed regions) finds the queue empty instead of pushing a marker
@@ -1305,12 +1321,15 @@ int persist_stop(nam_hip_batch* b)
   return rc;
 }
 
-int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride)
+// Everything a session needs that does not depend on its window — command ring, completion words, the launch's stream and events,
+// the low-latency sibling kernel's code object — allocated OUTSIDE the audio path: nam_hip_batch_set_persistent and nam_hip_batch_reset
+// call this (the reference's contract: process() never allocates, Reset / get_dsp run on a non-real-time thread; NAM/dsp.h:97,163), so
+// the first buffer of a session costs what every first buffer of a launch costs instead of ~7 ms of allocations (256 streams).
+int persist_prepare(nam_hip_batch* b)
 {
   PersistSession& ps = b->ps;
-  const int n = b->n_streams; // (a session holds every stream of the batch)
-  if (!ps.d_ring)
-  {
+  if (ps.d_ring)
+    return NAM_HIP_OK;
     ps.host_store_ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ps.d_ring), (kPRing + kPRingTail) * sizeof(unsigned long long),
                                              hipDeviceMallocFinegrained) == hipSuccess;
     if (!ps.host_store_ok)
@@ -1347,10 +1366,30 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     NAM_HIP_CHECK(hipMemset(ps.d_cons, 0, (size_t)b->n_streams * sizeof(unsigned)));
     std::memset(ps.h_words, 0, 2 * (size_t)b->n_streams * sizeof(unsigned));
     ps.seq = 0; // (sequence numbers run on across sessions — no ring slot needs clearing — until they are rebased, below)
+    ps.burst_start = 0;
     if (const char* e = std::getenv("NAM_HIP_PERSIST_REBASE_AT"))
       ps.rebase_at = (unsigned)std::max(1l, std::atol(e));
     if (const char* e = std::getenv("NAM_HIP_PERSIST_TIMEOUT_MS"))
       ps.timeout_ms = std::max(1l, std::atol(e));
+  {
+    // a session of the headline kernel may start its low-latency sibling later (short_bursts): its code object is loaded now,
+    // not at the switch (~1.6 ms on first use) — both output forms, the window is not known yet
+    const WidthGroup& g0 = b->groups[b->model->full_width];
+    if (g0.plan->arch == ARCH_WAVENET && g0.plan->a1.valid && g0.plan->a1.p2_ok && q_runs(b, *g0.plan))
+      for (int oh = 0; oh < 2; oh++)
+        NAM_HIP_CHECK(preload_a1_p4_session(g0.plan->a1.p2_c0, g0.plan->a1.p2_c1, g0.plan->a1.arr[0].act, oh != 0));
+  }
+  return NAM_HIP_OK;
+}
+
+int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride)
+{
+  PersistSession& ps = b->ps;
+  const int n = b->n_streams; // (a session holds every stream of the batch)
+  {
+    const int rc = persist_prepare(b); // (no-op when set_persistent / Reset have done it)
+    if (rc != NAM_HIP_OK)
+      return rc;
   }
   if (ps.seq >= ps.rebase_at)
   {
@@ -1369,6 +1408,7 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
       ps.h_words[b->n_streams + w] = 0x80000000u;
     }
     ps.seq = 0;
+    ps.burst_start = 0;
     ps.flushed = 0;
     ps.flushed_valid = true;
     ps.outstanding = false;
@@ -2350,6 +2390,12 @@ int nam_hip_batch_reset(nam_hip_batch* batch, int prewarm)
       return rc;
   }
   NAM_HIP_CHECK(hipStreamSynchronize(batch->stream));
+  if (batch->ps.enabled && persist_eligible(batch)) // (a session's window-independent resources: see nam_hip_batch_set_persistent)
+  {
+    const int rc = persist_prepare(batch);
+    if (rc != NAM_HIP_OK)
+      return rc;
+  }
   return NAM_HIP_OK;
 }
 
@@ -2679,7 +2725,17 @@ int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable)
       return rc;
   }
   batch->ps.enabled = enable != 0;
-  return (batch->ps.enabled && persist_eligible(batch)) ? 1 : 0;
+  const bool eligible = batch->ps.enabled && persist_eligible(batch);
+  if (eligible)
+  {
+    // this call and Reset are the non-real-time side of the contract (NAM/dsp.h:163): the session's ring, words, stream and the
+    // blocking entry points' host windows are allocated here, so that no process call ever allocates (the first used to: ~7 ms)
+    const int rc = persist_prepare(batch);
+    if (rc != NAM_HIP_OK)
+      return rc;
+    (void)host_windows(batch, 1, batch->in_bar, batch->h_out_map, batch->d_out_map, batch->map_failed); // (failure: the copying path serves host buffers)
+  }
+  return eligible ? 1 : 0;
 }
 
 int nam_hip_batch_flush(nam_hip_batch* batch, void* hip_stream)
