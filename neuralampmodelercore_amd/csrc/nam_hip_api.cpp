@@ -407,7 +407,7 @@ int pick_kernel(const nam_hip_batch* b, const WidthGroup& g)
 enum PersistKind : int
 {
   PERSIST_NONE = -1,
-  PERSIST_A1_P2 = 0, // nam_a1_p4_kernel (nam_a1_p2_kernel with NAM_HIP_NO_PIPE=1): one workgroup (most of a CU's LDS) per stream
+  PERSIST_A1_P2 = 0, // nam_a1_q_kernel / nam_a1_p4_kernel (nam_a1_p2_kernel with NAM_HIP_MAX_STAGES=1): one workgroup (most of a CU's LDS) per stream
   PERSIST_WN_REG = 1, // nam_wn_reg_kernel: one wavefront per stream
   PERSIST_LSTM_ROW = 2, // nam_lstm_row_kernel: one wavefront per four streams
   PERSIST_LSTM_WIDE = 3, // nam_lstm_wide_kernel: one wavefront per stream
