@@ -194,6 +194,7 @@ struct PersistSession
   unsigned bursts[3] = {~0u, ~0u, ~0u};
   unsigned burst_start = 0; // `seq` at the last whole flush
   bool short_bursts() const { return bursts[0] <= 4u && bursts[1] <= 4u && bursts[2] <= 4u; }
+  bool one_buffer_bursts() const { return bursts[0] == 1u && bursts[1] == 1u && bursts[2] == 1u; } // (nam_wn_reg_kernel: one wave per stream then)
   hipEvent_t retired = nullptr; // the completion signal of the session's latest launch (kernels.h: nam_launch), recorded by the dispatch itself
   bool cmd_done_published = false; // the running launch stores p_cmd_done behind every command's results (A1Args::p_out_host == 2); p_prog stays ring bookkeeping every 16 commands
 };
@@ -585,7 +586,9 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   // launch holds more than one buffer and the chip has the SIMDs for it — config 4's 512 streams become 1,024
   // wavefronts, 256 streams too
   int stages = 1;
-  if (!b->no_pipe && !b->one_buffer_call && (b->ps_launching || n_frames > kBlock))
+  // (a session whose caller flushes after EVERY buffer is a series of one-buffer calls: nothing for a pipeline to overlap)
+  const bool one_buffer_bursts = b->ps_launching && !b->pipe_session && b->ps.one_buffer_bursts();
+  if (!b->no_pipe && !b->one_buffer_call && !one_buffer_bursts && (b->ps_launching || n_frames > kBlock))
   {
     // the launch's relative duration with nst waves per stream: a workgroup is nst waves at one wave per SIMD plus its LDS
     // image (and the queues), the workgroups beyond what the chip holds run in later turns (persist_kind), and a stream's
