@@ -2,7 +2,11 @@
 shapes are outside nam_wn_reg_kernel's ahead-of-time tables get the kernel compiled for them here, and the code objects
 land in neuralampmodelercore_amd/lib/jit/ — next to the library, so they travel with it (the GPU box then finds them by
 hash instead of compiling). Run by __graft_entry__.build(). --prune: delete cache files no load of this run asked for
-(code objects of older kernel sources)."""
+(code objects of older kernel sources).
+
+Deployment: `python tools/warm_jit_cache.py --only path/to/a.nam path/to/b.nam ...` on a machine WITH hipcc (no GPU needed) builds the
+code objects of exactly those models (both tanh modes) into lib/jit/ (or $NAM_HIP_JIT_CACHE); ship that directory with the library and
+the serving hosts need neither a compiler nor the kernel sources ("Kernel selection")."""
 import glob, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -13,7 +17,16 @@ import make_synthetic_models as msm
 def main():
     t0 = time.time()
     n = acc = 0
-    cache = os.path.join(ROOT, "neuralampmodelercore_amd", "lib", "jit")
+    cache = os.environ.get("NAM_HIP_JIT_CACHE") or os.path.join(ROOT, "neuralampmodelercore_amd", "lib", "jit")
+    if "--only" in sys.argv:  # deployment: exactly the models named on the command line
+        paths = [a for a in sys.argv[sys.argv.index("--only") + 1:] if not a.startswith("--")]
+        for p in paths:
+            for ft in (False, True):
+                m = nam.get_dsp(p, fast_tanh=ft)
+                failed = bool(m.info.has_a1_kernel & 32)
+                print(f"{p} fast_tanh={ft}: nam_wn_reg_kernel {'compiled for its shapes / built in' if (m.info.has_a1_kernel & 16) and not failed else 'not used' if not failed else 'COMPILE FAILED (see stderr)'}")
+        print(f"warm_jit_cache: {len(paths)} models, {len(glob.glob(os.path.join(cache, '*.hsaco')))} code objects in {cache}")
+        return
     stamp = time.time() - 1.0  # code objects a load below neither built nor found are stale (their sources changed): pruned
     for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "models", "*.nam"))):
         for ft in (False, True):
