@@ -364,13 +364,22 @@ class HipEngine:
         return e0.elapsed_time(e1)
 
     def sync(self):
-        if self.persistent:
-            # every submitted buffer consumed and visible; the session's launch leaves by itself once the ring is empty,
-            # so the contract's device-wide synchronize below does not block on it (the next step's doorbell starts a
-            # launch again — inside the timed region, where it belongs)
+        # The contract's device-wide synchronize FIRST, the session's flush behind it. Every command of the region is in the ring
+        # by now (host stores, fenced) and the session's launch leaves by itself once it has drained the ring, so the synchronize
+        # returns when the region's work is done — and, called while the launch is still running, its marker is already queued
+        # behind the launch: it returns ~2 us after the launch retires. Called AFTER a flush that has polled the completion words
+        # (round 4's order) the same synchronize pushes its marker through an idle queue: 11 us for nothing
+        # (tools/src/sync_tail.hip, profiles/r05/sync_tail.txt: launch -> synchronized 120.5 vs 129.9 us). The flush then finds
+        # every workgroup's count published (it would start the launch again, and wait for it, had a command been missed).
+        if self.persistent and os.environ.get("NAM_BENCH_FLUSH_FIRST") == "1":  # (round 4's order, kept for same-box A/B runs)
             self.batch.flush(self.stream.cuda_stream)
             self.t_flushed = time.perf_counter()
+            self.torch.cuda.synchronize(self.dev)
+            return
         self.torch.cuda.synchronize(self.dev)
+        if self.persistent:
+            self.batch.flush(self.stream.cuda_stream)
+            self.t_flushed = time.perf_counter()
 
     def kernel_name(self):
         return self.batch.kernel_name()
@@ -1034,8 +1043,8 @@ def main():
                             "ms_per_step_max": round(regions[order[-1]]["wall_s"] * 1e3 / K, 6)},
             "host_enqueue_us_per_step": round(med["enqueue_s"] / K * 1e6, 2),
             "region_us": {"enqueued": round(med["enqueue_s"] * 1e6, 1),
-                          "results_visible_to_host": None if med["flushed_s"] is None else round(med["flushed_s"] * 1e6, 1),
-                          "after_device_synchronize": round(med["wall_s"] * 1e6, 1)},
+                          "synchronized_and_flushed": None if med["flushed_s"] is None else round(med["flushed_s"] * 1e6, 1),
+                          "end_of_region": round(med["wall_s"] * 1e6, 1)},
             "roofline": roofline,
             "gpu_ms_total": round(gpu_s_med * 1e3, 3),
             "latency_us": latency,

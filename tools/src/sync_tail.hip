@@ -43,7 +43,7 @@ int main()
   hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   unsigned tag = 0;
   for (int mb : {0, 20})
-    for (int mode = 0; mode < 6; mode++)
+    for (int mode = 0; mode < 8; mode++)
     {
       std::vector<double> seen, done;
       for (int rep = 0; rep < 60; rep++)
@@ -51,18 +51,19 @@ int main()
         tag++;
         const long n_per_wg = (long)mb * (1l << 20) / 4 / wgs;
         const double t0 = now_us();
-        if (mode >= 2)
+        if (mode >= 2 && mode < 6)
           hipExtLaunchKernelGGL(k, dim3(wgs), dim3(1024), 0, s, nullptr, ev, 0, buf, n_per_wg, d_flag, tag, 10000ll);
         else
           hipLaunchKernelGGL(k, dim3(wgs), dim3(1024), 0, s, buf, n_per_wg, d_flag, tag, 10000ll);
-        for (;;)
-        {
-          bool all = true;
-          for (int w = 0; w < wgs && all; w++)
-            all = __atomic_load_n(&h_flag[w], __ATOMIC_ACQUIRE) == tag;
-          if (all)
-            break;
-        }
+        if (mode < 6) // (modes 6, 7: synchronize at once, the marker queues up behind the running kernel)
+          for (;;)
+          {
+            bool all = true;
+            for (int w = 0; w < wgs && all; w++)
+              all = __atomic_load_n(&h_flag[w], __ATOMIC_ACQUIRE) == tag;
+            if (all)
+              break;
+          }
         const double t1 = now_us();
         if (mode == 0)
           hipDeviceSynchronize();
@@ -77,11 +78,15 @@ int main()
           hipEventSynchronize(ev);
           hipDeviceSynchronize(); // what a host that fences per burst does behind nam_hip_batch_flush
         }
-        else
+        else if (mode == 5)
         {
           hipEventSynchronize(ev);
           hipStreamSynchronize(s);
         }
+        else if (mode == 6)
+          hipDeviceSynchronize();
+        else
+          hipStreamSynchronize(s);
         const double t2 = now_us();
         if (rep >= 10)
         {
@@ -91,10 +96,15 @@ int main()
       }
       std::sort(seen.begin(), seen.end());
       std::sort(done.begin(), done.end());
-      const char* names[6] = {"plain + hipDeviceSynchronize", "plain + hipStreamSynchronize", "ext stop event + hipEventSynchronize", "ext stop event + hipStreamQuery spin",
-                              "ext stop event + EventSync + DeviceSync", "ext stop event + EventSync + StreamSync"};
-      printf("%2d MB dirtied, %-40s launch -> flags visible %7.2f us (median), flags visible -> synchronized %6.2f us (median; min %5.2f, p90 %5.2f)\n", mb, names[mode],
-             seen[seen.size() / 2], done[done.size() / 2], done[0], done[done.size() * 9 / 10]);
+      const char* names[8] = {"plain + hipDeviceSynchronize", "plain + hipStreamSynchronize", "ext stop event + hipEventSynchronize", "ext stop event + hipStreamQuery spin",
+                              "ext stop event + EventSync + DeviceSync", "ext stop event + EventSync + StreamSync",
+                              "DeviceSync AT ONCE (no polling first)", "StreamSync AT ONCE (no polling first)"};
+      std::vector<double> tot(seen.size());
+      for (size_t i = 0; i < seen.size(); i++)
+        tot[i] = seen[i] + done[i];
+      std::sort(tot.begin(), tot.end());
+      printf("%2d MB dirtied, %-40s launch -> flags visible %7.2f us (median), flags visible -> synchronized %6.2f us (median; min %5.2f, p90 %5.2f); launch -> synchronized %7.2f\n", mb, names[mode],
+             seen[seen.size() / 2], done[done.size() / 2], done[0], done[done.size() * 9 / 10], tot[tot.size() / 2]);
     }
   return 0;
 }
