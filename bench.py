@@ -517,7 +517,7 @@ def compact_line(out: dict, full_path) -> dict:
     names only. Everything else this file measures (every region's time, prose notes, the other configurations' own
     rooflines, host_io by buffer size) is in the full record: `full_path` (gpurun_out/bench_full.json), or --full-line."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "finite", "max_abs_err_vs_oracle")
+            "dtype", "data", "finite", "max_abs_err_vs_oracle", "parity_per_rank", "parity_streams_checked")
     line = {k: out[k] for k in keep if k in out}
     c = out.get("config") or {}
     line["config"] = {k: c[k] for k in ("workload", "baseline_config", "streams_per_gpu", "block", "launch", "kernel",
@@ -544,9 +544,9 @@ def compact_line(out: dict, full_path) -> dict:
         line["latency_us"] = {k: out["latency_us"].get(k) for k in ("kernel", "min", "p50", "p99", "p99_9")}
     if out.get("resident_launch"):
         line["resident_launch"] = {k: out["resident_launch"].get(k) for k in ("value", "ms_per_step")}
-    for k in ("zeros_input", "fast_tanh_off", "fast_tanh_on"):
+    for k in ("zeros_input", "fast_tanh_off", "fast_tanh_on", "wav_input"):
         if isinstance(out.get(k), dict):
-            line[k] = {q: out[k].get(q) for q in ("value", "ms_per_step", "kernel", "max_abs_err_vs_oracle")}
+            line[k] = {q: out[k].get(q) for q in ("value", "ms_per_step", "kernel", "max_abs_err_vs_oracle", "error") if q in out[k]}
     if isinstance(out.get("steady_state"), dict):
         line["steady_state"] = {k: out["steady_state"].get(k) for k in ("value", "ms_per_step", "steps_per_region", "max_abs_err_vs_oracle", "floor_frac", "compute_frac")}
     if isinstance(out.get("other_configs"), dict):
@@ -559,7 +559,7 @@ def compact_line(out: dict, full_path) -> dict:
         line["parity_detail"] = out["parity_detail"]
     line["full_record"] = full_path
     # a guard, not a plan: shed the optional blocks (least important first) should the line ever outgrow the limit
-    for k in ("host_io", "zeros_input", "resident_launch", "latency_us", "region_us", "repetitions", "other_configs"):
+    for k in ("host_io", "wav_input", "zeros_input", "resident_launch", "latency_us", "region_us", "repetitions", "other_configs"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(k, None)
@@ -578,6 +578,49 @@ def write_full_record(out: dict):
         except OSError:
             continue
     return None
+
+
+def wav_fidelity_run(fresh_engine, model, n_streams, block, dev, oracle_err, fast_tanh, torch, np, seconds=10.0, passes=10):
+    """SURVEY.md 8(d), config 2's input recipe: see the call site. The whole first pass of stream 0 (the WAV, looped: 10 s) and the
+    first 2,560 frames of the last stream are checked against the oracle; the passes are timed like the headline's regions
+    (fence, K steps, fence) with K = every 64-frame buffer of the 10 s."""
+    from signals import read_wav_mono24, two_tone
+    wav, sr = read_wav_mono24(os.path.join(ROOT, "tests", "golden", "audio", "input.wav"))
+    assert int(sr) == int(SR)
+    steps = int(np.ceil(seconds * SR / block))
+    T = steps * block
+    bank = np.empty((n_streams, T), dtype=np.float32)
+    bank[0] = np.tile(wav, T // len(wav) + 1)[:T]
+    for s_ in range(1, n_streams):
+        bank[s_] = two_tone(T, 1.0 + s_ / n_streams)  # (0.25 + 0.10 = the recipe's 0.35 peak)
+    xw = torch.from_numpy(bank[:, None, :]).to(dev)
+    yw = torch.zeros_like(xw)
+    e = fresh_engine(model)
+    e.bind(xw, yw)
+    ts = []
+    err = None
+    for p_ in range(passes + 1):  # (the first pass is untimed: it is the one checked)
+        e.sync()
+        t0 = time.perf_counter()
+        e.run_steps(0, steps, "block")
+        e.sync()
+        if p_ == 0:
+            rows = [0, n_streams - 1]
+            got0 = yw[0, 0].cpu().numpy()
+            gotl = yw[n_streams - 1, 0, :2560].cpu().numpy()
+            err = max(oracle_err(fast_tanh, bank[None, 0:1, :], got0[None], [0]),
+                      oracle_err(fast_tanh, bank[None, n_streams - 1:n_streams, :2560], gotl[None], [n_streams - 1]))
+        else:
+            ts.append(time.perf_counter() - t0)
+    kname = e.kernel_name()
+    e.close()
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(n_streams * T / SR / med, 1), "ms_per_step": round(med / steps * 1e3, 6), "kernel": kname,
+            "seconds_per_stream": round(T / SR, 2), "steps_per_pass": steps, "passes": passes, "max_abs_err_vs_oracle": err,
+            "checked": "stream 0 = input.wav looped, all 10 s; last stream, 2,560 frames",
+            "note": "SURVEY 8(d) input recipe (stream 0 = example_audio/input.wav looped, the others two-tones at (1 + s/n) x 220 / 1230 Hz, "
+                    "0.35 peak), median of the passes; a fidelity run beside `value`, not `value`"}
 
 
 def main():
@@ -738,6 +781,9 @@ def main():
     raw = []
     got_dev = None
     n_chk = min(T, 64 * 40)
+    # EVERY rank checks itself (each GPU renders its own shard, NAM/wavenet/model.cpp:822-910 per stream): the first
+    # and the last stream it owns, against the oracle, after timing; the line carries the MAX over ranks and every rank's own figure
+    chk_rows = sorted({0, n_local - 1}) if n_local > 0 else []
     pers = getattr(engine, "persistent", False)
     # In front of them P untimed repetitions of exactly the same shape: the device's clocks settle over tens of milliseconds
     # of THIS duty cycle (regions of the driver's 20-step shape run 9.0 -> 9.5 -> 8.3 us per step over the first 60 ms,
@@ -755,7 +801,7 @@ def main():
                 # repetition's session launch on its own: WAIT for the copy, or a slow first launch of the copy kernel (module
                 # load on some boxes) lets the second pass overwrite what it is about to read (round 5: three runs in seventy
                 # read max-abs 0.562 = exactly |first pass - second pass| of the checked stream)
-                got_dev = y[0, 0, :n_chk].clone()
+                got_dev = y[chk_rows, 0, :n_chk].clone()
                 if not args.dry_run:
                     torch.cuda.synchronize(dev)
             continue
@@ -774,7 +820,7 @@ def main():
         gpu_s = (engine.t_flushed - t0) if pers else engine.elapsed_ms(e0, e1) / 1e3
         raw.append((wall, gpu_s, t_enq))
         if rep == 0 and P == 0:
-            got_dev = y[0, 0, :n_chk].clone()  # parity sample: blocks 0..W+K of the FIRST pass over the window
+            got_dev = y[chk_rows, 0, :n_chk].clone()  # parity sample: blocks 0..W+K of the FIRST pass over the window
             if not args.dry_run:
                 torch.cuda.synchronize(dev)  # (see above: the copy must not race the next repetition)
     red = reduce_max([v for r_ in raw for v in r_[:2]])
@@ -842,31 +888,65 @@ def main():
 
     parity = None
     parity_detail = None
-    if rank == 0 and args.check and not args.dry_run:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import nam_oracle
-        ref = nam_oracle.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
-        if slim_mix:
-            ref.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[0]]])
-        ref.Reset(SR, block)
-        sig = bank[mine[0], :n_chk]
-        r = ref.process_stream(np.repeat(sig[None, :], ic, axis=0) if ic > 1 else sig, block)[0]  # (every input channel carries the signal)
-        got_np = got_dev.cpu().numpy()
-        parity = float(np.max(np.abs(r - got_np)))
-        if parity > 1e-3:
-            # a wrong result is a finding, not a number: say where (which frames of the checked stream, whole buffers of zeros?)
-            bad = np.nonzero(np.abs(r - got_np) > 1e-3)[0]
-            blocks = sorted(set((bad // block).tolist()))
-            parity_detail = {"bad_frames": int(bad.size), "first": int(bad[0]), "last": int(bad[-1]), "blocks": blocks[:16],
-                             "n_blocks": len(blocks),
-                             "zero_blocks": [int(b_) for b_ in blocks[:16] if not np.any(got_np[b_ * block:(b_ + 1) * block])]}
-            print("bench.py: PARITY FAILURE " + json.dumps(parity_detail), file=sys.stderr, flush=True)
-    elif rank == 0 and args.dry_run:
-        parity = float(torch.max(torch.abs(got_dev - 0.5 * x[0, 0, :n_chk])))
+    parity_per_rank = None
+    parity_streams = [int(mine[i]) for i in chk_rows]  # (global stream numbers this rank checked)
+    if args.check and chk_rows:
+        if args.dry_run:
+            parity = float(torch.max(torch.abs(got_dev - 0.5 * x[chk_rows, 0, :n_chk])))
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import nam_oracle
+            got_np = got_dev.cpu().numpy()
+            sig_np = x[chk_rows, :, :n_chk].cpu().numpy()  # this rank's OWN rows of the scattered bank (every input channel)
+            parity = 0.0
+            for j, i in enumerate(chk_rows):
+                ref = nam_oracle.get_dsp(model_path, fast_tanh=bool(args.fast_tanh))
+                if slim_mix:
+                    ref.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[i]]])
+                ref.Reset(SR, block)
+                r = ref.process_stream(sig_np[j] if ic > 1 else sig_np[j, 0], block)[0]
+                err = float(np.max(np.abs(r - got_np[j])))
+                parity = max(parity, err)
+                if err > 1e-3 and parity_detail is None:
+                    # a wrong result is a finding, not a number: say where (which frames of the checked stream, whole buffers of zeros?)
+                    bad = np.nonzero(np.abs(r - got_np[j]) > 1e-3)[0]
+                    blocks = sorted(set((bad // block).tolist()))
+                    parity_detail = {"rank": rank, "stream": int(mine[i]), "bad_frames": int(bad.size), "first": int(bad[0]), "last": int(bad[-1]),
+                                     "blocks": blocks[:16], "n_blocks": len(blocks),
+                                     "zero_blocks": [int(b_) for b_ in blocks[:16] if not np.any(got_np[j, b_ * block:(b_ + 1) * block])]}
+                    print("bench.py: PARITY FAILURE " + json.dumps(parity_detail), file=sys.stderr, flush=True)
+    if distributed:
+        # every rank's own figure travels to rank 0 (all_gather of one double per rank; -1 = that rank checked nothing)
+        mine_t = torch.tensor([parity if parity is not None else -1.0], dtype=torch.float64, device=dev)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        parity_per_rank = [float(t_[0]) for t_ in all_t]
+        checked = [v for v in parity_per_rank if v >= 0.0]
+        parity = max(checked) if checked else None
+        streams_t = torch.tensor((parity_streams + [-1, -1])[:2], dtype=torch.int64, device=dev)
+        all_s = [torch.zeros_like(streams_t) for _ in range(world)]
+        dist.all_gather(all_s, streams_t)
+        parity_streams = sorted({int(v) for t_ in all_s for v in t_ if int(v) >= 0})
+    elif parity is not None:
+        parity_per_rank = [parity]
 
     # side runs on rank 0 (N = 1): fast_tanh OFF and an all-zeros input (benchmodel's own input, tools/benchmodel.cpp:103-132)
     side = {}
     if rank == 0 and world == 1 and not args.no_side_runs and not args.dry_run:
+        def oracle_err(fast_tanh_flag, sig_rows, got_rows, row_ids):
+            """max |oracle - got| over the given local streams (fresh oracle each: Reset + prewarm, the signal from its first frame)"""
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import nam_oracle
+            worst = 0.0
+            for j, i in enumerate(row_ids):
+                ref2 = nam_oracle.get_dsp(model_path, fast_tanh=fast_tanh_flag)
+                if slim_mix:
+                    ref2.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[i]]])
+                ref2.Reset(SR, block)
+                r2 = ref2.process_stream(sig_rows[j] if ic > 1 else sig_rows[j, 0], block)[0]
+                worst = max(worst, float(np.max(np.abs(r2 - got_rows[j]))))
+            return worst
+
         def quick(engine2, xin, check_fast_tanh=None):
             # the headline's own protocol on another engine / input: the same launch mode (persistent block mode when the
             # headline runs it), warm-up steps, fence, a region of exactly K steps, fence; untimed regions of the same
@@ -875,18 +955,11 @@ def main():
             err = None
             if check_fast_tanh is not None and args.check:
                 # a fresh engine (Reset + prewarm, nothing run yet): its first pass over the window against the oracle with the
-                # same activation setting — the session-mode instantiation of the kernel with libm tanh is CHECKED, not only timed
-                sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                import nam_oracle
+                # same activation setting and the same input — the session-mode instantiation of the kernel with libm tanh, and
+                # benchmodel's own all-zeros input (tools/benchmodel.cpp:103-132), are CHECKED, not only timed
                 engine2.run_steps(0, W + K, args.launch)
                 engine2.sync()
-                ref2 = nam_oracle.get_dsp(model_path, fast_tanh=check_fast_tanh)
-                if slim_mix:
-                    ref2.SetSlimmableSize(SLIM_RATIOS[classes_global[mine[0]]])
-                ref2.Reset(SR, block)
-                sig2 = bank[mine[0], :n_chk]
-                r2 = ref2.process_stream(np.repeat(sig2[None, :], ic, axis=0) if ic > 1 else sig2, block)[0]
-                err = float(np.max(np.abs(r2 - y[0, 0, :n_chk].cpu().numpy())))
+                err = oracle_err(check_fast_tanh, xin[chk_rows, :, :n_chk].cpu().numpy(), y[chk_rows, 0, :n_chk].cpu().numpy(), chk_rows)
             ts = []
             n_pre, n_rep = min(P, 60), min(R, 21)
             for rep in range(-n_pre, n_rep):
@@ -901,13 +974,25 @@ def main():
             return {"value": round(n_streams * block * K / SR / ts[len(ts) // 2], 1), "ms_per_step": round(ts[len(ts) // 2] / K * 1e3, 6),
                     "kernel": engine2.kernel_name(), "persistent_block_mode": bool(getattr(engine2, "persistent", False)),
                     "regions": len(ts), "untimed_in_front": n_pre, "max_abs_err_vs_oracle": err}
-        side["zeros_input"] = quick(engine, torch.zeros_like(x))
-        engine.bind(x, y)
+
+        def fresh_engine(m_):
+            return HipEngine(nam, torch, m_, n_streams, block, local_rank, args.kernel, local_classes,
+                             persistent=bool(args.persistent) and args.launch == "block")
+        e0 = fresh_engine(model)
+        side["zeros_input"] = quick(e0, torch.zeros_like(x), check_fast_tanh=bool(args.fast_tanh))
+        e0.close()
         m2 = nam.get_dsp(model_path, fast_tanh=not bool(args.fast_tanh))
-        e2 = HipEngine(nam, torch, m2, n_streams, block, local_rank, args.kernel, local_classes,
-                       persistent=bool(args.persistent) and args.launch == "block")
+        e2 = fresh_engine(m2)
         side["fast_tanh_off" if args.fast_tanh else "fast_tanh_on"] = quick(e2, x, check_fast_tanh=not bool(args.fast_tanh))
         e2.close()
+        # SURVEY 8(d)'s input recipe as a fidelity run (never `value`; timing is data-independent): stream 0 = example_audio/input.wav
+        # looped, stream s = the two-tone at (1 + s / n) x the frequencies and 0.35 peak, >= 10 s of audio per stream after Reset +
+        # prewarm, 10 passes, the median (protocol of tools/benchmark_wavenet_a1.sh:10,75-95), buffer = 64 in the headline's launch mode
+        if args.launch == "block" and ic == 1:
+            try:
+                side["wav_input"] = wav_fidelity_run(fresh_engine, model, n_streams, block, dev, oracle_err, bool(args.fast_tanh), torch, np)
+            except Exception as e:  # noqa: BLE001  (a side figure must not take the line with it)
+                side["wav_input"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         macs = model_macs(model_path)
@@ -1053,6 +1138,8 @@ def main():
                 "note": "same K blocks as one launch walking device-resident audio (offline re-amp shape); not `value`"}),
             "finite": finite and gathered_ok,
             "max_abs_err_vs_oracle": parity,
+            "parity_per_rank": parity_per_rank,
+            "parity_streams_checked": parity_streams,
         }
         if parity_detail is not None:
             out["parity_detail"] = parity_detail

@@ -850,7 +850,11 @@ hipError_t launch_kq(const A1Args& a, int n_blocks, int act, hipStream_t stream)
   if (act == ACT_RELU)
   {
     A1Args r = a;
-    r.act_p0 = 0.0f; // max(v, 0 v): -0 where ReLU gives +0 — equal in every sum and product behind it
+    // max(v, 0 v): -0 where ReLU gives +0 — equal in every sum and product behind it — for every FINITE v. Non-finite values
+    // differ from the reference's `x > 0 ? x : 0` (NAM/activations.h:59-66): v = -inf gives 0 * v = NaN and the max returns -inf
+    // (reference: 0); v = NaN stays NaN (reference: 0). A model whose pre-activations are non-finite has left the range every
+    // parity statement of this repository is made for; the finite range is bit-for-bit the LeakyReLU path.
+    r.act_p0 = 0.0f;
     return launch_kq_act<kq::kActLeakyMax>(r, n_blocks, stream);
   }
   return launch_kq_act<kq::kActLeakyMax>(a, n_blocks, stream);

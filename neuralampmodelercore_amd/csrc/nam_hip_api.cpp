@@ -179,6 +179,8 @@ struct PersistSession
   // workgroup stands at exactly `seq` and nothing is in flight — rebases them to 0 once they pass this mark
   // (NAM_HIP_PERSIST_REBASE_AT overrides it: tests)
   unsigned rebase_at = 0x40000000u;
+  bool prepared = false; // persist_prepare ran to its end (every window-independent resource is there)
+  bool rebase_pending = false; // persist_submit ended the session because the next buffer would cross the rebase mark: persist_start renumbers
   long timeout_ms = 20000; // a resident launch that makes no progress for this long is a device failure (NAM_HIP_PERSIST_TIMEOUT_MS)
   // developer statistics (NAM_HIP_SESSION_STATS=1: printed when the batch is destroyed)
   unsigned long long n_launches = 0, n_host_doorbells = 0, n_stream_doorbells = 0, n_starts = 0, n_flush_relaunches = 0;
@@ -453,7 +455,7 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
     switch (persist_kind(b)) // persistent block mode
     {
       case PERSIST_A1_P2: // (what the NEXT launch of the session starts: PersistSession::short_bursts)
-        return b->no_pipe ? "nam_a1_p2_kernel" : (q_runs(b, p) && !(b->ps.active && !b->pipe_session && b->ps.short_bursts())) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel";
+        return b->no_pipe ? "nam_a1_p2_kernel" : (q_runs(b, p) && !(!b->pipe_session && b->ps.short_bursts())) ? "nam_a1_q_kernel" : "nam_a1_p4_kernel"; // (launch_group's own predicate: the burst history outlives a session)
       case PERSIST_KQ: return "nam_kq_kernel";
       case PERSIST_WN_REG: return "nam_wn_reg_kernel";
       case PERSIST_LSTM_ROW: return "nam_lstm_row_kernel";
@@ -1129,19 +1131,27 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
 // Watchdog of the host's spins on the session's completion words: the resident launch normally answers within
 // microseconds, so the spin itself stays a plain memory poll; every 4,096 polls it looks at the launch's stream — a
 // launch that has ENDED (or failed: a trap in the kernel, a memory fault, a GPU reset) without every workgroup having
-// set its "left" bit will never set it — and at the clock. Returns NAM_HIP_OK to keep spinning, 1 when the launch is
-// known to have ended (the caller re-reads the words once more), or an error.
+// set its "left" bit will never set it —, at the words the workgroups publish (progress every 16 commands, the count
+// when they leave: any change restarts the clock) and at the clock: NAM_HIP_PERSIST_TIMEOUT_MS without ANY workgroup
+// moving is a device failure (tests/test_gpu_tickets.py: test_watchdog_*: a launch kept off the CUs by another process).
+// Returns NAM_HIP_OK to keep spinning, 1 when the launch is known to have ended (the caller re-reads the words once
+// more), or an error.
 struct PersistWatch
 {
   long polls = 0;
+  unsigned long long seen = 0;
   std::chrono::steady_clock::time_point t0{};
   int check(nam_hip_batch* b)
   {
     if ((++polls & 4095) != 0)
       return NAM_HIP_OK;
     const auto now = std::chrono::steady_clock::now();
-    if (polls == 4096)
+    unsigned long long sig = 0;
+    for (int w = 0; w < 2 * b->ps.done_off; w++)
+      sig += __atomic_load_n(&b->ps.h_words[w], __ATOMIC_RELAXED);
+    if (polls == 4096 || sig != seen)
       t0 = now;
+    seen = sig;
     const hipError_t q = hipStreamQuery(b->ps.kstream);
     if (q == hipSuccess)
       return 1;
@@ -1328,11 +1338,28 @@ int persist_stop(nam_hip_batch* b)
 // the low-latency sibling kernel's code object — allocated OUTSIDE the audio path: nam_hip_batch_set_persistent and nam_hip_batch_reset
 // call this (the reference's contract: process() never allocates, Reset / get_dsp run on a non-real-time thread; NAM/dsp.h:97,163), so
 // the first buffer of a session costs what every first buffer of a launch costs instead of ~7 ms of allocations (256 streams).
+void persist_free(nam_hip_batch* b);
+static int persist_prepare_alloc(nam_hip_batch* b);
 int persist_prepare(nam_hip_batch* b)
 {
-  PersistSession& ps = b->ps;
-  if (ps.d_ring)
+  if (b->ps.prepared)
     return NAM_HIP_OK;
+  // all or nothing: a failure half-way (the ring is there, the stream or an event is not) must not look "prepared" to the next
+  // call — it would run a session with a null stream or completion word. Everything allocated so far is released, the mode is
+  // off again (nam_hip_batch_set_persistent / nam_hip_batch_reset report the error; a later call may try again)
+  const int rc = persist_prepare_alloc(b);
+  if (rc != NAM_HIP_OK)
+  {
+    const std::string why = nam_hip_last_error();
+    persist_free(b); // (ps = PersistSession(): enabled = false)
+    return fail(rc, why);
+  }
+  b->ps.prepared = true;
+  return NAM_HIP_OK;
+}
+static int persist_prepare_alloc(nam_hip_batch* b)
+{
+  PersistSession& ps = b->ps;
     ps.host_store_ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ps.d_ring), (kPRing + kPRingTail) * sizeof(unsigned long long),
                                              hipDeviceMallocFinegrained) == hipSuccess;
     if (!ps.host_store_ok)
@@ -1394,8 +1421,9 @@ int persist_start(nam_hip_batch* b, const float* d_in, float* d_out, long stride
     if (rc != NAM_HIP_OK)
       return rc;
   }
-  if (ps.seq >= ps.rebase_at)
+  if (ps.seq >= ps.rebase_at || ps.rebase_pending)
   {
+    ps.rebase_pending = false;
     // a session starts flushed (persist_stop: every workgroup at exactly `seq`, the launch gone): renumber from 0. Stale
     // ring slots carry tags near the old count, which a small count never matches; cleared anyway.
     NAM_HIP_CHECK(hipStreamSynchronize(ps.kstream));
@@ -1475,8 +1503,12 @@ int persist_submit(nam_hip_batch* b, const float* d_in, float* d_out, int n_fram
     if (ps.active)
     {
       const long off_last = (d_in + (n_frames - kBlock)) - ps.in_base;
-      if (ps.seq + (unsigned)(n_frames / kBlock) >= ps.rebase_at || off_last > 0x1fff0000l)
+      const bool past_mark = ps.seq + (unsigned)(n_frames / kBlock) >= ps.rebase_at;
+      if (past_mark || off_last > 0x1fff0000l)
       {
+        // (the session that starts with this buffer renumbers from 0 even if the count itself has not reached the mark yet:
+        // otherwise a buffer of several commands would reach it in mid-buffer and be split after all)
+        ps.rebase_pending = ps.rebase_pending || past_mark;
         const int rc = persist_stop(b);
         if (rc != NAM_HIP_OK)
           return rc;
@@ -1746,7 +1778,7 @@ int build_model(std::shared_ptr<ModelSpec> spec, nam_hip_model** out)
 // memory (float32 rows [stream][channel][max_frames]); in_f32 / in_f64 and out_f32 / out_f64: exactly one of each.
 // The host-mapped windows of the session's blocking (`slots` = 1: nam_hip_batch::in_bar, h_out_map) or ticketed
 // (NAM_HIP_PIPE_SLOTS: pipe_in_bar, pipe_h_out_map) entry points. false: no such memory here (the copying path serves the call).
-bool host_windows(nam_hip_batch* b, int slots, float*& in_bar, float*& h_out_map, float*& d_out_map, bool& failed)
+bool host_windows(nam_hip_batch* b, int slots, float*& in_bar, float*& h_out_map, float*& d_out_map, bool& failed, bool prealloc = false)
 {
   if (failed)
     return false;
@@ -1754,6 +1786,8 @@ bool host_windows(nam_hip_batch* b, int slots, float*& in_bar, float*& h_out_map
     return true;
   const int ic = b->model->spec->in_channels(), oc = b->model->spec->out_channels();
   const size_t pitch = (size_t)b->n_streams * std::max(ic, oc) * b->max_frames; // (one slot; the same for both windows: a command carries ONE offset)
+  if (prealloc && pitch * (size_t)slots * sizeof(float) > ((size_t)64 << 20))
+    return false; // (ahead of any host-buffer call: only when cheap — nothing decided, nothing said)
   if (pitch * (size_t)slots > (size_t)0x1fff0000)
   {
     // the kernels address a session's window through one 2 GB buffer descriptor: windows beyond it would make every buffer a
@@ -2011,7 +2045,7 @@ int nam_hip_version_support(const char* nam_file_version)
 
 const char* nam_hip_version(void)
 {
-  return "nam_hip 0.2.0 gfx950"; // 0.2: nam_hip_load_options::struct_size (0.1 callers: the first 16 bytes are read)
+  return "nam_hip 0.2.1 gfx950"; // 0.2.1: nam_hip_model_info has_a1_kernel bits 2 and 3 always equal (include/nam_hip.h); 0.2: nam_hip_load_options::struct_size (0.1 callers: the first 16 bytes are read)
 }
 
 int nam_hip_model_load(const char* nam_path, int fast_tanh, nam_hip_model** out_model)
@@ -2727,17 +2761,21 @@ int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable)
     if (rc != NAM_HIP_OK)
       return rc;
   }
-  batch->ps.enabled = enable != 0;
-  const bool eligible = batch->ps.enabled && persist_eligible(batch);
+  batch->ps.enabled = false;
+  const bool eligible = enable != 0 && persist_eligible(batch);
   if (eligible)
   {
     // this call and Reset are the non-real-time side of the contract (NAM/dsp.h:163): the session's ring, words, stream and the
     // blocking entry points' host windows are allocated here, so that no process call ever allocates (the first used to: ~7 ms)
     const int rc = persist_prepare(batch);
     if (rc != NAM_HIP_OK)
-      return rc;
-    (void)host_windows(batch, 1, batch->in_bar, batch->h_out_map, batch->d_out_map, batch->map_failed); // (failure: the copying path serves host buffers)
+      return rc; // (the mode stays off: persist_prepare released what it had)
+    // the blocking entry points' host windows too, when they are small (a batch of long buffers that only ever runs
+    // device-resident audio must not pin hundreds of MB for calls it never makes: such a batch allocates them at its first
+    // host-buffer call, if it makes one)
+    (void)host_windows(batch, 1, batch->in_bar, batch->h_out_map, batch->d_out_map, batch->map_failed, /*prealloc=*/true);
   }
+  batch->ps.enabled = enable != 0;
   return eligible ? 1 : 0;
 }
 

@@ -20,6 +20,7 @@ for C in 2 4; do
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(f"config {j['config']['baseline_config']}: {j['n_gpus']} GPUs, {j['value']:,.0f} {j['unit'].split(' ')[0]}, {j['ms_per_step'] * 1e3:.2f} us/step, kernel {j['config']['kernel']}")
+print(f"  parity vs oracle, every rank's first and last stream (global streams {j.get('parity_streams_checked')}): per rank {j.get('parity_per_rank')}, max {j.get('max_abs_err_vs_oracle')}")
 PY
 done
 # the C++ tool: 8 x N short files dealt to N devices, one batch + host thread per device (cpp/NAM/multi_device.h)

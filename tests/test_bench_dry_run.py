@@ -41,6 +41,11 @@ def test_shard_by_class_gives_every_rank_the_same_mix():
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("config,streams", [(5, 6), (2, 5)])
 def test_bench_distributed_branch_world2_gloo(config, streams):
+    from neuralampmodelercore_amd import sharding
+    import bench
+    n_total = 2 * streams
+    classes = [s % len(bench.SLIM_RATIOS) for s in range(n_total)] if bench.CONFIGS[config]["slim_mix"] else [0] * n_total
+    owners = [sharding.shard_by_class(classes, r, 2) for r in range(2)]
     port = _free_port()
     procs = []
     for rank in range(2):
@@ -59,6 +64,10 @@ def test_bench_distributed_branch_world2_gloo(config, streams):
     assert json.loads(json.dumps(line)) == line
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["finite"] is True and line["max_abs_err_vs_oracle"] == 0.0
+    # EVERY rank checks its own first and last stream after timing; the line carries each rank's figure and their MAX
+    assert line["parity_per_rank"] == [0.0, 0.0]
+    first_last = sorted({o for r in range(2) for o in (owners[r][0], owners[r][-1])})
+    assert line["parity_streams_checked"] == first_last
     assert line["repetitions"]["n"] == 3 and line["repetitions"]["ms_per_step_min"] <= line["repetitions"]["ms_per_step_max"]
     assert line["roofline"]["bound"] in ("hbm", "mfma") and line["roofline"]["frac"] is not None
     assert line["value"] > 0 and line["config"]["streams_per_gpu"] == streams
@@ -116,4 +125,5 @@ def test_bench_distributed_branch_on_rccl_one_rank(config, streams):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["finite"] is True
     assert line["max_abs_err_vs_oracle"] <= 5e-5 and line["value"] > 0
+    assert line["parity_per_rank"] == [line["max_abs_err_vs_oracle"]] and len(line["parity_streams_checked"]) == 2
     assert line["config"]["streams_per_gpu"] == streams

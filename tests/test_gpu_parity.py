@@ -672,7 +672,7 @@ def test_headline_config_every_stream_matches_oracle(nam_lib, oracle, n_streams)
         r = ref.process_stream(x[s], block)
         err = float(np.max(np.abs(r - y[s])))
         worst = max(worst, err)
-        assert err <= 5e-5 * max(1.0, float(np.max(np.abs(r)))), (n_streams, s, err)
+        assert err <= 5e-5, (n_streams, s, err)  # ABSOLUTE, as the reference's own bound is written (test_a2_fast.cpp:296-298)
     print(f"headline parity: {n_streams} streams x {n} frames, worst max-abs error {worst:.3e}")
 
 
