@@ -99,8 +99,33 @@ __device__ __forceinline__ void aq_steady_prio()
     __builtin_amdgcn_s_setprio((short)0);
 }
 
+// The prologue's memory requests in the order the launch's first buffer needs them. A stage's prologue is one memory round trip
+// behind the kernel-argument load — 1.7 - 2.5 us when the launch is cold, whatever else is in flight — and 256 workgroups asking
+// for all 21 MB of rings at once make that ~4.5 us for everybody. Stage s holds its requests back by s x NAM_AQ_STAG_SLEEP x 64
+// cycles (0.64 us per stage: the launch's first buffer reaches stage s ~0.8 s us after stage 0 has started), so stage 0 starts
+// on its first sub-block at 2.5 us instead of 4.4 and the other stages' requests land while the buffer is on its way to them
+// (profiles/r06/a1q_variants.txt: first output of a 20-buffer launch 26.6 -> 24.0 us; 0 / 3 / 6 / 12 / 24 / 40 measured).
+#ifndef NAM_AQ_STAG_SLEEP
+#define NAM_AQ_STAG_SLEEP 24
+#endif
+template <int SS>
+__device__ __forceinline__ void aq_stagger()
+{
+#ifdef NAM_AQ_STAG_FIXED
+  if constexpr (SS > 0)
+    __builtin_amdgcn_s_sleep(NAM_AQ_STAG_FIXED);
+#endif
+  if constexpr (SS > 0 && NAM_AQ_STAG_SLEEP > 0)
+  {
+#pragma unroll 1
+    for (int r = 0; r < SS; r++)
+      __builtin_amdgcn_s_sleep(NAM_AQ_STAG_SLEEP);
+  }
+}
+
 namespace aq
 {
+constexpr int kNotReady = -(1 << 20); // a "consumed" word before its stage is ready (any hand-over wait on it blocks)
 constexpr int kNoRow = 1 << 26; // a ring row index no descriptor holds: the access is dropped / returns 0
 constexpr int kRowsMax = 1 << 20; // num_records of the ring descriptors (rows)
 constexpr int far_jobs_before(int s, int job) // HBM-ring jobs of stage s in front of `job`
@@ -175,21 +200,25 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   const int wposv = lane < aq::kRings ? wpos_tbl[lane] : 0; // lane r = write position of ring r at launch
   int* const flags = reinterpret_cast<int*>(lds + aq::kFlagB);
 
-  // ---- the small stages' tiles and every constant -> LDS, once per launch, by every wave ----
-  constexpr int NT = NST * 64;
-  {
-    constexpr int kSrc4 = aq::kBlockFloats / 4; // 16-byte records
-    const f4* __restrict__ src = reinterpret_cast<const f4*>(blob + a.tiles_off);
-#pragma unroll 1
-    for (int i0 = 0; i0 < kSrc4; i0 += 2 * NT)
+  // ---- No workgroup-wide prologue (round 6). Every stage brings in what IT needs — its matrices and constants (registers / its
+  // own part of the weight block in LDS), its resident rings — and tells its producer so through its "consumed" word, which
+  // starts below zero (kNotReady) and is set to 0 when the stage is ready: the producer's ordinary hand-over wait is the
+  // only synchronisation. The launch's first buffer therefore starts when stage 0's 4 KB ring has arrived, not when all
+  // 81 KB of the stream's rings have (first hand-over of stage 0 at ~2 us instead of 5.2: profiles/r06/a1q_timeline_*.txt);
+  // the later stages' requests are in flight meanwhile and have landed long before the buffer reaches them.
+  constexpr int NT = 64;
+  auto copy_block = [&](int first_float, int n_floats) { // this wave's part of the weight block -> LDS as it lies (16-byte records)
+    const f4* __restrict__ src = reinterpret_cast<const f4*>(blob + a.tiles_off + first_float);
+    const int n4 = n_floats / 4;
+    for (int i0 = 0; i0 < n4; i0 += 2 * NT)
     {
-      const f4 t0 = src[min(i0 + tid, kSrc4 - 1)], t1 = src[min(i0 + NT + tid, kSrc4 - 1)];
-      if (i0 + tid < kSrc4)
-        lds_st4(lds, (unsigned)aq::kWB + (unsigned)(i0 + tid) * 16u, t0);
-      if (i0 + NT + tid < kSrc4)
-        lds_st4(lds, (unsigned)aq::kWB + (unsigned)(i0 + NT + tid) * 16u, t1);
+      const f4 t0 = src[min(i0 + lane, n4 - 1)], t1 = src[min(i0 + NT + lane, n4 - 1)];
+      if (i0 + lane < n4)
+        lds_st4(lds, (unsigned)aq::kWB + (unsigned)(first_float * 4) + (unsigned)(i0 + lane) * 16u, t0);
+      if (i0 + NT + lane < n4)
+        lds_st4(lds, (unsigned)aq::kWB + (unsigned)(first_float * 4) + (unsigned)(i0 + NT + lane) * 16u, t1);
     }
-  }
+  };
 
   // The stream's rings through two descriptors with the row pitch as the stride (64 / 32 bytes): an access names its row by
   // index and its ring by the scalar offset; kNoRow drops it.
@@ -312,8 +341,9 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
   unsigned na = 0; // PERSIST, stage 0: commands finished by this stage (its current command carries tag na + 1)
   unsigned done = 0; // PERSIST: commands consumed before this launch (+ finished by the last stage during it)
   unsigned boff0 = 0; // stage 0: byte offset of its first buffer
-  if (tid < 64)
-    flags[tid] = 0;
+  if (tid < 64) // words [16 + 2 b + 1], b = 0 .. 14: "consumed" across boundary b — below zero until the consumer is ready
+    flags[tid] = (tid >= 17 && tid < 17 + 2 * (NST - 1) && (tid & 1)) ? aq::kNotReady : 0;
+  lds_barrier(); // the ONLY workgroup-wide rendezvous of a launch's start: the words are in place
   if constexpr (PERSIST)
   {
     const bool by_value = a.p_seq0 >= 0;
@@ -322,7 +352,6 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     unsigned lo = (unsigned)a.p_cmd0;
     if (!by_value)
     {
-      lds_barrier(); // (the counters are zero)
       if (wall == 0)
       {
         // started right behind a stream-ordered doorbell on another hardware queue: look for it for a bounded time
@@ -383,6 +412,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     static_assert(aq::is_big(JN) || JN == aq::kJobT, "aq: array 0's last stage hands over to the transition");
     // ---- this stage's weights: registers for the whole launch. Tile q of job j (plan.cpp: build_a1_ws, FULL layout):
     // lane (g, i) holds W[out = i][in = 4 g + s], s = 0 .. 3 — the A operand of k-step s ----
+    aq_stagger<SS>();
     f4 W[NJS][4];
     {
       const f4* __restrict__ tsrc = reinterpret_cast<const f4*>(blob + a.consts_off); // (the p2 tiles: A1Args::consts_off, see launch_a1_q)
@@ -430,17 +460,27 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     float inp = 0.0f; // stage 0: the next buffer's input sample of frame `lane`
     if constexpr (FIRST)
       inp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, frame * 4, uni((int)boff0), kInAux));
-    lds_barrier(); // weights, constants, rings and flags are in place
+    // the layers' constants (bias, mixin, 1x1 bias by channel quad): registers for the whole launch, like the matrices
+    // (same-box A/B, profiles/r04/a1q_variants.txt: 5.63 -> 5.37 us per buffer inside a 200-buffer launch); straight from the
+    // weight block in memory (no other wave's copy to wait for)
+    f4 cst[NJS][3];
+    f4 rech = {0.f, 0.f, 0.f, 0.f}; // stage 0: array 0's rechannel column, this lane's channel quad
+    {
+      const f4* __restrict__ csrc = reinterpret_cast<const f4*>(blob + a.tiles_off + aq::kBigConsts);
+#pragma unroll
+      for (int u = 0; u < NJS; u++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+          cst[u][q] = csrc[(J0 + u) * 16 + q * 4 + g];
+      if constexpr (FIRST)
+        rech = csrc[12 + g];
+    }
+    // this stage is ready: its rings are in LDS (every store of the prologue has been executed), its producer may hand over
+    __builtin_amdgcn_s_waitcnt(0);
+    if constexpr (!FIRST)
+      set_word(cons_b(QIN), 0);
     if constexpr (DBG)
       dbg_t[1] = clock64();
-    // the layers' constants (bias, mixin, 1x1 bias by channel quad): registers for the whole launch, like the matrices
-    // (same-box A/B, profiles/r04/a1q_variants.txt: 5.63 -> 5.37 us per buffer inside a 200-buffer launch)
-    f4 cst[NJS][3];
-#pragma unroll
-    for (int u = 0; u < NJS; u++)
-#pragma unroll
-      for (int q = 0; q < 3; q++)
-        cst[u][q] = lds_ld4(lds, (unsigned)(aq::kWB + (aq::kBigConsts + (J0 + u) * 64) * 4) + (unsigned)q * 64u + g16);
 
     f4 xs, hd;
     float cnd = 0.0f;
@@ -579,7 +619,6 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
         if constexpr (FIRST)
         {
           // array 0's rechannel (1 -> 16, model.cpp:488-490): x = column * input
-          const f4 rech = lds_ld4(lds, (unsigned)(aq::kWB + aq::kBigConsts * 4) + 192u + g16);
           cnd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 * i + n) * 4, __builtin_bit_cast(int, cond)));
           xs = rech * cnd;
           hd = f4{0.f, 0.f, 0.f, 0.f};
@@ -707,6 +746,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     constexpr int QIN = SS - 1, QOUT = SS;
     constexpr int NFAR = aq::far_jobs_before(SS, JM0 + NL);
     static_assert(NL >= 1 && (LAST || aq::is_small(JN)), "aq: small stages hold layers");
+    aq_stagger<SS>();
     int wp[NL];
 #pragma unroll
     for (int u = 0; u < NL; u++)
@@ -742,7 +782,17 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
           fetch_far(std::integral_constant<int, TJ>{}, wp[TJ - JM0]);
       },
       std::make_integer_sequence<int, NL>{});
-    lds_barrier();
+    // this stage's own part of the weight block -> LDS: its layers' tiles and constants (+ the transition's / the head's)
+    copy_block(aq::kMTiles + (JM0 - aq::kJobM0) * 4 * aq::kTileM, NL * 4 * aq::kTileM);
+    copy_block(aq::kMConsts + (JM0 - aq::kJobM0) * 24, NL * 24);
+    if constexpr (HAS_T)
+      copy_block(aq::kWrOff, 2 * aq::kTileT);
+    if constexpr (LAST)
+      copy_block(aq::kHeadTile, aq::kTileM);
+    if constexpr (HAS_T || LAST)
+      copy_block(aq::kTConsts, 16);
+    __builtin_amdgcn_s_waitcnt(0);
+    set_word(cons_b(QIN), 0); // ready: the producer may hand over
     if constexpr (DBG)
       dbg_t[1] = clock64();
 

@@ -2761,21 +2761,20 @@ int nam_hip_batch_set_persistent(nam_hip_batch* batch, int enable)
     if (rc != NAM_HIP_OK)
       return rc;
   }
-  batch->ps.enabled = false;
-  const bool eligible = enable != 0 && persist_eligible(batch);
+  batch->ps.enabled = enable != 0; // (persist_eligible / persist_kind look at it)
+  const bool eligible = batch->ps.enabled && persist_eligible(batch);
   if (eligible)
   {
     // this call and Reset are the non-real-time side of the contract (NAM/dsp.h:163): the session's ring, words, stream and the
     // blocking entry points' host windows are allocated here, so that no process call ever allocates (the first used to: ~7 ms)
     const int rc = persist_prepare(batch);
     if (rc != NAM_HIP_OK)
-      return rc; // (the mode stays off: persist_prepare released what it had)
+      return rc; // (the mode is off again: persist_prepare released what it had and cleared `enabled`)
     // the blocking entry points' host windows too, when they are small (a batch of long buffers that only ever runs
     // device-resident audio must not pin hundreds of MB for calls it never makes: such a batch allocates them at its first
     // host-buffer call, if it makes one)
     (void)host_windows(batch, 1, batch->in_bar, batch->h_out_map, batch->d_out_map, batch->map_failed, /*prealloc=*/true);
   }
-  batch->ps.enabled = enable != 0;
   return eligible ? 1 : 0;
 }
 
