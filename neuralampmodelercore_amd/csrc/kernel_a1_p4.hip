@@ -91,7 +91,11 @@ constexpr int kQueueB = kFlagB + 256;
 // (One slot is enough: a stage hands over at the END of its buffer and the next stage takes at the START of its own.)
 constexpr int kSlotB = 64 * 16 + 64 * 16 + 64 * 4 + 16;
 constexpr int queue_b(int q, int w) { return kQueueB + (q * 4 + w) * kSlotB; }
-constexpr int lds_bytes(int nst) { return kQueueB + (nst - 1) * 4 * kSlotB; }
+// behind the queues: two rows of 64 output samples (by the parity of the command count) — a session that publishes every
+// command's completion (A1Args::p_out_host == 2) gathers the last stage's four waves' interleaved frames here, and ONE wave
+// stores the row to the host's window with one contiguous write-through instruction
+constexpr int out_stage_b(int nst) { return kQueueB + (nst - 1) * 4 * kSlotB; }
+constexpr int lds_bytes(int nst) { return out_stage_b(nst) + 2 * 256; }
 static_assert(lds_bytes(4) <= 160 * 1024, "p4 LDS layout");
 constexpr bool exchange_pairs_ok(int nst)
 {
@@ -532,8 +536,17 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
       // behind this launch's end). To HOST memory such stores complete one at a time (~1 us each, 1 ms per buffer at
       // 256 streams: profiles/r03/persist_io_store_scope_variants.txt): plain stores there, made visible by the release
       // fence before the completion word (kOutHost below)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob, uni((int)boff),
-                                            PERSIST && !kOutHost ? 17 : 0);
+      if (kOutHost && a.p_out_host == 2)
+      {
+        // every command a completion of its own (the stage loop below): the wave's sixteen frames — every fourth sample of the
+        // row — go to the staging row in LDS; written through to HOST memory from here they would be sixteen 4-byte PCIe
+        // writes per wave (measured: 1.75 ms per 64-frame call at 256 streams)
+        if (ok)
+          *reinterpret_cast<float*>(lds + p4::out_stage_b(NST) + (int)(done & 1u) * 256 + tl * 4) = yout;
+      }
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yout), rsrc_out, ok ? tl * 4 : (int)kOob, uni((int)boff),
+                                              PERSIST && !kOutHost ? 17 : 0);
     }
     else if constexpr ((flags_j & CD_POST_RECH) != 0)
       x = mfma_n<NK>(xt, x, f4{0.f, 0.f, 0.f, 0.f});
@@ -603,6 +616,30 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
       else if constexpr (PERSIST)
       {
         done++;
+        if (kOutHost && a.p_out_host == 2)
+        {
+          // a blocking host caller waits for THIS command (round 6: nam_hip_batch_process_f32 back to back rides one lingering
+          // launch, kernel_a1_q.hip's ticket protocol): the stage's four waves meet, wave 0 stores the row (one contiguous
+          // instruction, system scope, written through), has it acknowledged and counts the workgroup in; the last workgroup
+          // through the command stores the host's completion word (kernels.h: p_cmd_count / p_cmd_done)
+          stage_barrier(); // (a wave's LDS operations execute in order: its samples are in the row before its word says so)
+          if (w == 0)
+          {
+            const float yrow = *reinterpret_cast<const float*>(lds + p4::out_stage_b(NST) + (int)((done - 1u) & 1u) * 256 + lane * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yrow), rsrc_out, lane < nvalid ? lane * 4 : (int)kOob, uni((int)boff), 17);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // acknowledged (system scope, written through)
+            unsigned before = 0u;
+            const unsigned cslot = (done - 1u) & (unsigned)a.p_ring_mask;
+            if (lane == 0)
+              before = __hip_atomic_fetch_add(a.p_cmd_count + cslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)uni((int)before) == gridDim.x - 1u && lane == 0)
+            {
+              __hip_atomic_store(a.p_cmd_count + cslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(a.p_cmd_done + cslot, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_fetch_max(a.p_cmd_count + a.p_ring_mask + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (il_common.h: session_wait_command)
+            }
+          }
+        }
         if (w == 0 && lane == 0 && (done & 15u) == 0u) // progress for the host's ring bookkeeping (not a completion signal)
           __hip_atomic_store(a.p_prog + blockIdx.x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -617,20 +654,17 @@ __global__ __launch_bounds__(NST * 256) void nam_a1_p4_kernel(const float* __res
             unsigned long long v = spec_cmd;
             if ((unsigned)(v >> 32) != tag)
             {
-              // the early look missed: look again; while the later stages still work, for a few microseconds (bounded:
-              // the launch never waits for a command)
-              v = ring_load(tag - 1u);
-              const long long t_end = (long long)wall_clock64() + 100; // 1 us of the 100 MHz clock
-              while ((unsigned)(v >> 32) != tag && (long long)wall_clock64() < t_end)
-              {
-                __builtin_amdgcn_s_sleep(16);
-                v = ring_load(tag - 1u);
-              }
+              // the early look missed: look again; while the later stages still work, for a few microseconds (bounded: the
+              // launch never waits for a command) — or for A1Args::p_linger when the session serves a host caller that hands
+              // one buffer in after the other (il_common.h: session_wait_command, the rules of a lingering launch)
+              v = session_wait_command<16>(a, ring_load, tag, ring_load(tag - 1u), (long long)(a.p_linger > 0 ? a.p_linger : 100)); // (1 us unless the launch lingers)
             }
             if (lane == 0)
             {
               flags[48 + 2 * (k & 1)] = (int)(unsigned)v;
               flags[48 + 2 * (k & 1) + 1] = (unsigned)(v >> 32) == tag ? 1 : 0;
+              if ((unsigned)(v >> 32) != tag)
+                session_leaving(a); // (the others stop waiting for workgroups behind them)
             }
           }
           stage_barrier(); // wave 0's decision is the stage's (two decision slots by parity: the one written now was

@@ -255,7 +255,12 @@ struct nam_hip_batch
   bool short_blocking_call = false; // a blocking host call of up to four buffers is being served: the caller waits for it, so the FIRST buffer's
                                     // latency is what counts — nam_a1_p4_kernel (four waves per layer: ~6 us through the model) rather than
                                     // nam_a1_q_kernel (one wave per layer: ~30 us; faster only once buffers overlap)
+  bool blocking_linger = false; // blocking host calls are coming back to back (the previous one returned < kBlockingLingerGapUs ago): the session's
+                                // launch publishes every command and lingers for the next call, like a ticket session's
+  double t_blocking_return = -1e18; // host clock (us) when the last blocking host call of the session path returned
   bool one_buffer_call = false; // a blocking host call of ONE 64-frame buffer is being served: nothing to overlap, a launch started now runs nam_wn_reg_kernel as one wave per stream
+  int blocking_linger_us = 200; // 0 = blocking host calls never make a launch linger (NAM_HIP_BLOCKING_LINGER_US)
+  int blocking_linger_gap_us = 50; // "back to back": the previous blocking call returned less than this ago
   int ticket_linger = kTicketLingerDefault; // ticks of the 100 MHz clock a ticket session's launch looks for the next buffer (NAM_HIP_TICKET_LINGER_US)
   // NAM_HIP_MAX_STAGES = 1 / 2 / 4 (developer switch; default: no cap): the most pipeline stages a stream is spread over.
   // 1 = no pipelines at all (`no_pipe`: nam_a1_p2_kernel where nam_a1_p4 / q would run, nam_kt_mfma_kernel instead of nam_kq_kernel,
@@ -444,6 +449,12 @@ inline bool q_runs(const nam_hip_batch*, const Plan& p)
 inline bool kq_runs(const nam_hip_batch*, const Plan& p)
 {
   return p.a1.kp_ok && kq_takes(p.a1.arr[0].act, p.a1.arr[0].act_p0);
+}
+
+// how long a session's launch that publishes every command looks for the next one (ticks of the 100 MHz clock)
+inline int session_linger_ticks(const nam_hip_batch* b)
+{
+  return (b->blocking_linger && !b->pipe_session) ? b->blocking_linger_us * 100 : b->ticket_linger;
 }
 
 // `n_frames`: the launch length the question is about (under AUTO a launch of four or more blocks runs another kernel
@@ -778,7 +789,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_out_host = b->ps.out_is_host ? (b->ps.cmd_done_published ? 2 : 1) : 0;
-          a.p_linger = (b->ps.cmd_done_published && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
+          a.p_linger = (b->ps.cmd_done_published && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? session_linger_ticks(b) : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -821,7 +832,7 @@ int launch_group(nam_hip_batch* b, WidthGroup& g, const int* d_map, int n, const
           a.p_done = b->ps.d_words + b->ps.done_off;
           a.p_grace = b->ps.grace;
           a.p_out_host = b->ps.out_is_host ? (b->ps.cmd_done_published ? 2 : 1) : 0;
-          a.p_linger = (b->ps.cmd_done_published && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? b->ticket_linger : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
+          a.p_linger = (b->ps.cmd_done_published && b->ps.host_store_ok && b->ps.n_wg <= b->n_cus) ? session_linger_ticks(b) : 0; // (more workgroups than CUs take turns: the ones on the chip must leave when the ring is empty)
           a.p_cmd_count = b->ps.d_cmd_count;
           a.p_cmd_done = b->ps.d_cmd_done;
           a.p_seq0 = b->ps.seq0;
@@ -1102,14 +1113,18 @@ int persist_launch(nam_hip_batch* b, int grace_us, long long seq0 = -1, unsigned
   // the other kernels' tickets complete when the launch has left)
   {
     const Plan& p = *g.plan;
-    ps.cmd_done_published = b->pipe_session && ps.out_is_host && !b->no_pipe
-                        && ((ps.kind == PERSIST_A1_P2 && q_runs(b, p) && !b->short_blocking_call) || ps.kind == PERSIST_KQ); // (pipe_session: never the short-burst rule)
+    // ... and, round 6, a BLOCKING host caller that hands one buffer in after the other (nam_hip_batch::blocking_linger):
+    // nam_a1_p4_kernel — what the official topology's short blocking calls run — publishes the word too, so the call waits
+    // for its own command and the next call finds the launch still there (no launch, no prologue, no retirement per call)
+    (void)p;
+    ps.cmd_done_published = (b->pipe_session || b->blocking_linger) && ps.out_is_host && !b->no_pipe
+                        && (ps.kind == PERSIST_A1_P2 || ps.kind == PERSIST_KQ); // (pipe_session: never the short-burst rule)
     // ... and linger: a workgroup that finds itself up to date when a launch starts (another one's backlog was the reason for
     // the launch) must not leave at once — the commands to come would find it gone, and the rest of the launch would have to
     // linger and leave before the next launch could pick it up again
     if (ps.cmd_done_published && ps.host_store_ok && ps.n_wg <= b->n_cus)
     {
-      ps.grace = std::max(ps.grace, b->ticket_linger);
+      ps.grace = std::max(ps.grace, session_linger_ticks(b));
       // "a workgroup of this launch has left" (il_common.h: session_leaving; p_cmd_count[mask + 2] = [kPRing + 1]): none yet
       NAM_HIP_CHECK(hipMemsetAsync(ps.d_cmd_count + kPRing + 1, 0, sizeof(unsigned), ps.kstream));
     }
@@ -1888,13 +1903,28 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
   push_out_host_stores();
   b->one_buffer_call = n_frames == kBlock; // (one command, then the caller waits: the stages of a pipeline would only queue up)
   b->short_blocking_call = n_frames <= 4 * kBlock;
+  // nam::DSP::process back to back (NAM/dsp.h:97; tools/benchmodel.cpp:129-132: a loop of blocking calls): when the previous
+  // call returned a moment ago, the launch this call starts — or still finds — publishes every command's completion and
+  // lingers for the next one. A caller that comes once per audio period (1.3 ms at 64 frames) never makes a launch linger.
+  const double t_call = stat_now_us();
+  const bool linger_now = b->blocking_linger_us > 0 && t_call - b->t_blocking_return < (double)b->blocking_linger_gap_us;
+  if (linger_now != b->blocking_linger && b->ps.active && b->ps.outstanding)
+  {
+    // (the running launch was started under the other rule: let it go first — a whole flush; rare: the pattern changed)
+    const int rf = persist_flush(b, b->stream);
+    if (rf != NAM_HIP_OK)
+      return rf;
+  }
+  b->blocking_linger = linger_now;
   const int rc = persist_submit(b, b->in_bar, b->d_out_map, n_frames, stride, b->stream);
   if (rc != NAM_HIP_OK)
   {
     b->one_buffer_call = b->short_blocking_call = false;
     return rc < 0 ? rc : fail(NAM_HIP_ERR_DEVICE, "persistent session: the host-mapped buffer was refused");
   }
-  const int rw = persist_flush(b, b->stream);
+  // this call's own commands: the per-command completion word when the launch publishes it (it may linger on), else the
+  // whole launch (it leaves when it has drained the ring)
+  const int rw = b->ps.cmd_done_published ? persist_wait(b, b->stream, b->ps.seq, false) : persist_flush(b, b->stream);
   b->one_buffer_call = b->short_blocking_call = false;
   if (rw != NAM_HIP_OK)
     return rw;
@@ -1908,6 +1938,7 @@ int process_host_mapped(nam_hip_batch* b, const float* in_f32, const double* in_
       for (int i = 0; i < n_frames; i++)
         out_f64[r * n_frames + i] = (double)src[i];
   }
+  b->t_blocking_return = stat_now_us();
   return NAM_HIP_OK;
 }
 
@@ -2308,6 +2339,8 @@ int nam_hip_batch_create(const nam_hip_model* model, int device, int n_streams, 
   (void)hipDeviceGetAttribute(&b->n_cus, hipDeviceAttributeMultiprocessorCount, device);
   {
     b->ticket_linger = ticket_linger_from_env();
+    if (const char* e = std::getenv("NAM_HIP_BLOCKING_LINGER_US")) // (0: blocking host calls never make a launch linger)
+      b->blocking_linger_us = (int)std::min(std::max(std::atol(e), 0l), 100000l);
     if (const char* e = std::getenv("NAM_HIP_MAX_STAGES"))
     {
       const int v = std::atoi(e);

@@ -287,3 +287,38 @@ def test_tickets_survive_control_calls_outside_persistent_mode(nam_lib):
     y1 = b.process(x[:, frames:])
     b.close()
     assert float(np.abs(y0 - want0).max()) <= 1e-6 and float(np.abs(y1 - want1).max()) <= 1e-6
+
+
+def test_blocking_calls_back_to_back_ride_one_lingering_launch(nam_lib, oracle):
+    """nam::DSP::process in a loop (NAM/dsp.h:97; tools/benchmodel.cpp:129-132): from the second call on, the session's launch
+    publishes every command and lingers for the next call (round 6). Same audio as a device-resident render, every stream against
+    the oracle on three; a foreign device-wide synchronize in the middle returns (bounded by the linger, never a deadlock) and the
+    loop goes on; a pause longer than the linger, then more calls; 64-frame and 256-frame calls, one stream and 256."""
+    import time
+    torch = pytest.importorskip("torch")
+    nam = nam_lib
+    model = nam.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+    for n_streams, frames, nb in ((256, 64, 40), (1, 64, 40), (32, 256, 12)):
+        x = stream_bank(n_streams, nb * frames, seed=900 + n_streams)
+        b = model.batch(n_streams, frames)
+        assert b.set_persistent(True)
+        b.Reset(prewarm=True)
+        ys = []
+        t_sync = None
+        for k in range(nb):
+            ys.append(b.process(x[:, k * frames:(k + 1) * frames]))
+            if k == nb // 2:
+                t0 = time.perf_counter()
+                torch.cuda.synchronize()  # (a launch that lingers for the next call holds the device for at most the linger)
+                t_sync = time.perf_counter() - t0
+            if k == nb // 2 + 4:
+                time.sleep(0.002)  # (the launch gives up and leaves; the next call starts one again)
+        b.close()
+        assert t_sync is not None and t_sync < 0.05, t_sync
+        y = np.concatenate(ys, axis=2)
+        assert np.isfinite(y).all()
+        for s in sorted({0, n_streams - 1, n_streams // 3}):
+            ref = oracle.get_dsp(model_path("wavenet_a1_standard"), fast_tanh=True)
+            ref.Reset(48000.0, frames)
+            r = ref.process_stream(x[s], frames)[0]
+            assert float(np.max(np.abs(r - y[s, 0]))) <= 5e-5, (n_streams, frames, s)
