@@ -554,11 +554,12 @@ struct WrPlainW
   f4 conv[3 * C], conv_b, mix, l1[C], l1_b;
   i4 rec; // {-, ring area float offset, R, dilation | slot << 24}
 };
-template <int C>
+template <int C, bool LDREC = true>
 __device__ __forceinline__ void wr_plain_ld(WrPlainW<C>& w, const char* lds, unsigned wb, unsigned rec_b)
 {
   constexpr WrPlainLayout L = wr_plain_layout(C); // the compact block of a plain layer: 4 C + 3 rows of four floats
-  w.rec = *reinterpret_cast<const i4*>(lds + rec_b);
+  if constexpr (LDREC) // (a program compiled in — NAM_WR_PROGRAMS — knows its records: constants)
+    w.rec = *reinterpret_cast<const i4*>(lds + rec_b);
 #pragma unroll
   for (int i = 0; i < 3 * C; i++)
     w.conv[i] = lds_ld4(lds, wb + (unsigned)(L.conv + 4 * i) * 4u);
@@ -572,14 +573,15 @@ __device__ __forceinline__ void wr_plain_ld(WrPlainW<C>& w, const char* lds, uns
 // One plain layer with the weights in `w`; the next layer's weights / record (LDS byte addresses nxt_wb / nxt_rec) are
 // requested BEHIND this layer's taps: LDS returns in order, so the arithmetic waits for the taps only (a counted
 // lgkmcnt) while the 16 weight reads stream in under it.
-template <int C, int ACT>
+template <int C, int ACT, bool LDREC = true>
 __device__ __forceinline__ void wr_plain_layer(WrRegs& r, const WrPlainW<C>& w, WrPlainW<C>& nxt, unsigned nxt_wb,
-                                               unsigned nxt_rec, char* lds, int lane, int posv)
+                                               unsigned nxt_rec, char* lds, int lane, int posv, const i4 rec_k = i4{0, 0, 0, 0})
 {
-  const int R = w.rec[2], dil = w.rec[3] & 0xffffff;
-  int widx = __builtin_amdgcn_readlane(posv, __builtin_amdgcn_readfirstlane(w.rec[3] >> 24)) + lane;
+  const i4 rec = LDREC ? w.rec : rec_k;
+  const int R = rec[2], dil = rec[3] & 0xffffff;
+  int widx = __builtin_amdgcn_readlane(posv, LDREC ? __builtin_amdgcn_readfirstlane(rec[3] >> 24) : (rec[3] >> 24)) + lane;
   widx -= widx >= R ? R : 0;
-  const unsigned hb = (unsigned)w.rec[1] * 4u;
+  const unsigned hb = (unsigned)rec[1] * 4u;
   wr_ring_put<C>(lds, hb, widx, R, r.x);
   float t0[C], t1[C]; // taps 2 and 1 dilations back
   int i0 = widx - 2 * dil, i1 = widx - dil;
@@ -588,7 +590,7 @@ __device__ __forceinline__ void wr_plain_layer(WrRegs& r, const WrPlainW<C>& w, 
   wr_ring_get<C>(lds, hb, i0, R, t0);
   wr_ring_get<C>(lds, hb, i1, R, t1);
   wr_fence();
-  wr_plain_ld(nxt, lds, nxt_wb, nxt_rec);
+  wr_plain_ld<C, LDREC>(nxt, lds, nxt_wb, nxt_rec);
   wr_fence();
   const f4 m = w.mix * r.cond[0]; // input mixin (no bias): 0 + W cond
   f4 z = w.conv_b;
@@ -733,6 +735,114 @@ __device__ __forceinline__ void wr_post_head(WrRegs& r, const WrOpS& op, char* l
   wr_mv(o, taps, m);
   wr_unpack<HS>(r.hout, o);
 }
+
+// ---- A model's op PROGRAMS compiled in (round 6; NAM_WR_PROGRAMS, generated by plan.cpp: WrShapeSet::header_text) ----
+// The per-model build used to compile the model's layer SHAPES and still walk its program as data: every op cost a fetch
+// (four LDS reads, thirteen v_readfirstlane), a two-level switch, and its offsets / ring length / dilation / slot / flags as
+// scalar registers feeding address arithmetic — about a fifth of the instructions a lone wavefront issues per buffer (and a
+// lone wavefront's time IS its instruction count). With the program in the header every op is a constant expression: the op
+// loop is unrolled at compile time, the handler is chosen by `if constexpr`, every LDS address is an immediate.
+#ifdef NAM_WR_PROGRAMS
+constexpr WrOpS kWrProgOps[NAM_WR_N_PROGRAMS][NAM_WR_MAX_OPS] = NAM_WR_PROGRAM_OPS;
+constexpr int kWrProgCount[NAM_WR_N_PROGRAMS] = NAM_WR_PROGRAM_COUNTS;
+constexpr int kWrProgSplit[NAM_WR_N_PROGRAMS][3] = NAM_WR_PROGRAM_SPLITS;
+constexpr int kWrRunRecs[][4] = NAM_WR_RUN_RECS; // WR_RUN: {-, ring area float offset, R, dilation | slot << 24} per layer; op.slot = first row
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void wr_static_for(F&& f)
+{
+  if constexpr (I0 < I1)
+  {
+    f(std::integral_constant<int, I0>{});
+    wr_static_for<I0 + 1, I1>(f);
+  }
+}
+template <int ID>
+__device__ __forceinline__ void wr_layer_by_id(WrRegs& r, const WrOpS& op, char* lds, int lane, int posv)
+{
+#define X(ID_, COND, C, B, G, K, HO, FM, SM, BL, A1, A2, L1) \
+  if constexpr (ID == ID_) \
+    wr_layer<COND, C, B, G, K, HO, FM, SM, BL, A1, A2, L1>(r, op, lds, lane, posv);
+  WR_LAYER_SHAPES(X)
+#undef X
+}
+// a WR_RUN with its layer count, weight stride and ring records as constants (wr_run's two-register-set rotation, unrolled)
+template <int C, int ACT, int P, int I>
+__device__ __forceinline__ void wr_run_prog(WrRegs& r, char* lds, int lane, int posv)
+{
+  constexpr WrOpS op = kWrProgOps[P][I];
+  constexpr int NL = op.n_in, R0 = op.slot;
+  constexpr unsigned w0 = (unsigned)op.w * 4u, ws = (unsigned)op.n_out * 4u;
+  WrPlainW<C> wa, wb;
+  wr_plain_ld<C, false>(wa, lds, w0, 0u);
+  wr_static_for<0, (NL + 1) / 2>([&](auto t_tag) {
+    constexpr int l = 2 * decltype(t_tag)::value;
+    constexpr unsigned l1 = (unsigned)(l + 1 < NL ? l + 1 : NL - 1), l2 = (unsigned)(l + 2 < NL ? l + 2 : NL - 1);
+    wr_plain_layer<C, ACT, false>(r, wa, wb, w0 + l1 * ws, 0u, lds, lane, posv,
+                                  i4{0, kWrRunRecs[R0 + l][1], kWrRunRecs[R0 + l][2], kWrRunRecs[R0 + l][3]});
+    if constexpr (l + 1 < NL)
+      wr_plain_layer<C, ACT, false>(r, wb, wa, w0 + l2 * ws, 0u, lds, lane, posv,
+                                    i4{0, kWrRunRecs[R0 + l + 1][1], kWrRunRecs[R0 + l + 1][2], kWrRunRecs[R0 + l + 1][3]});
+  });
+}
+template <int ID, int P, int I>
+__device__ __forceinline__ void wr_run_by_id(WrRegs& r, char* lds, int lane, int posv)
+{
+#define X(ID_, C, A) \
+  if constexpr (ID == ID_) \
+    wr_run_prog<C, A, P, I>(r, lds, lane, posv);
+  WR_RUN_SHAPES(X)
+#undef X
+}
+// op I of program P (everything but WR_OUTPUT, which needs the launch's windows: the caller's)
+template <int P, int I>
+__device__ __forceinline__ void wr_exec_op(WrRegs& r, char* lds, int lane, int posv)
+{
+  constexpr WrOpS cur = kWrProgOps[P][I];
+  if constexpr (cur.type == WR_LAYER)
+    wr_layer_by_id<cur.shape>(r, cur, lds, lane, posv);
+  else if constexpr (cur.type == WR_RUN)
+    wr_run_by_id<cur.shape, P, I>(r, lds, lane, posv);
+  else if constexpr (cur.type == WR_ARRAY_BEGIN)
+  {
+#define X(ID, IN, OUT) \
+  if constexpr (cur.shape == ID) \
+    wr_array_begin<IN, OUT>(r, cur, lds);
+    WR_PAIR_SHAPES(X)
+#undef X
+  }
+  else if constexpr (cur.type == WR_ARRAY_END)
+  {
+#define X(ID, IN, OUT) \
+  if constexpr (cur.shape == ID) \
+    wr_array_end<IN, OUT>(r, cur, lds);
+    WR_PAIR_SHAPES(X)
+#undef X
+  }
+  else if constexpr (cur.type == WR_ARRAY_END_K)
+  {
+#define X(ID, IN, OUT, KH) \
+  if constexpr (cur.shape == ID) \
+    wr_array_end_k<IN, OUT, KH>(r, cur, lds, lane, posv);
+    WR_HEADK_SHAPES(X)
+#undef X
+  }
+  else if constexpr (cur.type == WR_POST_HEAD)
+  {
+#define X(ID, IN, OUT, KH, ACT) \
+  if constexpr (cur.shape == ID) \
+    wr_post_head<IN, OUT, KH, ACT>(r, cur, lds, lane, posv);
+    WR_POSTHEAD_SHAPES(X)
+#undef X
+  }
+  else if constexpr (cur.type == WR_SET_COND)
+  {
+#pragma unroll
+    for (int c = 0; c < kWrRegs; c++)
+      r.cond[c] = cur.scale() * r.hout[c];
+  }
+}
+#endif
 
 } // namespace
 
@@ -1038,6 +1148,97 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
         break;
       }
     }
+#ifdef NAM_WR_PROGRAMS
+    // the group's program, compiled in: this wave's part of it, op by op
+    auto run_program = [&](auto p_tag) {
+      constexpr int P = decltype(p_tag)::value;
+      constexpr int NOPS = kWrProgCount[P];
+      auto part = [&](auto i0_tag, auto i1_tag) {
+        constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value, PF = (I0 + I1) >> 1;
+        wr_static_for<I0, I1>([&](auto i_tag) {
+          constexpr int I = decltype(i_tag)::value;
+          constexpr WrOpS cur = kWrProgOps[P][I];
+          if constexpr (I == PF)
+          {
+            if (NST == 1 || S == 0)
+            {
+              int nf = -1, nn = kBlock;
+              if (pers)
+              {
+                if ((unsigned)(pw.spec >> 32) == pw.seq + 2u)
+                  nf = (int)(unsigned)pw.spec;
+              }
+              else if (f0 + kBlock < a.n_frames)
+              {
+                nf = f0 + kBlock;
+                nn = min(kBlock, a.n_frames - nf);
+              }
+              if (nf >= 0)
+              {
+                load_in(in_pf, nf, nn);
+                pf_off = nf;
+              }
+            }
+          }
+          if constexpr (cur.type == WR_OUTPUT)
+          {
+            if (out)
+            {
+#pragma unroll
+              for (int c = 0; c < kWrRegs; c++)
+                if (c < cur.n_out && lane < n)
+                  out[(long)c * a.io_stride + f0 + lane] = cur.scale() * r.hout[c];
+            }
+          }
+          else
+            wr_exec_op<P, I>(r, lds, lane, posv);
+        });
+      };
+      using std::integral_constant;
+      if constexpr (NST == 1)
+        part(integral_constant<int, 0>{}, integral_constant<int, NOPS>{});
+      else if constexpr (NST == 2)
+      {
+        constexpr int c = kWrProgSplit[P][1] < 1 ? 1 : kWrProgSplit[P][1] > NOPS - 1 ? NOPS - 1 : kWrProgSplit[P][1];
+        if (S == 0)
+          part(integral_constant<int, 0>{}, integral_constant<int, c>{});
+        else
+          part(integral_constant<int, c>{}, integral_constant<int, NOPS>{});
+      }
+      else
+      {
+        constexpr int s0 = kWrProgSplit[P][0], s1 = kWrProgSplit[P][1], s2 = kWrProgSplit[P][2];
+        constexpr int c0 = s0 < 1 ? 1 : s0 > NOPS - 3 ? NOPS - 3 : s0;
+        constexpr int c1 = (s1 > NOPS - 2 ? NOPS - 2 : s1) < c0 + 1 ? c0 + 1 : (s1 > NOPS - 2 ? NOPS - 2 : s1);
+        constexpr int c2 = (s2 > NOPS - 1 ? NOPS - 1 : s2) < c1 + 1 ? c1 + 1 : (s2 > NOPS - 1 ? NOPS - 1 : s2);
+        if (S == 0)
+          part(integral_constant<int, 0>{}, integral_constant<int, c0>{});
+        else if (S == 1)
+          part(integral_constant<int, c0>{}, integral_constant<int, c1>{});
+        else if (S == 2)
+          part(integral_constant<int, c1>{}, integral_constant<int, c2>{});
+        else
+          part(integral_constant<int, c2>{}, integral_constant<int, NOPS>{});
+      }
+    };
+    {
+      bool ran = false;
+      wr_static_for<0, NAM_WR_N_PROGRAMS>([&](auto p_tag) {
+        if (!ran && G.prog == decltype(p_tag)::value)
+        {
+          run_program(p_tag);
+          ran = true;
+        }
+      });
+      if (!ran)
+        __builtin_trap();
+    }
+    (void)ops_b;
+    (void)n_ops;
+    (void)oi0;
+    (void)oi1;
+    (void)pf_at;
+#else
     WrOpS cur = wr_fetch(lds, ops_b, oi0);
     for (int oi = oi0; oi < oi1; oi++)
     {
@@ -1156,6 +1357,7 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
       }
       cur = nxt;
     }
+#endif
     // every ring moves on by the block's n frames (lane = slot; lanes without a slot stay at 0)
     posv += ring_len > 0 ? n : 0;
     posv -= posv >= ring_len ? ring_len : 0;

@@ -172,6 +172,7 @@ struct WrGroup
   int tab_rows, n_rows, tab_pf, n_pf, tab_ring, tab_ops; // blob float offsets / entry counts of the tables
   int first; // first workgroup of the group
   int split_op[3]; // pipelined launches: the program's cuts at 1/4, 1/2, 3/4 of its weights (two stages: [1]; four: all three)
+  int prog; // per-model code objects with the programs compiled in (NAM_WR_PROGRAMS): which of them this group runs
 };
 struct WrArgs
 {

@@ -589,6 +589,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
     G.first = total;
     for (int q = 0; q < 3; q++)
       G.split_op[q] = w.split_op[q];
+    G.prog = w.program;
     can_split = can_split && w.split_op[1] >= 1 && w.split_op[1] < (int)w.ops.size();
     can_split4 = can_split4 && w.split_op[0] >= 1 && w.split_op[0] < w.split_op[1] && w.split_op[1] < w.split_op[2]
                  && w.split_op[2] < (int)w.ops.size();

@@ -8,6 +8,7 @@
 // and the weight blob is built by walking the flat weight stream in set_weights_ order
 // (model.cpp:152-181, 563-569, 661-683; Conv1D conv1d.cpp:40-55; Conv1x1 dsp.cpp:384-397).
 #include "plan.h"
+#include <cstdlib>
 #include "kp_table.h"
 #include "aq_table.h"
 
@@ -1953,6 +1954,47 @@ std::string WrShapeSet::header_text() const
   for (size_t i = 0; i < posts.size(); i++)
     ss << " X(" << i << ", " << posts[i].n_in << ", " << posts[i].n_out << ", " << posts[i].K << ", " << posts[i].act << ")";
   ss << "\n";
+  size_t total_ops = 0, max_ops = 1;
+  for (const auto& pr : programs)
+  {
+    total_ops += pr.ops.size();
+    max_ops = std::max(max_ops, pr.ops.size());
+  }
+  if (!programs.empty() && total_ops <= 768) // (a model of hundreds of ops stays a walked program: code size)
+  {
+    ss << "#define NAM_WR_PROGRAMS 1\n#define NAM_WR_N_PROGRAMS " << programs.size() << "\n#define NAM_WR_MAX_OPS " << max_ops << "\n";
+    ss << "#define NAM_WR_PROGRAM_COUNTS {";
+    for (size_t i = 0; i < programs.size(); i++)
+      ss << (i ? ", " : "") << programs[i].ops.size();
+    ss << "}\n#define NAM_WR_PROGRAM_SPLITS {";
+    for (size_t i = 0; i < programs.size(); i++)
+      ss << (i ? ", " : "") << "{" << programs[i].split_op[0] << ", " << programs[i].split_op[1] << ", " << programs[i].split_op[2] << "}";
+    ss << "}\n#define NAM_WR_PROGRAM_OPS {";
+    for (size_t i = 0; i < programs.size(); i++)
+    {
+      ss << (i ? ", " : "") << "{";
+      for (size_t k = 0; k < max_ops; k++)
+      {
+        WrOp o;
+        std::memset(&o, 0, sizeof(o));
+        if (k < programs[i].ops.size())
+          o = programs[i].ops[k];
+        int32_t scale_bits;
+        std::memcpy(&scale_bits, &o.scale, sizeof(scale_bits));
+        // {type, shape, w, hist, ring, dil, flags, act, act2, n_in, n_out, scale_bits, slot}; a WR_RUN's slot = its first record
+        const int32_t slot = o.type == WR_RUN ? programs[i].first_rec + o.pad[0] : o.slot;
+        ss << (k ? ", " : "") << "{" << o.type << ", " << o.shape << ", " << o.w << ", " << o.hist << ", " << o.ring << ", " << o.dil << ", "
+           << o.flags << ", " << o.act << ", " << o.act2 << ", " << o.n_in << ", " << o.n_out << ", " << scale_bits << ", " << slot << "}";
+      }
+      ss << "}";
+    }
+    ss << "}\n#define NAM_WR_RUN_RECS {";
+    for (size_t i = 0; i < run_recs.size(); i++)
+      ss << (i ? ", " : "") << "{" << run_recs[i][0] << ", " << run_recs[i][1] << ", " << run_recs[i][2] << ", " << run_recs[i][3] << "}";
+    if (run_recs.empty())
+      ss << "{0, 0, 0, 0}";
+    ss << "}\n";
+  }
   return ss.str();
 }
 
@@ -2025,11 +2067,13 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
     for (const auto& run : runs)
     {
       wr.ops[run.op].hist = run.table;
+      wr.ops[run.op].pad[0] = (int32_t)wr.run_recs.size(); // (the program compiled in: first record of this run)
       for (size_t l = 0; l < run.layers.size(); l++)
       {
         const WrOp& o = run.layers[l];
         const int32_t rec[4] = {o.w, o.hist + hist_base, o.ring, o.dil | (o.slot << 24)};
         std::memcpy(&wr.blob[(size_t)run.table + 4 * l], rec, sizeof(rec));
+        wr.run_recs.push_back({rec[0], rec[1], rec[2], rec[3]});
       }
     }
     std::memcpy(&wr.blob[(size_t)wr.tab_ops], wr.ops.data(), wr.ops.size() * sizeof(WrOp));
@@ -2104,17 +2148,33 @@ void build_wr(const WaveNetSpec& wn, Plan& plan, WrShapeSet* jit_shapes)
         why = e.what();
     }
   };
-  attempt(WrBuilder::AOT_EXACT_ONLY, nullptr);
-  if (!done && jit_shapes)
-  {
+  // Round 6: with a shape set on offer the per-model build comes FIRST — it compiles the plan's program in (every op a
+  // constant expression: WrShapeSet::programs), which beats the ahead-of-time kernels walking the same program as data even
+  // where they hold every shape (configs 4 and 5 of the bench: profiles/r06). NAM_HIP_WR_PROGRAM=0: round 5's order.
+  static const bool program_first = [] { const char* e = std::getenv("NAM_HIP_WR_PROGRAM"); return !(e && e[0] == '0'); }();
+  auto attempt_jit = [&]() {
+    if (done || !jit_shapes)
+      return;
     WrShapeSet trial = *jit_shapes; // (only a plan that succeeds leaves its shapes in the caller's set)
     attempt(WrBuilder::JIT, &trial);
     if (done)
     {
+      WrShapeSet::Program pr;
+      pr.ops = wr.ops;
+      for (int q = 0; q < 3; q++)
+        pr.split_op[q] = wr.split_op[q];
+      pr.first_rec = (int)trial.run_recs.size();
+      trial.run_recs.insert(trial.run_recs.end(), wr.run_recs.begin(), wr.run_recs.end());
+      wr.program = (int)trial.programs.size();
+      trial.programs.push_back(std::move(pr));
       *jit_shapes = std::move(trial);
       wr.jit = true;
     }
-  }
+  };
+  if (program_first)
+    attempt_jit();
+  attempt(WrBuilder::AOT_EXACT_ONLY, nullptr);
+  attempt_jit();
   attempt(WrBuilder::AOT_ANY, nullptr);
   if (!done)
   {

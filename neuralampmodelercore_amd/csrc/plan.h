@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstdint>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -451,6 +452,8 @@ struct WrPlan
   int tab_pf = 0, n_pf = 0; // ... of the one-block prefetch windows
   int tab_ring = 0; // ... of R per slot (n_layers ints, padded to 4)
   int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
+  int program = -1; // per-model compile with the programs compiled in: this plan's program in the model's code object (WrShapeSet::programs)
+  std::vector<std::array<int32_t, 4>> run_recs; // (planner) the records of this plan's WR_RUN layers, in op order; WrOp::pad[0] of a WR_RUN = its first
   int split_op[3] = {0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its weights (kernel_wn_reg.hip, NST)
   // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
   // object compiled for it ("" until nam_hip_api.cpp has prepared it — the plan is not runnable before)
@@ -539,6 +542,16 @@ struct WrShapeSet
   int layer(int cond, int C, int B, bool G, int K, int HO, int flags, int act, int act2, bool l1);
   int run(int C, int act);
   int pair(int n_in, int n_out);
+  // Round 6: the op PROGRAMS of the model's plans too (one per width / submodel): the per-model build compiles them in
+  // (kernel_wn_reg.hip: NAM_WR_PROGRAMS) — no op fetch, no dispatch, every offset an immediate
+  struct Program
+  {
+    std::vector<WrOp> ops; // as the blob holds them (LDS offsets final)
+    int split_op[3];
+    int first_rec; // WR_RUN ops: their layers' records start at run_recs[first_rec + (op.slot as stored here)]
+  };
+  std::vector<Program> programs;
+  std::vector<std::array<int32_t, 4>> run_recs; // {w, ring area offset, R, dilation | slot << 24} of every layer of every WR_RUN
   bool empty() const { return layers.empty() && runs.empty() && pairs.empty() && heads.empty() && posts.empty(); }
   std::string header_text() const; // the generated tables: "#define NAM_WR_JIT_SHAPES 1 / #define WR_LAYER_SHAPES(X) ..."
 };
