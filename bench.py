@@ -1042,7 +1042,10 @@ def main():
         if tr is not None:
             floor_parts = {"hbm_us": traffic_b / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6, "fp32_us": flops_per_launch / (FP32_PEAK_TFLOPS * 1e12) * 1e6}
             if tr.get("mfma_busy_cycles") is not None and tr.get("insts_per_launch", {}).get("VALU") is not None:
-                n_simd = 1024.0
+                # (kernels without matrix instructions too — nam_wn_reg_kernel: mfma_busy_cycles = 0 and the whole floor is the
+                # vector instructions of a SIMD's lone wave at the measured one-wave issue rate; `simds_busy`: the SIMDs that
+                # hold a wave at all — 768 lone waves of config 5 sit on 768 of the 1,024)
+                n_simd = float(tr.get("simds_busy", 1024))
                 other_valu = tr["insts_per_launch"]["VALU"] - tr.get("mfma_insts", 0.0)
                 # cycles of the issue port per non-matrix vector instruction of a SIMD: MEASURED (tools/src/valu_rate.hip at the
                 # kernel's waves per SIMD and instruction mix, profiles/r05/valu_rate_microbench.txt), recorded with the entry

@@ -1158,6 +1158,9 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
         wr_static_for<I0, I1>([&](auto i_tag) {
           constexpr int I = decltype(i_tag)::value;
           constexpr WrOpS cur = kWrProgOps[P][I];
+#ifdef NAM_WR_MARKERS // (developer builds: tools/isa_regions.py --markers counts the instructions between these comments)
+          asm volatile("; nam_op program %0 op %1 type %2 stages %3" ::"i"(P), "i"(I), "i"(cur.type), "i"(NST));
+#endif
           if constexpr (I == PF)
           {
             if (NST == 1 || S == 0)
@@ -1233,6 +1236,9 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
       if (!ran)
         __builtin_trap();
     }
+#ifdef NAM_WR_MARKERS
+    asm volatile("; nam_op program -1 op -1 type -1 stages %0" ::"i"(NST)); // (behind the program: the per-buffer remainder)
+#endif
     (void)ops_b;
     (void)n_ops;
     (void)oi0;

@@ -56,9 +56,50 @@ def count(items, a, b):
     return c
 
 
+def markers(path, kernel_substr):
+    """--markers: nam_wn_reg_kernel built with -DNAM_WR_MARKERS (kernel_wn_reg.hip: '; nam_op program P op I type T stages N' in
+    front of every op of a compiled-in program): instructions by class per op, in program order, for one kernel function."""
+    lines = open(path).read().splitlines()
+    names = {0: "ARRAY_BEGIN", 1: "LAYER", 2: "ARRAY_END", 3: "SET_COND", 4: "OUTPUT", 5: "RUN", 6: "ARRAY_END_K", 7: "POST_HEAD", -1: "(per-buffer remainder)"}
+    cur_fn, rows, cur = None, [], None
+    for i, l in enumerate(lines, 1):
+        t = l.strip()
+        m = re.match(r"^([A-Za-z_][\w$.]*):", t)
+        if m and not t.startswith(".L"):
+            cur_fn = m.group(1)
+            cur = None
+            continue
+        if cur_fn is None or kernel_substr not in cur_fn:
+            continue
+        m = re.match(r"^; nam_op program (-?\d+) op (-?\d+) type (-?\d+) stages (\d+)", t)
+        if m:
+            cur = {"program": int(m.group(1)), "op": int(m.group(2)), "type": names.get(int(m.group(3)), m.group(3)), "c": {}}
+            rows.append(cur)
+            continue
+        if cur is None or not t or t.startswith((";", "//", ".")) or re.match(r"^\S+:$", t):
+            continue
+        if t.startswith("s_endpgm"):
+            cur = None
+            continue
+        op = t.split()[0]
+        if re.match(r"^[a-z_0-9]+$", op):
+            cl = classify(op)
+            cur["c"][cl] = cur["c"].get(cl, 0) + 1
+    print(f"{'program':>7s} {'op':>3s} {'type':22s} {'valu':>6s} {'salu':>6s} {'lds':>6s} {'vmem':>6s} {'wait':>6s} {'smem':>5s}")
+    tot = {}
+    for r in rows:
+        c = r["c"]
+        for k, v in c.items():
+            tot[k] = tot.get(k, 0) + v
+        print(f"{r['program']:7d} {r['op']:3d} {r['type']:22s} {c.get('valu', 0):6d} {c.get('salu', 0):6d} {c.get('lds', 0):6d} {c.get('vmem', 0):6d} {c.get('wait', 0):6d} {c.get('smem', 0):5d}")
+    print(f"{'':7s} {'':3s} {'total':22s} {tot.get('valu', 0):6d} {tot.get('salu', 0):6d} {tot.get('lds', 0):6d} {tot.get('vmem', 0):6d} {tot.get('wait', 0):6d} {tot.get('smem', 0):5d}")
+
+
 def main():
     args = sys.argv[1:]
     path = args[0]
+    if "--markers" in args:
+        return markers(path, args[args.index("--markers") + 1])
     items = parse(path)
     if "--range" in args:
         k = args.index("--range")

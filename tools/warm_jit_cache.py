@@ -14,6 +14,12 @@ import neuralampmodelercore_amd as nam
 import make_synthetic_models as msm
 
 
+def _load(job):
+    p, ft = job
+    m = nam.get_dsp(p, fast_tanh=ft)
+    return bool(m.info.has_a1_kernel & 16)
+
+
 def main():
     t0 = time.time()
     n = acc = 0
@@ -28,17 +34,23 @@ def main():
         print(f"warm_jit_cache: {len(paths)} models, {len(glob.glob(os.path.join(cache, '*.hsaco')))} code objects in {cache}")
         return
     stamp = time.time() - 1.0  # code objects a load below neither built nor found are stale (their sources changed): pruned
+    # (round 6: every nam_wn_reg_kernel model gets a code object of its own — its programs compiled in —, ~6 s each: the
+    # loads run in worker processes, one per core; the cache publishes by rename, concurrent builds of one key are benign)
+    import multiprocessing as mp
+    jobs = []
     for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "models", "*.nam"))):
         for ft in (False, True):
-            nam.get_dsp(p, fast_tanh=ft)
-            n += 1
+            jobs.append((p, ft))
     with tempfile.TemporaryDirectory() as tmp:
         for seed in range(50):  # tests/test_gpu_breadth.py: FEATURED_SEEDS (40 ..: with a post-stack head)
             p = os.path.join(tmp, f"featured_{seed}.nam")
             msm.write_featured(p, 7000 + seed, wr_shapes=bool(seed % 2), post_head=seed >= 40)
-            m = nam.get_dsp(p, fast_tanh=seed % 3 == 0)
-            acc += bool(m.info.has_a1_kernel & 16)
-            n += 1
+            jobs.append((p, seed % 3 == 0))
+        workers = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 8))
+        with mp.get_context("spawn").Pool(workers) as pool:
+            res = pool.map(_load, jobs)
+    n = len(jobs)
+    acc = sum(1 for (p, _), ok in zip(jobs, res) if ok and os.path.basename(p).startswith("featured_"))
     pruned = 0
     for f in glob.glob(os.path.join(cache, "*")) if "--prune" in sys.argv else []:  # (a hit refreshes the file's time stamp, wr_jit.cpp)
         if os.path.getmtime(f) < stamp:
