@@ -743,8 +743,10 @@ __device__ __forceinline__ void wr_post_head(WrRegs& r, const WrOpS& op, char* l
 // lone wavefront's time IS its instruction count). With the program in the header every op is a constant expression: the op
 // loop is unrolled at compile time, the handler is chosen by `if constexpr`, every LDS address is an immediate.
 #ifdef NAM_WR_PROGRAMS
-constexpr WrOpS kWrProgOps[NAM_WR_N_PROGRAMS][NAM_WR_MAX_OPS] = NAM_WR_PROGRAM_OPS;
-constexpr int kWrProgCount[NAM_WR_N_PROGRAMS] = NAM_WR_PROGRAM_COUNTS;
+// two forms of every program: as planned (CUT = 0: what one wavefront per stream runs) and with its WR_RUNs cut into sub-runs
+// (CUT = 1: what two / four wavefronts per stream share — kWrProgSplit are the cuts of that form)
+constexpr WrOpS kWrProgOps[2][NAM_WR_N_PROGRAMS][NAM_WR_MAX_OPS] = {NAM_WR_PROGRAM_OPS, NAM_WR_PROGRAM_OPS_CUT};
+constexpr int kWrProgCount[2][NAM_WR_N_PROGRAMS] = {NAM_WR_PROGRAM_COUNTS, NAM_WR_PROGRAM_COUNTS_CUT};
 constexpr int kWrProgSplit[NAM_WR_N_PROGRAMS][3] = NAM_WR_PROGRAM_SPLITS;
 constexpr int kWrRunRecs[][4] = NAM_WR_RUN_RECS; // WR_RUN: {-, ring area float offset, R, dilation | slot << 24} per layer; op.slot = first row
 
@@ -767,10 +769,10 @@ __device__ __forceinline__ void wr_layer_by_id(WrRegs& r, const WrOpS& op, char*
 #undef X
 }
 // a WR_RUN with its layer count, weight stride and ring records as constants (wr_run's two-register-set rotation, unrolled)
-template <int C, int ACT, int P, int I>
+template <int C, int ACT, int CUT, int P, int I>
 __device__ __forceinline__ void wr_run_prog(WrRegs& r, char* lds, int lane, int posv)
 {
-  constexpr WrOpS op = kWrProgOps[P][I];
+  constexpr WrOpS op = kWrProgOps[CUT][P][I];
   constexpr int NL = op.n_in, R0 = op.slot;
   constexpr unsigned w0 = (unsigned)op.w * 4u, ws = (unsigned)op.n_out * 4u;
   WrPlainW<C> wa, wb;
@@ -785,24 +787,24 @@ __device__ __forceinline__ void wr_run_prog(WrRegs& r, char* lds, int lane, int 
                                     i4{0, kWrRunRecs[R0 + l + 1][1], kWrRunRecs[R0 + l + 1][2], kWrRunRecs[R0 + l + 1][3]});
   });
 }
-template <int ID, int P, int I>
+template <int ID, int CUT, int P, int I>
 __device__ __forceinline__ void wr_run_by_id(WrRegs& r, char* lds, int lane, int posv)
 {
 #define X(ID_, C, A) \
   if constexpr (ID == ID_) \
-    wr_run_prog<C, A, P, I>(r, lds, lane, posv);
+    wr_run_prog<C, A, CUT, P, I>(r, lds, lane, posv);
   WR_RUN_SHAPES(X)
 #undef X
 }
 // op I of program P (everything but WR_OUTPUT, which needs the launch's windows: the caller's)
-template <int P, int I>
+template <int CUT, int P, int I>
 __device__ __forceinline__ void wr_exec_op(WrRegs& r, char* lds, int lane, int posv)
 {
-  constexpr WrOpS cur = kWrProgOps[P][I];
+  constexpr WrOpS cur = kWrProgOps[CUT][P][I];
   if constexpr (cur.type == WR_LAYER)
     wr_layer_by_id<cur.shape>(r, cur, lds, lane, posv);
   else if constexpr (cur.type == WR_RUN)
-    wr_run_by_id<cur.shape, P, I>(r, lds, lane, posv);
+    wr_run_by_id<cur.shape, CUT, P, I>(r, lds, lane, posv);
   else if constexpr (cur.type == WR_ARRAY_BEGIN)
   {
 #define X(ID, IN, OUT) \
@@ -1151,13 +1153,13 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
 #ifdef NAM_WR_PROGRAMS
     // the group's program, compiled in: this wave's part of it, op by op
     auto run_program = [&](auto p_tag) {
-      constexpr int P = decltype(p_tag)::value;
-      constexpr int NOPS = kWrProgCount[P];
+      constexpr int P = decltype(p_tag)::value, CUT = NST > 1 ? 1 : 0;
+      constexpr int NOPS = kWrProgCount[CUT][P];
       auto part = [&](auto i0_tag, auto i1_tag) {
         constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value, PF = (I0 + I1) >> 1;
         wr_static_for<I0, I1>([&](auto i_tag) {
           constexpr int I = decltype(i_tag)::value;
-          constexpr WrOpS cur = kWrProgOps[P][I];
+          constexpr WrOpS cur = kWrProgOps[CUT][P][I];
 #ifdef NAM_WR_MARKERS // (developer builds: tools/isa_regions.py --markers counts the instructions between these comments)
           asm volatile("; nam_op program %0 op %1 type %2 stages %3" ::"i"(P), "i"(I), "i"(cur.type), "i"(NST));
 #endif
@@ -1194,7 +1196,7 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
             }
           }
           else
-            wr_exec_op<P, I>(r, lds, lane, posv);
+            wr_exec_op<CUT, P, I>(r, lds, lane, posv);
         });
       };
       using std::integral_constant;
@@ -1479,6 +1481,18 @@ extern "C" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nam_wn_reg_jit4(const WrArgs a)
 {
   wn_reg_body<2, 4>(a); // four stages
+}
+// The DENSE forms (round 6): the same bodies built for TWO wavefronts per SIMD (at most 256 vector registers). A lone wave issues
+// one instruction every ~8 cycles whatever it is — half of what its SIMD could issue —, so a batch that leaves SIMDs idle or a
+// model small enough to live in 256 registers runs two stages' waves side by side on a SIMD: the host uses a dense form only
+// when the compiler fitted it without scratch (nam_hip_api.cpp: wr_jit_function, launch_wr's duration model).
+extern "C" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void nam_wn_reg_jit2d(const WrArgs a)
+{
+  wn_reg_body<2, 2>(a);
+}
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void nam_wn_reg_jit4d(const WrArgs a)
+{
+  wn_reg_body<2, 4>(a);
 }
 #else
 template <int SET>

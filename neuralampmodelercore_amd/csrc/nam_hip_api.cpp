@@ -255,6 +255,8 @@ struct nam_hip_batch
   bool short_blocking_call = false; // a blocking host call of up to four buffers is being served: the caller waits for it, so the FIRST buffer's
                                     // latency is what counts — nam_a1_p4_kernel (four waves per layer: ~6 us through the model) rather than
                                     // nam_a1_q_kernel (one wave per layer: ~30 us; faster only once buffers overlap)
+  int wr_last_stages = 0; // (NAM_HIP_SESSION_STATS: what nam_wn_reg_kernel's last multi-buffer launch ran as)
+  bool wr_last_dense = false;
   bool blocking_linger = false; // blocking host calls are coming back to back (the previous one returned < kBlockingLingerGapUs ago): the session's
                                 // launch publishes every command and lingers for the next call, like a ticket session's
   double t_blocking_return = -1e18; // host clock (us) when the last blocking host call of the session path returned
@@ -498,6 +500,16 @@ const char* group_kernel_name(const nam_hip_batch* b, const WidthGroup& g, int n
   return "nam_lstm_kernel";
 }
 
+inline double stat_now_us()
+{
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool stats_on()
+{
+  static const bool on = [] { const char* e = std::getenv("NAM_HIP_SESSION_STATS"); return e && e[0] == '1'; }();
+  return on;
+}
+
 // the session's side of a persistent launch of a one-wavefront-per-workgroup kernel (kernels.h: PersistArgs)
 PersistArgs persist_args(const nam_hip_batch* b)
 {
@@ -517,7 +529,9 @@ PersistArgs persist_args(const nam_hip_batch* b)
 
 // The function of a per-model code object on the current device (hipModuleLoad is per device: cached per path and
 // device for the life of the process; a handful of entries).
-int wr_jit_function(const std::string& path, int device, int stages, void** fn)
+// `dense`: the form built for two wavefronts per SIMD (kernel_wn_reg.hip: nam_wn_reg_jit2d / 4d); *dense_ok (optional) reports
+// which stage counts have one the compiler fitted into 256 registers WITHOUT scratch (bit 1: two stages, bit 2: four).
+int wr_jit_function(const std::string& path, int device, int stages, void** fn, bool dense = false, int* dense_ok = nullptr)
 {
   struct Entry
   {
@@ -525,17 +539,24 @@ int wr_jit_function(const std::string& path, int device, int stages, void** fn)
     int device;
     hipModule_t module;
     hipFunction_t fn, fn2, fn4; // nam_wn_reg_jit, nam_wn_reg_jit2 (two stages), nam_wn_reg_jit4
+    hipFunction_t fn2d, fn4d; // the dense forms (nullptr: not usable)
   };
   static std::vector<Entry> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
+  auto pick = [&](const Entry& e) {
+    if (dense_ok)
+      *dense_ok = (e.fn2d ? 2 : 0) | (e.fn4d ? 4 : 0);
+    if (fn)
+      *fn = reinterpret_cast<void*>(stages == 4 ? (dense && e.fn4d ? e.fn4d : e.fn4) : stages == 2 ? (dense && e.fn2d ? e.fn2d : e.fn2) : e.fn);
+  };
   for (const Entry& e : cache)
     if (e.device == device && e.path == path)
     {
-      *fn = reinterpret_cast<void*>(stages == 4 ? e.fn4 : stages == 2 ? e.fn2 : e.fn);
+      pick(e);
       return NAM_HIP_OK;
     }
-  Entry e{path, device, nullptr, nullptr, nullptr, nullptr};
+  Entry e{path, device, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   NAM_HIP_CHECK(hipModuleLoad(&e.module, path.c_str()));
   NAM_HIP_CHECK(hipModuleGetFunction(&e.fn, e.module, "nam_wn_reg_jit"));
   NAM_HIP_CHECK(hipModuleGetFunction(&e.fn2, e.module, "nam_wn_reg_jit2"));
@@ -544,9 +565,22 @@ int wr_jit_function(const std::string& path, int device, int stages, void** fn)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn2), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn4), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
+  static const bool dense_on = [] { const char* v = std::getenv("NAM_HIP_WR_DENSE"); return !(v && v[0] == '0'); }();
+  for (int q = 0; q < 2 && dense_on; q++)
+  {
+    hipFunction_t f = nullptr;
+    if (hipModuleGetFunction(&f, e.module, q == 0 ? "nam_wn_reg_jit2d" : "nam_wn_reg_jit4d") != hipSuccess || !f)
+      continue;
+    int scratch = 1, regs = 1 << 20;
+    if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess
+        || hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, f) != hipSuccess || scratch > 32 || regs > 256)
+      continue; // (spilled more than a handful of registers, or not a two-per-SIMD build after all: the one-wave-per-SIMD form serves)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, kWrMaxLdsBytes);
+    (q == 0 ? e.fn2d : e.fn4d) = f;
+  }
   (void)hipGetLastError();
   cache.push_back(e);
-  *fn = reinterpret_cast<void*>(stages == 4 ? e.fn4 : stages == 2 ? e.fn2 : e.fn);
+  pick(e);
   return NAM_HIP_OK;
 }
 
@@ -600,6 +634,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   // launch holds more than one buffer and the chip has the SIMDs for it — config 4's 512 streams become 1,024
   // wavefronts, 256 streams too
   int stages = 1;
+  bool dense = false; // the two-wavefronts-per-SIMD build of the per-model code object
   // (a session whose caller flushes after EVERY buffer is a series of one-buffer calls: nothing for a pipeline to overlap)
   const bool one_buffer_bursts = b->ps_launching && !b->pipe_session && b->ps.one_buffer_bursts();
   if (!b->no_pipe && !b->one_buffer_call && !one_buffer_bursts && (b->ps_launching || n_frames > kBlock))
@@ -624,8 +659,47 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
       best = duration(2);
     }
     if (can_split && can_split4 && b->wr_max_stages >= 4 && duration(4) < 0.9 * best)
+    {
       stages = 4;
+      best = duration(4);
+    }
+    // ... or the DENSE forms of a per-model code object (two wavefronts per SIMD: twice the workgroups per CU; two waves that
+    // share a SIMD each issue nearly as fast as a lone one — profiles/r05/valu_rate_microbench.txt: 8.6 cycles per instruction of
+    // a wave at one AND at two per SIMD — minus what they lose to each other's LDS traffic: 0.9)
+    const std::string& module0 = groups[0]->plan->wr.jit_module;
+    if (!module0.empty() && can_split && b->wr_max_stages >= 2)
+    {
+      int ok = 0;
+      if (wr_jit_function(module0, b->device, 1, nullptr, false, &ok) == NAM_HIP_OK && ok != 0)
+      {
+        auto duration_dense = [&](int nst) {
+          const int lds = lds_bytes + (nst - 1) * kWrQueueBytes;
+          if (lds > kWrMaxLdsBytes)
+            return 1e9;
+          const int on_chip = cus * std::min(8 / nst, (160 * 1024) / (lds + 512));
+          const double speed = 0.9 * (nst == 4 ? 3.1 : 1.75);
+          const int turns = (total + on_chip - 1) / on_chip;
+          return turns * (1.0 + 0.15 * (turns - 1)) / speed;
+        };
+        if ((ok & 2) && duration_dense(2) < 0.9 * best)
+        {
+          stages = 2;
+          dense = true;
+          best = duration_dense(2);
+        }
+        if ((ok & 4) && can_split4 && b->wr_max_stages >= 4 && duration_dense(4) < 0.9 * best)
+        {
+          stages = 4;
+          dense = true;
+        }
+      }
+    }
     lds_bytes += (stages - 1) * kWrQueueBytes;
+    if (stats_on() && (stages != b->wr_last_stages || dense != b->wr_last_dense))
+      std::fprintf(stderr, "nam_hip nam_wn_reg_kernel: %d workgroups as %d wavefront(s) per stream%s, %d bytes of LDS each\n", total, stages,
+                   dense ? " (two per SIMD)" : "", lds_bytes);
+    b->wr_last_stages = stages;
+    b->wr_last_dense = dense;
   }
   a.n_groups = n_groups;
   a.in = d_in;
@@ -643,7 +717,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   if (!module.empty())
   {
     void* fn = nullptr;
-    const int rc = wr_jit_function(module, b->device, stages, &fn);
+    const int rc = wr_jit_function(module, b->device, stages, &fn, dense);
     if (rc != NAM_HIP_OK)
       return rc;
     NAM_HIP_CHECK(launch_wn_reg_jit(fn, a, total, lds_bytes, stages, s));
@@ -1182,15 +1256,6 @@ struct PersistWatch
 
 // Blocks until every submitted command has been consumed by every workgroup and its results are visible.
 // `caller`: the stream the doorbells were rung on.
-inline double stat_now_us()
-{
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-inline bool stats_on()
-{
-  static const bool on = [] { const char* e = std::getenv("NAM_HIP_SESSION_STATS"); return e && e[0] == '1'; }();
-  return on;
-}
 
 int persist_wait(nam_hip_batch* b, hipStream_t caller, unsigned target, bool whole);
 inline void push_out_host_stores();

@@ -1957,38 +1957,44 @@ std::string WrShapeSet::header_text() const
   size_t total_ops = 0, max_ops = 1;
   for (const auto& pr : programs)
   {
-    total_ops += pr.ops.size();
-    max_ops = std::max(max_ops, pr.ops.size());
+    total_ops += pr.ops.size() + pr.ops_cut.size();
+    max_ops = std::max(max_ops, std::max(pr.ops.size(), pr.ops_cut.size()));
   }
-  if (!programs.empty() && total_ops <= 768) // (a model of hundreds of ops stays a walked program: code size)
+  if (!programs.empty() && total_ops <= 1536) // (a model of hundreds of ops stays a walked program: code size)
   {
     ss << "#define NAM_WR_PROGRAMS 1\n#define NAM_WR_N_PROGRAMS " << programs.size() << "\n#define NAM_WR_MAX_OPS " << max_ops << "\n";
-    ss << "#define NAM_WR_PROGRAM_COUNTS {";
-    for (size_t i = 0; i < programs.size(); i++)
-      ss << (i ? ", " : "") << programs[i].ops.size();
-    ss << "}\n#define NAM_WR_PROGRAM_SPLITS {";
+    ss << "#define NAM_WR_PROGRAM_SPLITS {";
     for (size_t i = 0; i < programs.size(); i++)
       ss << (i ? ", " : "") << "{" << programs[i].split_op[0] << ", " << programs[i].split_op[1] << ", " << programs[i].split_op[2] << "}";
-    ss << "}\n#define NAM_WR_PROGRAM_OPS {";
-    for (size_t i = 0; i < programs.size(); i++)
+    ss << "}\n";
+    for (int cut = 0; cut < 2; cut++)
     {
-      ss << (i ? ", " : "") << "{";
-      for (size_t k = 0; k < max_ops; k++)
+      ss << "#define " << (cut ? "NAM_WR_PROGRAM_COUNTS_CUT" : "NAM_WR_PROGRAM_COUNTS") << " {";
+      for (size_t i = 0; i < programs.size(); i++)
+        ss << (i ? ", " : "") << (cut ? programs[i].ops_cut : programs[i].ops).size();
+      ss << "}\n#define " << (cut ? "NAM_WR_PROGRAM_OPS_CUT" : "NAM_WR_PROGRAM_OPS") << " {";
+      for (size_t i = 0; i < programs.size(); i++)
       {
-        WrOp o;
-        std::memset(&o, 0, sizeof(o));
-        if (k < programs[i].ops.size())
-          o = programs[i].ops[k];
-        int32_t scale_bits;
-        std::memcpy(&scale_bits, &o.scale, sizeof(scale_bits));
-        // {type, shape, w, hist, ring, dil, flags, act, act2, n_in, n_out, scale_bits, slot}; a WR_RUN's slot = its first record
-        const int32_t slot = o.type == WR_RUN ? programs[i].first_rec + o.pad[0] : o.slot;
-        ss << (k ? ", " : "") << "{" << o.type << ", " << o.shape << ", " << o.w << ", " << o.hist << ", " << o.ring << ", " << o.dil << ", "
-           << o.flags << ", " << o.act << ", " << o.act2 << ", " << o.n_in << ", " << o.n_out << ", " << scale_bits << ", " << slot << "}";
+        const std::vector<WrOp>& ops = cut ? programs[i].ops_cut : programs[i].ops;
+        ss << (i ? ", " : "") << "{";
+        for (size_t k = 0; k < max_ops; k++)
+        {
+          WrOp o;
+          std::memset(&o, 0, sizeof(o));
+          if (k < ops.size())
+            o = ops[k];
+          int32_t scale_bits;
+          std::memcpy(&scale_bits, &o.scale, sizeof(scale_bits));
+          // {type, shape, w, hist, ring, dil, flags, act, act2, n_in, n_out, scale_bits, slot}; a WR_RUN's slot = its first record
+          const int32_t slot = o.type == WR_RUN ? programs[i].first_rec + o.pad[0] : o.slot;
+          ss << (k ? ", " : "") << "{" << o.type << ", " << o.shape << ", " << o.w << ", " << o.hist << ", " << o.ring << ", " << o.dil << ", "
+             << o.flags << ", " << o.act << ", " << o.act2 << ", " << o.n_in << ", " << o.n_out << ", " << scale_bits << ", " << slot << "}";
+        }
+        ss << "}";
       }
-      ss << "}";
+      ss << "}\n";
     }
-    ss << "}\n#define NAM_WR_RUN_RECS {";
+    ss << "#define NAM_WR_RUN_RECS {";
     for (size_t i = 0; i < run_recs.size(); i++)
       ss << (i ? ", " : "") << "{" << run_recs[i][0] << ", " << run_recs[i][1] << ", " << run_recs[i][2] << ", " << run_recs[i][3] << "}";
     if (run_recs.empty())
@@ -1996,6 +2002,50 @@ std::string WrShapeSet::header_text() const
     ss << "}\n";
   }
   return ss.str();
+}
+
+// Two- / four-stage launches (kernel_wn_reg.hip, NST) cut the program where the work balances; an op's weights are a fair
+// measure of its arithmetic (every weight is one multiply-add per frame): op i owns the blob from its offset to the next
+// larger one (`weights_end`: the first table behind the weights). split[q] = the cut closest to (q + 1) / 4 of the work.
+static void wr_program_cuts(const std::vector<WrOp>& ops, int weights_end, int split[3])
+{
+  auto weighs = [](const WrOp& op) {
+    return op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K
+           || op.type == WR_POST_HEAD;
+  };
+  std::vector<int> ws;
+  for (const auto& op : ops)
+    if (weighs(op))
+      ws.push_back(op.w);
+  ws.push_back(weights_end);
+  std::sort(ws.begin(), ws.end());
+  std::vector<long> cost(ops.size(), 8);
+  long total = 0;
+  for (size_t i = 0; i < ops.size(); i++)
+  {
+    const auto& op = ops[i];
+    if (weighs(op))
+    {
+      const auto nx = std::upper_bound(ws.begin(), ws.end(), op.w);
+      cost[i] += nx != ws.end() ? *nx - op.w : 0;
+    }
+    total += cost[i];
+  }
+  for (int q = 0; q < 3; q++)
+  {
+    long acc = 0, best = -1;
+    split[q] = 0;
+    for (size_t m = 1; m < ops.size(); m++)
+    {
+      acc += cost[m - 1];
+      const long d = std::labs(4 * acc - (q + 1) * total);
+      if (best < 0 || d < best)
+      {
+        best = d;
+        split[q] = (int)m;
+      }
+    }
+  }
 }
 
 // One attempt under one shape policy; throws WrBuilder::Unsupported
@@ -2077,44 +2127,7 @@ static void build_wr_with(const WaveNetSpec& wn, WrPlan& wr, WrBuilder::Policy p
       }
     }
     std::memcpy(&wr.blob[(size_t)wr.tab_ops], wr.ops.data(), wr.ops.size() * sizeof(WrOp));
-    {
-      // Two-stage launches (kernel_wn_reg.hip, NST = 2) cut the program where the work balances; an op's weights are a
-      // fair measure of its arithmetic (every weight is one multiply-add per frame): op i owns the blob from its offset to
-      // the next larger one.
-      std::vector<int> ws;
-      for (const auto& op : wr.ops)
-        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K || op.type == WR_POST_HEAD)
-          ws.push_back(op.w);
-      ws.push_back(wr.tab_rows); // (the first table: the end of the weights)
-      std::sort(ws.begin(), ws.end());
-      std::vector<long> cost(wr.ops.size(), 8);
-      long total = 0;
-      for (size_t i = 0; i < wr.ops.size(); i++)
-      {
-        const auto& op = wr.ops[i];
-        if (op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K || op.type == WR_POST_HEAD)
-        {
-          const auto nx = std::upper_bound(ws.begin(), ws.end(), op.w);
-          cost[i] += nx != ws.end() ? *nx - op.w : 0;
-        }
-        total += cost[i];
-      }
-      for (int q = 0; q < 3; q++) // the cut closest to (q + 1) / 4 of the work
-      {
-        long acc = 0, best = -1;
-        wr.split_op[q] = 0;
-        for (size_t m = 1; m < wr.ops.size(); m++)
-        {
-          acc += cost[m - 1];
-          const long d = std::labs(4 * acc - (q + 1) * total);
-          if (best < 0 || d < best)
-          {
-            best = d;
-            wr.split_op[q] = (int)m;
-          }
-        }
-      }
-    }
+    wr_program_cuts(wr.ops, wr.tab_rows, wr.split_op);
     wr.hist_floats = b.hist;
     wr.state_floats = (kWrPosInts + b.hist + 63) / 64 * 64;
     wr.lds_bytes = (hist_base + wr.hist_floats) * 4;
@@ -2160,9 +2173,97 @@ void build_wr(const WaveNetSpec& wn, Plan& plan, WrShapeSet* jit_shapes)
     if (done)
     {
       WrShapeSet::Program pr;
+      // the program as the code object holds it, twice: as it is (one wavefront per stream), and — a WR_RUN is ONE op to the
+      // walked program (one dispatch for ten layers) and so could not be cut across the wavefronts of a two- / four-stage
+      // launch — with every run cut at the quartile points of the program's work that fall inside it (sub-runs: their layers'
+      // weights and ring records are consecutive; a sub-run costs one more exposed weight fetch, which is why the one-wavefront
+      // form keeps the whole run) and the cuts taken again
       pr.ops = wr.ops;
-      for (int q = 0; q < 3; q++)
-        pr.split_op[q] = wr.split_op[q];
+      {
+        // cost of every op as wr_program_cuts counts it (weights + 8), a run's layer by layer; the quartile points of the total
+        std::vector<WrOp> probe = wr.ops;
+        long total = 0;
+        std::vector<long> cost(wr.ops.size(), 8);
+        {
+          std::vector<int> ws;
+          auto weighs = [](const WrOp& op) {
+            return op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K
+                   || op.type == WR_POST_HEAD;
+          };
+          for (const auto& op : wr.ops)
+            if (weighs(op))
+              ws.push_back(op.w);
+          ws.push_back(wr.tab_rows);
+          std::sort(ws.begin(), ws.end());
+          for (size_t i = 0; i < wr.ops.size(); i++)
+          {
+            if (weighs(wr.ops[i]))
+            {
+              const auto nx = std::upper_bound(ws.begin(), ws.end(), wr.ops[i].w);
+              cost[i] += nx != ws.end() ? *nx - wr.ops[i].w : 0;
+            }
+            total += cost[i];
+          }
+        }
+        // atoms: every op, a run layer by layer; the atom boundary closest to each quartile point of the total
+        struct Atom
+        {
+          size_t op;
+          int layer; // -1: not a run
+          long cost;
+        };
+        std::vector<Atom> atoms;
+        for (size_t i = 0; i < wr.ops.size(); i++)
+        {
+          const WrOp& o = wr.ops[i];
+          if (o.type == WR_RUN && o.n_in >= 2)
+            for (int l = 0; l < o.n_in; l++)
+              atoms.push_back({i, l, cost[i] / o.n_in});
+          else
+            atoms.push_back({i, -1, cost[i]});
+        }
+        std::vector<std::vector<int>> cuts(wr.ops.size()); // per run: the layers a sub-run starts at
+        for (int q = 1; q <= 3; q++)
+        {
+          long acc = 0, best = -1;
+          size_t best_at = 0;
+          for (size_t k = 1; k < atoms.size(); k++)
+          {
+            acc += atoms[k - 1].cost;
+            const long d = std::labs(4 * acc - (long)q * total);
+            if (best < 0 || d < best)
+            {
+              best = d;
+              best_at = k;
+            }
+          }
+          if (best_at > 0 && atoms[best_at].layer > 0) // the boundary lies inside a run: in front of this layer
+            cuts[atoms[best_at].op].push_back(atoms[best_at].layer);
+        }
+        for (size_t i = 0; i < wr.ops.size(); i++)
+        {
+          const WrOp& o = wr.ops[i];
+          if (o.type != WR_RUN || o.n_in < 2 || cuts[i].empty())
+          {
+            pr.ops_cut.push_back(o);
+            continue;
+          }
+          std::vector<int> at = cuts[i];
+          at.push_back(0);
+          at.push_back(o.n_in);
+          std::sort(at.begin(), at.end());
+          at.erase(std::unique(at.begin(), at.end()), at.end());
+          for (size_t k = 0; k + 1 < at.size(); k++)
+          {
+            WrOp sub = o;
+            sub.w = o.w + at[k] * o.n_out; // (n_out: the layers' weight stride)
+            sub.n_in = at[k + 1] - at[k];
+            sub.pad[0] = o.pad[0] + at[k];
+            pr.ops_cut.push_back(sub);
+          }
+        }
+      }
+      wr_program_cuts(pr.ops_cut, wr.tab_rows, pr.split_op);
       pr.first_rec = (int)trial.run_recs.size();
       trial.run_recs.insert(trial.run_recs.end(), wr.run_recs.begin(), wr.run_recs.end());
       wr.program = (int)trial.programs.size();

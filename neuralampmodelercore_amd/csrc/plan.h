@@ -546,8 +546,9 @@ struct WrShapeSet
   // (kernel_wn_reg.hip: NAM_WR_PROGRAMS) — no op fetch, no dispatch, every offset an immediate
   struct Program
   {
-    std::vector<WrOp> ops; // as the blob holds them (LDS offsets final)
-    int split_op[3];
+    std::vector<WrOp> ops; // as the blob holds them (LDS offsets final): what ONE wavefront per stream runs
+    std::vector<WrOp> ops_cut; // ... and with every WR_RUN cut into up to four sub-runs: what two / four wavefronts per stream share
+    int split_op[3]; // the cuts of ops_cut
     int first_rec; // WR_RUN ops: their layers' records start at run_recs[first_rec + (op.slot as stored here)]
   };
   std::vector<Program> programs;
