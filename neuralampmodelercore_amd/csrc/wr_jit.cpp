@@ -196,7 +196,8 @@ std::string wr_jit_build(const WrShapeSet& shapes, std::string& why)
   const int rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form",
                                "-include", hdr, "-I" + src, "-c", "-o", tmp, src + "/kernel_wn_reg.hip"},
                               log);
-  std::remove(hdr.c_str());
+  if (!std::getenv("NAM_HIP_JIT_KEEP")) // (developer switch: the generated shapes header stays next to the code object)
+    std::remove(hdr.c_str());
   if (rc != 0 || !readable(tmp))
   {
     std::string tail = read_file(log);
