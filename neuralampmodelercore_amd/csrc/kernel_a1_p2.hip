@@ -22,7 +22,7 @@ namespace namhip
 // ================================================================================================
 // PERSIST (block mode without a kernel boundary per buffer): the launch consumes COMMANDS — one per 64-frame buffer,
 // `(seq << 32) | frame offset`, written into a device-memory ring by hipStreamWriteValue64 on the caller's stream
-// (nam_hip_api.cpp: persistent session) — for as long as the next one is already there. Wave 0 looks at command k + 1
+// (api_session.cpp: persistent session) — for as long as the next one is already there. Wave 0 looks at command k + 1
 // while block k is still computing and the workgroup agrees on it at the end of the block (one extra barrier). With
 // the ring empty the workgroup makes its results visible (system-scope release), publishes how many commands it has
 // consumed and LEAVES: it never waits, so nothing can hang and a device-wide synchronise simply returns when the

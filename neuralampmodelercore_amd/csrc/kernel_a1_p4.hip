@@ -790,7 +790,7 @@ hipError_t launch_p4_shape(const A1Args& a, int n_blocks, int act, hipStream_t s
 }
 } // namespace
 
-// A session of the 16 / 8 topology may switch to this kernel in the middle of a caller's real-time loop (nam_hip_api.cpp:
+// A session of the 16 / 8 topology may switch to this kernel in the middle of a caller's real-time loop (api_launch.cpp:
 // PersistSession::short_bursts): its session instantiation is made ready when the session starts, not at the switch.
 hipError_t preload_a1_p4_session(int c0, int c1, int act, bool out_host)
 {

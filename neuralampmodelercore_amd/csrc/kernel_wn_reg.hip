@@ -1485,7 +1485,7 @@ extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 // The DENSE forms (round 6): the same bodies built for TWO wavefronts per SIMD (at most 256 vector registers). A lone wave issues
 // one instruction every ~8 cycles whatever it is — half of what its SIMD could issue —, so a batch that leaves SIMDs idle or a
 // model small enough to live in 256 registers runs two stages' waves side by side on a SIMD: the host uses a dense form only
-// when the compiler fitted it without scratch (nam_hip_api.cpp: wr_jit_function, launch_wr's duration model).
+// when the compiler fitted it without scratch (api_launch.cpp: wr_jit_function, launch_wr's duration model).
 extern "C" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void nam_wn_reg_jit2d(const WrArgs a)
 {
   wn_reg_body<2, 2>(a);

@@ -32,7 +32,7 @@ struct DynamicLdsLimit
   }
 };
 
-// A session's resident launch carries its own completion signal: persist_launch (nam_hip_api.cpp) sets this thread's stop event
+// A session's resident launch carries its own completion signal: persist_launch (api_session.cpp) sets this thread's stop event
 // around the launch call, and the launch sites of the session-capable kernels go through nam_launch — hipExtLaunchKernelGGL puts
 // the event's signal on the dispatch packet itself, so the host's wait for "the launch has retired" (nam_hip_batch_flush,
 // synchronize, the end of a session) is a wait on that signal: ~1.4 us behind the last workgroup instead of the ~11 us a

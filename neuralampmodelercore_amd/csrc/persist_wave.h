@@ -1,6 +1,6 @@
 // persist_wave.h — device side of the persistent block mode for kernels whose workgroup is ONE wavefront
 // (nam_wn_reg_kernel, nam_lstm_row_kernel). The protocol is the one nam_a1_p2_kernel speaks (kernel_a1_p2.hip, PERSIST;
-// host side: nam_hip_api.cpp, PersistSession): the launch consumes COMMANDS — one per 64-frame buffer, `(seq << 32) |
+// host side: api_session.cpp; api_internal.h: PersistSession): the launch consumes COMMANDS — one per 64-frame buffer, `(seq << 32) |
 // frame offset` in a ring the host (or the caller's stream) stores into — for as long as the next one is already there
 // when a buffer is finished, and leaves as soon as the ring is empty (it never waits unboundedly: a device-wide
 // synchronize must not depend on a command arriving). A wavefront of its own needs no agreement step: every lane

@@ -456,7 +456,7 @@ struct WrPlan
   std::vector<std::array<int32_t, 4>> run_recs; // (planner) the records of this plan's WR_RUN layers, in op order; WrOp::pad[0] of a WR_RUN = its first
   int split_op[3] = {0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its weights (kernel_wn_reg.hip, NST)
   // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
-  // object compiled for it ("" until nam_hip_api.cpp has prepared it — the plan is not runnable before)
+  // object compiled for it ("" until api_launch.cpp: build_model has prepared it — the plan is not runnable before)
   bool jit = false;
   std::string jit_module;
 };
@@ -658,7 +658,7 @@ struct Plan
   int state_floats = 0; // per-stream state size (floats), multiple of 64; first n_rings words = write positions
   // true when the A1 kernels run a zero-padded copy of the model (plan.cpp: pad_channels_for_mfma): their rings are
   // [R][C_padded] while the op program's are [R][C] — two state layouts, so switching between the generic kernel and
-  // the A1 kernels needs freshly reset state (nam_hip_api.cpp enforces it)
+  // the A1 kernels needs freshly reset state (api_launch.cpp: launch_group enforces it)
   bool a1_padded_layout = false;
   A1Plan a1;
   LSTMPlan lstm;

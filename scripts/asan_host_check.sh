@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 mkdir -p variants/obj_asan
-for f in nam_hip_api nam_loader plan wr_jit; do
+for f in nam_hip_api api_launch api_session api_host_io nam_loader plan wr_jit; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fvisibility=hidden -fsanitize=address,undefined -fno-gpu-sanitize \
     -fno-omit-frame-pointer -x hip -c -o variants/obj_asan/$f.o neuralampmodelercore_amd/csrc/$f.cpp &
 done

@@ -12,9 +12,10 @@ RUNS = [
     ("c4_wn_reg", "nam_wn_reg_kernel", "wavenet_a2_max", 512, 1, 1024, 6.79,
      "profiles/r05/valu_rate_microbench.txt: ONE wave per SIMD, v_fma_f32 + v_mul_f32 interleaved 6.79 cycles per instruction of the wave "
      "(plain v_fma_f32 8.61, v_pk_fma_f32 9.58: the lowest of the one-wave rows = the floor). Config 4 runs two waves per stream = one per SIMD."),
-    ("c5_wn_reg", "nam_wn_reg_kernel", "slimmable_wavenet", 768, 1, 768, 6.79,
-     "profiles/r05/valu_rate_microbench.txt: ONE wave per SIMD, 6.79 cycles per instruction of the wave (the lowest one-wave row). Config 5 is "
-     "768 lone waves: 768 of the 1,024 SIMDs hold one, the per-SIMD count is taken over those."),
+    ("c5_wn_reg", "nam_wn_reg_kernel", "slimmable_wavenet", 768, 2, 1024, 3.40,
+     "profiles/r05/valu_rate_microbench.txt: TWO waves per SIMD, v_fma_f32 + v_mul_f32 interleaved 3.40 cycles per SIMD-instruction (v_pk_fma_f32 5.05: "
+     "the lowest of the two-wave rows = the floor). Config 5 runs the dense form (round 6): two waves per stream, 1,536 waves = one or two on "
+     "every one of the 1,024 SIMDs."),
     ("c2_q", "nam_a1_q_kernel", "wavenet_a1_standard", 256, 4, 1024, 3.84,
      "tools/src/valu_rate.hip, four waves per SIMD, the stage bodies' own mix next to the kernel's fp32 matrix instructions (profiles/r05/valu_rate_microbench.txt)"),
     ("a2_kq", "nam_kq_kernel", "A2", 256, 4, 1024, 4.06,

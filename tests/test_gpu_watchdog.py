@@ -1,4 +1,4 @@
-"""The session watchdog (NAM_HIP_PERSIST_TIMEOUT_MS, csrc/nam_hip_api.cpp: PersistWatch): a resident launch that makes no
+"""The session watchdog (NAM_HIP_PERSIST_TIMEOUT_MS, csrc/api_session.cpp: PersistWatch): a resident launch that makes no
 progress for that long is reported as a device failure instead of spinning for ever — and a launch that IS making progress,
 however long the host waits for it, is not. The stall is real: another process (tests/helpers/gpu_hog.hip) holds every CU's
 LDS, so the session's workgroups (144 KB each) cannot be placed until it ends."""
