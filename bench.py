@@ -739,10 +739,17 @@ def main():
     y = torch.zeros((n_local, oc, T), dtype=torch.float32, device=dev)
 
     def fence(engine):
+        """barrier + device synchronize: this rank's work is done (synchronize), then every rank's is (barrier), then the
+        barrier's own collective has left the device (synchronize). Returns the host clock right behind the FIRST synchronize:
+        a timed region ends when this rank's K steps are done — the MAX over ranks of those is when the whole job's are; the
+        barrier that follows brackets the region (nothing of the next one starts before every rank is here) but its own
+        collective (a launch + an all-reduce over xGMI: tens of microseconds, a third of a 20-step region) is not a step."""
         engine.sync()
+        t_done = time.perf_counter()
         if distributed:
             dist.barrier()
             engine.sync()
+        return t_done
 
     def reduce_max(vals):
         t = torch.tensor(vals, dtype=torch.float64, device=dev)
@@ -812,8 +819,7 @@ def main():
         engine.run_steps(W, K, args.launch)
         t_enq = time.perf_counter() - t0
         e1 = None if pers else engine.event()
-        fence(engine)
-        wall = time.perf_counter() - t0
+        wall = fence(engine) - t0
         # the K steps' own time: HIP events on the launch stream around the K launches — or, in persistent block mode
         # (the work runs on the session's stream, not between two events of the caller's), the host clock from before
         # the first command until the host has seen every workgroup publish the last buffer (launch latency included)
@@ -840,8 +846,7 @@ def main():
         fence(engine)
         t1 = time.perf_counter()
         engine.run_steps(W, K, "resident")
-        fence(engine)
-        other = reduce_max([time.perf_counter() - t1])[0]
+        other = reduce_max([fence(engine) - t1])[0]
 
     # per-launch latency distribution (min / p50 / p99 / p99.9, tools/bench_a2_fast.cpp:274-296): a separate pass with a
     # HIP event between launches on the launch stream (the events cost a little, so this is never the timed region)
