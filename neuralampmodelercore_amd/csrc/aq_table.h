@@ -73,7 +73,9 @@ constexpr bool takes_area(int job) { return job > 0 && job < kJobHead && starts_
 // 2 d + 64 rows has room for the consumer's sub-block, its 2 d of history and at most three sub-blocks ahead of it, and the words
 // count modulo a power of two — except into the stages whose first ring is in HBM (L7, L8, L9: they take their rows through an area
 // of their own, which may be as deep as LDS allows): four with NAM_AQ_DEEP_Q (A/B: profiles/r05/a1q_variants.txt)
-#ifdef NAM_AQ_DEEP_Q
+#if defined(NAM_AQ_DEPTH4_MASK) // (A/B builds: bit j = four sub-blocks into big job j)
+constexpr int depth_in(int job) { return (is_big(job) && ((NAM_AQ_DEPTH4_MASK >> job) & 1)) ? 4 : 2; }
+#elif defined(NAM_AQ_DEEP_Q)
 constexpr int depth_in(int job) { return (is_big(job) && !res(job)) ? 4 : 2; }
 #else
 constexpr int depth_in(int) { return 2; }
