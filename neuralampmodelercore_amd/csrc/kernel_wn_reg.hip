@@ -234,11 +234,22 @@ __device__ __forceinline__ void wr_mv_acc(f2* acc, const float* in, const WrMat<
 }
 
 // film.h:76-204 — v[d] = v[d] * scale[d] (+ shift[d]);  scale = Ws cond + bs, shift = Wh cond + bh
-// block at `fb`: Ws [COND][pad4(D)], Wh [COND][pad4(D)], bs [pad4(D)], bh [pad4(D)]
+// block at `fb`: Ws, Wh, bs [pad4(D)], bh [pad4(D)]. The two matrices come in one of two forms (plan.cpp: WrBuilder packs what
+// wr_film_matrix_form says):
+//   * vector form [COND][pad4(D)]: one broadcast b128 = four outputs' weights for one input = two v_pk_fma_f32;
+//   * MATRIX form (a condition of 4 or 8 values — every FiLM of a model behind a condition_dsp): [lane % 4][pad4(D) / 4][COND] —
+//     the lane's own row W[4 q + lane % 4][c] of every output quad q, the A operand of v_mfma_f32_4x4x1_16b_f32 with the
+//     lane's condition value c as B (one lane per frame: the sixteen 4 x 4 blocks are four frames each) — ONE matrix
+//     instruction per input and output quad instead of two packed FMAs, one b128 per four inputs instead of one per input, and
+//     a quarter of the registers per matrix. Same sums in the same order (bias, then inputs 0 .. COND - 1; an fp32 MFMA is the
+//     fmaf chain).
 template <int D, int COND>
 struct WrFilm
 {
-  WrMat<(D > 0 ? D : 1), COND> s, h;
+  static constexpr bool kM = wr_film_matrix_form(COND);
+  static constexpr int Q = wr_pad4(D > 0 ? D : 1) / 4;
+  WrMat<(D > 0 ? D : 1), (kM ? 1 : COND)> s, h; // vector form
+  f4 ms[Q][kM ? COND / 4 : 1], mh[Q][kM ? COND / 4 : 1], mbs[Q], mbh[Q]; // matrix form: the lane's rows, the biases
 };
 template <int D, int COND>
 __device__ __forceinline__ void wr_ld(WrFilm<D, COND>& f, const char* lds, unsigned fb, bool shift)
@@ -246,9 +257,36 @@ __device__ __forceinline__ void wr_ld(WrFilm<D, COND>& f, const char* lds, unsig
   if constexpr (D > 0)
   {
     constexpr unsigned kMat = (unsigned)COND * wr_pad4(D) * 4u, kVec = (unsigned)wr_pad4(D) * 4u;
-    wr_ld(f.s, lds, fb, true, fb + 2u * kMat);
-    if (shift)
-      wr_ld(f.h, lds, fb + kMat, true, fb + 2u * kMat + kVec);
+    if constexpr (WrFilm<D, COND>::kM)
+    {
+      constexpr int Q = WrFilm<D, COND>::Q;
+      const unsigned cls_b = (threadIdx.x & 3u) * (unsigned)(Q * COND * 4);
+#pragma unroll
+      for (int q = 0; q < Q; q++)
+      {
+#pragma unroll
+        for (int c4 = 0; c4 < COND / 4; c4++)
+          f.ms[q][c4] = lds_ld4(lds, fb + cls_b + (unsigned)((q * COND + c4 * 4) * 4));
+        f.mbs[q] = lds_ld4(lds, fb + 2u * kMat + (unsigned)q * 16u);
+      }
+      if (shift)
+      {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+        {
+#pragma unroll
+          for (int c4 = 0; c4 < COND / 4; c4++)
+            f.mh[q][c4] = lds_ld4(lds, fb + kMat + cls_b + (unsigned)((q * COND + c4 * 4) * 4));
+          f.mbh[q] = lds_ld4(lds, fb + 2u * kMat + kVec + (unsigned)q * 16u);
+        }
+      }
+    }
+    else
+    {
+      wr_ld(f.s, lds, fb, true, fb + 2u * kMat);
+      if (shift)
+        wr_ld(f.h, lds, fb + kMat, true, fb + 2u * kMat + kVec);
+    }
   }
 }
 template <int D, int COND>
@@ -256,21 +294,66 @@ __device__ __forceinline__ void wr_film(f2* v, const float* cond, const WrFilm<D
 {
   if constexpr (D > 0)
   {
-    f2 sc[wr_pairs(D)];
-    wr_mv(sc, cond, f.s);
-    if (shift)
+    if constexpr (WrFilm<D, COND>::kM)
     {
-      f2 sh[wr_pairs(D)];
-      wr_mv(sh, cond, f.h);
+      constexpr int Q = WrFilm<D, COND>::Q, P = wr_pairs(D);
+      f4 sc[Q];
 #pragma unroll
-      for (int d = 0; d < wr_pairs(D); d++)
-        v[d] = __builtin_elementwise_fma(v[d], sc[d], sh[d]);
+      for (int q = 0; q < Q; q++)
+        sc[q] = f.mbs[q];
+#pragma unroll
+      for (int c = 0; c < COND; c++)
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+          sc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(f.ms[q][c >> 2][c & 3], cond[c], sc[q], 0, 0, 0);
+      if (shift)
+      {
+        f4 sh[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+          sh[q] = f.mbh[q];
+#pragma unroll
+        for (int c = 0; c < COND; c++)
+#pragma unroll
+          for (int q = 0; q < Q; q++)
+            sh[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(f.mh[q][c >> 2][c & 3], cond[c], sh[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+        {
+          v[2 * q] = __builtin_elementwise_fma(v[2 * q], f2{sc[q][0], sc[q][1]}, f2{sh[q][0], sh[q][1]});
+          if (2 * q + 1 < P)
+            v[2 * q + 1] = __builtin_elementwise_fma(v[2 * q + 1], f2{sc[q][2], sc[q][3]}, f2{sh[q][2], sh[q][3]});
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+        {
+          v[2 * q] *= f2{sc[q][0], sc[q][1]};
+          if (2 * q + 1 < P)
+            v[2 * q + 1] *= f2{sc[q][2], sc[q][3]};
+        }
+      }
     }
     else
     {
+      f2 sc[wr_pairs(D)];
+      wr_mv(sc, cond, f.s);
+      if (shift)
+      {
+        f2 sh[wr_pairs(D)];
+        wr_mv(sh, cond, f.h);
 #pragma unroll
-      for (int d = 0; d < wr_pairs(D); d++)
-        v[d] *= sc[d];
+        for (int d = 0; d < wr_pairs(D); d++)
+          v[d] = __builtin_elementwise_fma(v[d], sc[d], sh[d]);
+      }
+      else
+      {
+#pragma unroll
+        for (int d = 0; d < wr_pairs(D); d++)
+          v[d] *= sc[d];
+      }
     }
   }
 }

@@ -1673,6 +1673,7 @@ struct WrBuilder
           throw Unsupported("layer shape cond=" + std::to_string(cond_dim) + " C=" + std::to_string(C) + " B=" + std::to_string(B)
                             + (G ? " gating" : "") + " K=" + std::to_string(K) + " head1x1=" + std::to_string(h1o));
         int off = 0;
+        int film_matrix_floats = 0; // this layer's FiLM weights that lie in the matrix form (half the instructions per weight)
         if (run_shape >= 0)
         {
           const WrPlainLayout P = wr_plain_layout(C);
@@ -1721,6 +1722,22 @@ struct WrBuilder
             dense(d + L.film[k], w, cond_dim, outc, 1, A.film[k].groups, 0, D, !A.film[k].shift);
             if (A.film[k].shift)
               dense(d + L.film[k] + cond_dim * D4, w, cond_dim, outc, 1, A.film[k].groups, D, D);
+            if (wr_film_matrix_form(cond_dim))
+            {
+              film_matrix_floats += (A.film[k].shift ? 2 : 1) * cond_dim * D4;
+              // [cond][pad4(D)] -> [lane class][output quad][cond]: class i of quad q = row 4 q + i, its weights for inputs 0 .. cond - 1
+              const int Q = D4 / 4;
+              std::vector<float> t((size_t)cond_dim * D4);
+              for (int m = 0; m < (A.film[k].shift ? 2 : 1); m++)
+              {
+                float* mat = d + L.film[k] + m * cond_dim * D4;
+                std::copy(mat, mat + cond_dim * D4, t.begin());
+                for (int cls = 0; cls < 4; cls++)
+                  for (int q = 0; q < Q; q++)
+                    for (int c = 0; c < cond_dim; c++)
+                      mat[(cls * Q + q) * cond_dim + c] = t[(size_t)c * D4 + 4 * q + cls];
+              }
+            }
             float* bias = d + L.film[k] + 2 * cond_dim * D4;
             for (int i = 0; i < D; i++)
               bias[i] = *(w++);
@@ -1735,6 +1752,7 @@ struct WrBuilder
         WrOp& op = push(WR_LAYER);
         op.shape = shape;
         op.w = off;
+        op.pad[1] = film_matrix_floats; // (planner only: wr_program_cuts)
         op.slot = (int)ring_of_slot.size();
         op.run = run_shape + 1;
         op.hist = ring_area(C, K, dil); // + the ring area's base, added once the weights and tables are complete
@@ -2028,6 +2046,10 @@ static void wr_program_cuts(const std::vector<WrOp>& ops, int weights_end, int s
     {
       const auto nx = std::upper_bound(ws.begin(), ws.end(), op.w);
       cost[i] += nx != ws.end() ? *nx - op.w : 0;
+      // a FiLM matrix in the matrix form (kernel_wn_reg.hip: WrFilm) costs one matrix instruction per four weights and one LDS
+      // read per sixteen, against one packed FMA per two and one read per four: 0.45 of its weights
+      if (op.type == WR_LAYER)
+        cost[i] -= (long)op.pad[1] * 55 / 100;
     }
     total += cost[i];
   }

@@ -571,6 +571,12 @@ constexpr int wr_pad4(int n)
 {
   return (n + 3) & ~3;
 }
+// a FiLM's two matrices in the MATRIX form (kernel_wn_reg.hip: WrFilm — [lane % 4][pad4(D) / 4][cond] for v_mfma_f32_4x4x1) instead
+// of the vector form [cond][pad4(D)]: conditions of 4 or 8 values (what a condition_dsp hands to every FiLM of its model)
+constexpr bool wr_film_matrix_form(int cond)
+{
+  return cond == 4 || cond == 8;
+}
 constexpr WrLayerLayout wr_layer_layout(int cond, int C, int B, bool gating, int K, int HO)
 {
   // every matrix is stored TRANSPOSED, [in][pad4(out)]: one b128 read = the weights of four outputs for one input,

@@ -193,9 +193,19 @@ std::string wr_jit_build(const WrShapeSet& shapes, std::string& why)
     std::ofstream f(hdr);
     f << "// generated by libnam_hip.so (wr_jit.cpp): the layer shapes of one model\n" << text;
   }
-  const int rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                               "-include", hdr, "-I" + src, "-c", "-o", tmp, src + "/kernel_wn_reg.hip"},
-                              log);
+  int rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                         "-include", hdr, "-I" + src, "-c", "-o", tmp, src + "/kernel_wn_reg.hip"},
+                        log);
+  if (rc != 0 || !readable(tmp))
+  {
+    // once more with the compiler's own choice of where matrix-instruction results live: forcing them into vector registers
+    // (-amdgpu-mfma-vgpr-form: fewer moves) crashes ROCm 7.2's "Rewrite AGPR-Copy-MFMA" pass on some register-hungry layer
+    // shapes (a gated 16-row layer with every FiLM on a 4-value condition: tools/fuzz_models.py 160 7707, model 123)
+    std::remove(tmp.c_str());
+    rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-include", hdr, "-I" + src, "-c", "-o", tmp,
+                       src + "/kernel_wn_reg.hip"},
+                      log);
+  }
   if (!std::getenv("NAM_HIP_JIT_KEEP")) // (developer switch: the generated shapes header stays next to the code object)
     std::remove(hdr.c_str());
   if (rc != 0 || !readable(tmp))

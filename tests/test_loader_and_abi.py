@@ -319,3 +319,24 @@ def test_ticket_entry_points_refuse_bad_arguments(nam_lib):
     assert L.nam_hip_batch_wait_f64(None, 0, xd) == nam_lib.ERR_INVALID_ARGUMENT
     assert b"nam_hip_batch_wait_f64" in L.nam_hip_last_error()
     assert nam_lib.Batch.PIPE_SLOTS == int(re.search(r"#define NAM_HIP_PIPE_SLOTS (\d+)", open(os.path.join(ROOT, "include", "nam_hip.h")).read()).group(1))
+
+
+def test_per_model_compile_survives_a_compiler_crash(nam_lib, tmp_path, monkeypatch):
+    """ROCm 7.2's "Rewrite AGPR-Copy-MFMA" pass crashes on some register-hungry layer shapes when matrix-instruction results are
+    forced into vector registers (found by tools/fuzz_models.py 160 7707, model 123: a gated 16-row layer with every FiLM on a
+    4-value condition — the FiLMs run on v_mfma_f32_4x4x1 since round 6). csrc/wr_jit.cpp compiles once more without the flag:
+    the model still gets its compiled shapes instead of the slow fallback, and nothing of the failed attempt stays behind."""
+    import sys
+    sys_path_golden = os.path.join(ROOT, "tests", "golden")
+    if sys_path_golden not in sys.path:
+        sys.path.insert(0, sys_path_golden)
+    import make_synthetic_models as msm
+    nam = nam_lib
+    p = str(tmp_path / "featured_crash.nam")
+    msm.write_featured(p, 752428520, wr_shapes=False, post_head=True)
+    cache = tmp_path / "cache"
+    cache.mkdir(mode=0o700)
+    monkeypatch.setenv("NAM_HIP_JIT_CACHE", str(cache))
+    m = nam.get_dsp(p, fast_tanh=False)
+    assert m.info.has_a1_kernel & 16 and not (m.info.has_a1_kernel & 32) and m.jit_failed() == "", m.describe()
+    assert [f.name.endswith(".hsaco") for f in cache.iterdir()] == [True]
