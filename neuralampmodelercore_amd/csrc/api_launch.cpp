@@ -296,7 +296,7 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
     for (int q = 0; q < 3; q++)
       G.split_op[q] = w.split_op[q];
     G.prog = w.program;
-    can_split = can_split && w.split_op[1] >= 1 && w.split_op[1] < (int)w.ops.size();
+    can_split = can_split && w.split_op[3] >= 1 && w.split_op[3] < (int)w.ops.size();
     can_split4 = can_split4 && w.split_op[0] >= 1 && w.split_op[0] < w.split_op[1] && w.split_op[1] < w.split_op[2]
                  && w.split_op[2] < (int)w.ops.size();
     total += counts[k];
@@ -382,6 +382,9 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
   a.out_ch = groups[0]->plan->out_channels;
   a.ps = persist_args(b);
   // every group on the model's own code object (they share one: build_model), or every group on the ahead-of-time kernel
+  if (stages == 2) // (the kernels read a two-wave launch's cut from [1]: WrGroup::split_op)
+    for (int k = 0; k < n_groups; k++)
+      a.g[k].split_op[1] = groups[k]->plan->wr.split_op[3];
   const std::string& module = groups[0]->plan->wr.jit_module;
   for (int k = 1; k < n_groups; k++)
     if (groups[k]->plan->wr.jit_module != module)

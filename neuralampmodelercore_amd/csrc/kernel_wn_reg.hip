@@ -830,7 +830,7 @@ __device__ __forceinline__ void wr_post_head(WrRegs& r, const WrOpS& op, char* l
 // (CUT = 1: what two / four wavefronts per stream share — kWrProgSplit are the cuts of that form)
 constexpr WrOpS kWrProgOps[2][NAM_WR_N_PROGRAMS][NAM_WR_MAX_OPS] = {NAM_WR_PROGRAM_OPS, NAM_WR_PROGRAM_OPS_CUT};
 constexpr int kWrProgCount[2][NAM_WR_N_PROGRAMS] = {NAM_WR_PROGRAM_COUNTS, NAM_WR_PROGRAM_COUNTS_CUT};
-constexpr int kWrProgSplit[NAM_WR_N_PROGRAMS][3] = NAM_WR_PROGRAM_SPLITS;
+constexpr int kWrProgSplit[NAM_WR_N_PROGRAMS][4] = NAM_WR_PROGRAM_SPLITS; // [0 .. 2]: four waves per stream, [3]: two (plan.cpp: wr_program_cuts)
 constexpr int kWrRunRecs[][4] = NAM_WR_RUN_RECS; // WR_RUN: {-, ring area float offset, R, dilation | slot << 24} per layer; op.slot = first row
 
 template <int I0, int I1, class F>
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void wn_reg_body(const WrArgs& a)
         part(integral_constant<int, 0>{}, integral_constant<int, NOPS>{});
       else if constexpr (NST == 2)
       {
-        constexpr int c = kWrProgSplit[P][1] < 1 ? 1 : kWrProgSplit[P][1] > NOPS - 1 ? NOPS - 1 : kWrProgSplit[P][1];
+        constexpr int c = kWrProgSplit[P][3] < 1 ? 1 : kWrProgSplit[P][3] > NOPS - 1 ? NOPS - 1 : kWrProgSplit[P][3];
         if (S == 0)
           part(integral_constant<int, 0>{}, integral_constant<int, c>{});
         else

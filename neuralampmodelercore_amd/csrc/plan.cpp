@@ -1752,7 +1752,8 @@ struct WrBuilder
         WrOp& op = push(WR_LAYER);
         op.shape = shape;
         op.w = off;
-        op.pad[1] = film_matrix_floats; // (planner only: wr_program_cuts)
+        op.pad[0] = zc + (G ? B : 0); // (planner only, like pad[1]: wr_program_cuts — activation evaluations per frame)
+        op.pad[1] = film_matrix_floats;
         op.slot = (int)ring_of_slot.size();
         op.run = run_shape + 1;
         op.hist = ring_area(C, K, dil); // + the ring area's base, added once the weights and tables are complete
@@ -1983,7 +1984,8 @@ std::string WrShapeSet::header_text() const
     ss << "#define NAM_WR_PROGRAMS 1\n#define NAM_WR_N_PROGRAMS " << programs.size() << "\n#define NAM_WR_MAX_OPS " << max_ops << "\n";
     ss << "#define NAM_WR_PROGRAM_SPLITS {";
     for (size_t i = 0; i < programs.size(); i++)
-      ss << (i ? ", " : "") << "{" << programs[i].split_op[0] << ", " << programs[i].split_op[1] << ", " << programs[i].split_op[2] << "}";
+      ss << (i ? ", " : "") << "{" << programs[i].split_op[0] << ", " << programs[i].split_op[1] << ", " << programs[i].split_op[2] << ", "
+         << programs[i].split_op[3] << "}";
     ss << "}\n";
     for (int cut = 0; cut < 2; cut++)
     {
@@ -2053,21 +2055,32 @@ static void wr_program_cuts(const std::vector<WrOp>& ops, int weights_end, int s
     }
     total += cost[i];
   }
-  for (int q = 0; q < 3; q++)
-  {
+  auto cut_at = [&](const std::vector<long>& c, long tot, int num, int den) { // the cut closest to num / den of the work
     long acc = 0, best = -1;
-    split[q] = 0;
+    int at = 0;
     for (size_t m = 1; m < ops.size(); m++)
     {
-      acc += cost[m - 1];
-      const long d = std::labs(4 * acc - (q + 1) * total);
+      acc += c[m - 1];
+      const long d = std::labs(den * acc - num * tot);
       if (best < 0 || d < best)
       {
         best = d;
-        split[q] = (int)m;
+        at = (int)m;
       }
     }
-  }
+    return at;
+  };
+  for (int q = 0; q < 3; q++)
+    split[q] = cut_at(cost, total, q + 1, 4);
+  std::vector<long> cost2 = cost;
+  long total2 = total;
+  for (size_t i = 0; i < ops.size(); i++)
+    if (ops[i].type == WR_LAYER)
+    {
+      cost2[i] += 16l * ops[i].pad[0];
+      total2 += 16l * ops[i].pad[0];
+    }
+  split[3] = cut_at(cost2, total2, 1, 2);
 }
 
 // One attempt under one shape policy; throws WrBuilder::Unsupported
@@ -2286,6 +2299,8 @@ void build_wr(const WaveNetSpec& wn, Plan& plan, WrShapeSet* jit_shapes)
         }
       }
       wr_program_cuts(pr.ops_cut, wr.tab_rows, pr.split_op);
+      if (const char* e = std::getenv("NAM_HIP_WR_CUT2")) // (developer switch: the two-wave cut at this op, for A/B runs of the cost model)
+        pr.split_op[3] = std::min(std::max(std::atoi(e), 1), (int)pr.ops_cut.size() - 1);
       pr.first_rec = (int)trial.run_recs.size();
       trial.run_recs.insert(trial.run_recs.end(), wr.run_recs.begin(), wr.run_recs.end());
       wr.program = (int)trial.programs.size();

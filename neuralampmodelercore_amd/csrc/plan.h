@@ -454,7 +454,7 @@ struct WrPlan
   int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
   int program = -1; // per-model compile with the programs compiled in: this plan's program in the model's code object (WrShapeSet::programs)
   std::vector<std::array<int32_t, 4>> run_recs; // (planner) the records of this plan's WR_RUN layers, in op order; WrOp::pad[0] of a WR_RUN = its first
-  int split_op[3] = {0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its weights (kernel_wn_reg.hip, NST)
+  int split_op[4] = {0, 0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its work (four wavefronts per stream), [3]: the two-wave cut (plan.cpp: wr_program_cuts; kernel_wn_reg.hip, NST)
   // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
   // object compiled for it ("" until api_launch.cpp: build_model has prepared it — the plan is not runnable before)
   bool jit = false;
@@ -548,7 +548,7 @@ struct WrShapeSet
   {
     std::vector<WrOp> ops; // as the blob holds them (LDS offsets final): what ONE wavefront per stream runs
     std::vector<WrOp> ops_cut; // ... and with every WR_RUN cut into up to four sub-runs: what two / four wavefronts per stream share
-    int split_op[3]; // the cuts of ops_cut
+    int split_op[4]; // the cuts of ops_cut ([0 .. 2]: four waves, [3]: two)
     int first_rec; // WR_RUN ops: their layers' records start at run_recs[first_rec + (op.slot as stored here)]
   };
   std::vector<Program> programs;
