@@ -631,26 +631,30 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
 // 3, C = bottleneck <= 4, so every matrix row is one b128). One dispatch for the whole run; layer l + 1's weights and
 // ring record are requested before layer l computes, so a layer costs one exposed LDS round trip (its taps) instead of
 // four. Compact weight block (plan.h: wr_plain_layout), the same summation order as wr_layer.
+// Round 6: the two matrices on v_mfma_f32_4x4x1_16b_f32, one lane per frame (the sixteen 4 x 4 blocks are four frames each): the
+// lane holds ITS output row (lane % 4) of the conv and of the 1x1 — pad4(3 C) / 4 + 1 b128 reads per layer instead of 4 C —, the
+// B operand is the lane's own tap / activation value: one matrix instruction per input instead of two packed FMAs. Same sums in
+// the same order (bias, tap 0's channels, tap 1's, the current frame's; an fp32 MFMA is the fmaf chain).
 template <int C>
 struct WrPlainW
 {
-  f4 conv[3 * C], conv_b, mix, l1[C], l1_b;
+  f4 conv[wr_pad4(3 * C) / 4], conv_b, mix, l1, l1_b;
   i4 rec; // {-, ring area float offset, R, dilation | slot << 24}
 };
 template <int C, bool LDREC = true>
 __device__ __forceinline__ void wr_plain_ld(WrPlainW<C>& w, const char* lds, unsigned wb, unsigned rec_b)
 {
-  constexpr WrPlainLayout L = wr_plain_layout(C); // the compact block of a plain layer: 4 C + 3 rows of four floats
+  constexpr WrPlainLayout L = wr_plain_layout(C); // the compact block of a plain layer (matrix form)
   if constexpr (LDREC) // (a program compiled in — NAM_WR_PROGRAMS — knows its records: constants)
     w.rec = *reinterpret_cast<const i4*>(lds + rec_b);
+  constexpr int IN4 = wr_pad4(3 * C);
+  const unsigned cls = threadIdx.x & 3u; // the lane's output row
 #pragma unroll
-  for (int i = 0; i < 3 * C; i++)
-    w.conv[i] = lds_ld4(lds, wb + (unsigned)(L.conv + 4 * i) * 4u);
+  for (int q = 0; q < IN4 / 4; q++)
+    w.conv[q] = lds_ld4(lds, wb + (unsigned)L.conv * 4u + cls * (unsigned)(IN4 * 4) + (unsigned)q * 16u);
   w.conv_b = lds_ld4(lds, wb + (unsigned)L.conv_b * 4u);
   w.mix = lds_ld4(lds, wb + (unsigned)L.mixin * 4u);
-#pragma unroll
-  for (int i = 0; i < C; i++)
-    w.l1[i] = lds_ld4(lds, wb + (unsigned)(L.l1 + 4 * i) * 4u);
+  w.l1 = lds_ld4(lds, wb + (unsigned)L.l1 * 4u + cls * 16u);
   w.l1_b = lds_ld4(lds, wb + (unsigned)L.l1_b * 4u);
 }
 // One plain layer with the weights in `w`; the next layer's weights / record (LDS byte addresses nxt_wb / nxt_rec) are
@@ -679,13 +683,13 @@ __device__ __forceinline__ void wr_plain_layer(WrRegs& r, const WrPlainW<C>& w, 
   f4 z = w.conv_b;
 #pragma unroll
   for (int i = 0; i < C; i++)
-    z = __builtin_elementwise_fma(w.conv[i], f4{t0[i], t0[i], t0[i], t0[i]}, z);
+    z = __builtin_amdgcn_mfma_f32_4x4x1f32(w.conv[i >> 2][i & 3], t0[i], z, 0, 0, 0);
 #pragma unroll
   for (int i = 0; i < C; i++)
-    z = __builtin_elementwise_fma(w.conv[C + i], f4{t1[i], t1[i], t1[i], t1[i]}, z);
+    z = __builtin_amdgcn_mfma_f32_4x4x1f32(w.conv[(C + i) >> 2][(C + i) & 3], t1[i], z, 0, 0, 0);
 #pragma unroll
   for (int i = 0; i < C; i++)
-    z = __builtin_elementwise_fma(w.conv[2 * C + i], f4{r.x[i], r.x[i], r.x[i], r.x[i]}, z);
+    z = __builtin_amdgcn_mfma_f32_4x4x1f32(w.conv[(2 * C + i) >> 2][(2 * C + i) & 3], r.x[i], z, 0, 0, 0);
   z += m;
   float a[C];
 #pragma unroll
@@ -697,7 +701,7 @@ __device__ __forceinline__ void wr_plain_layer(WrRegs& r, const WrPlainW<C>& w, 
   f4 y = w.l1_b;
 #pragma unroll
   for (int i = 0; i < C; i++)
-    y = __builtin_elementwise_fma(w.l1[i], f4{a[i], a[i], a[i], a[i]}, y);
+    y = __builtin_amdgcn_mfma_f32_4x4x1f32(w.l1[i], a[i], y, 0, 0, 0);
 #pragma unroll
   for (int c = 0; c < C; c++)
     r.x[c] += y[c];

@@ -1679,11 +1679,22 @@ struct WrBuilder
           const WrPlainLayout P = wr_plain_layout(C);
           off = reserve(P.total);
           float* d = &wr.blob[(size_t)off];
-          dense(d + P.conv, w, C, C, 3, A.groups_input);
+          // conv and layer1x1 in the matrix form: row `o` of the block = output o's weights over the inputs in order (zero rows
+          // for o >= C, zero columns behind the last input: never multiplied)
+          float t[12 * 4] = {0};
+          dense(t, w, C, C, 3, A.groups_input); // [tap * C + channel][4 outputs]
+          const int in4 = wr_pad4(3 * C);
+          for (int o = 0; o < 4; o++)
+            for (int j = 0; j < 3 * C; j++)
+              d[P.conv + o * in4 + j] = t[j * 4 + o];
           for (int i = 0; i < C; i++)
             d[P.conv_b + i] = *(w++);
           dense(d + P.mixin, w, 1, C, 1, A.groups_input_mixin);
-          dense(d + P.l1, w, C, C, 1, A.layer1x1_groups);
+          std::fill(t, t + 16, 0.0f);
+          dense(t, w, C, C, 1, A.layer1x1_groups);
+          for (int o = 0; o < 4; o++)
+            for (int j = 0; j < C; j++)
+              d[P.l1 + o * 4 + j] = t[j * 4 + o];
           for (int i = 0; i < C; i++)
             d[P.l1_b + i] = *(w++);
         }

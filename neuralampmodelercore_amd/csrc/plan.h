@@ -612,15 +612,17 @@ constexpr WrLayerLayout wr_layer_layout(int cond, int C, int B, bool gating, int
   return L;
 }
 
-// a PLAIN layer's weight block (WR_RUN): kernel size 3, C = bottleneck <= 4, condition size 1, nothing else — every
-// matrix transposed to rows of four floats: conv [3 C] (row = tap * C + input), conv bias, mixin, layer1x1 [C], its bias
+// a PLAIN layer's weight block (WR_RUN): kernel size 3, C = bottleneck <= 4, condition size 1, nothing else. The two matrices
+// in the MATRIX form (round 6; kernel_wn_reg.hip: wr_plain_layer runs them on v_mfma_f32_4x4x1, one lane per frame): conv
+// [lane % 4 = output row][pad4(3 C) inputs, input = tap * C + channel], layer1x1 [output row][4 inputs]; conv bias, mixin and
+// the 1x1's bias as rows of four floats (lane-uniform)
 struct WrPlainLayout
 {
   int conv, conv_b, mixin, l1, l1_b, total;
 };
 constexpr WrPlainLayout wr_plain_layout(int C)
 {
-  return WrPlainLayout{0, 12 * C, 12 * C + 4, 12 * C + 8, 16 * C + 8, 16 * C + 12};
+  return WrPlainLayout{0, 4 * wr_pad4(3 * C), 4 * wr_pad4(3 * C) + 4, 4 * wr_pad4(3 * C) + 8, 4 * wr_pad4(3 * C) + 24, 4 * wr_pad4(3 * C) + 28};
 }
 
 // ---- LSTM ------------------------------------------------------------------------------------
