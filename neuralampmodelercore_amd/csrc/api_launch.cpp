@@ -338,8 +338,12 @@ int launch_wr(nam_hip_batch* b, WidthGroup* const* groups, const int* const* map
     // ... or the DENSE forms of a per-model code object (two wavefronts per SIMD: twice the workgroups per CU; two waves that
     // share a SIMD each issue nearly as fast as a lone one — profiles/r05/valu_rate_microbench.txt: 8.6 cycles per instruction of
     // a wave at one AND at two per SIMD — minus what they lose to each other's LDS traffic: 0.9)
+    // ONLY when the best one-per-SIMD form leaves SIMDs without a wavefront (config 5: 768 streams on 1,024 SIMDs): where it
+    // fills the chip exactly (config 4: 512 streams x 2, 1,024 x 1, 256 x 4) a second wavefront per SIMD only adds hand-overs —
+    // measured 3.95 vs 3.87 us (512 streams, four waves per stream dense vs two plain) and 7.59 vs 6.94 (1,024 streams)
+    const bool plain_fills = ((long)total * stages) % (4l * cus) == 0;
     const std::string& module0 = groups[0]->plan->wr.jit_module;
-    if (!module0.empty() && can_split && b->wr_max_stages >= 2)
+    if (!module0.empty() && can_split && b->wr_max_stages >= 2 && !plain_fills)
     {
       int ok = 0;
       if (wr_jit_function(module0, b->device, 1, nullptr, false, &ok) == NAM_HIP_OK && ok != 0)

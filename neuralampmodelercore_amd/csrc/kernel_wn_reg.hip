@@ -233,6 +233,81 @@ __device__ __forceinline__ void wr_mv_acc(f2* acc, const float* in, const WrMat<
   }
 }
 
+// A matrix in the MATRIX form (round 6): [lane % 4][pad4(OUT) / 4][pad4(IN)] — the lane's own row W[4 q + lane % 4][c] of every
+// output quad q, the A operand of v_mfma_f32_4x4x1_16b_f32 with the lane's input value c as B (one lane per frame: the sixteen
+// 4 x 4 blocks of the instruction are four frames each): ONE matrix instruction per input and output quad instead of two packed
+// FMAs, one b128 read per four inputs instead of one per input, a quarter of the registers. Same sums in the same order as
+// wr_mv / wr_mv_acc (bias, then the inputs in order: an fp32 MFMA is the fmaf chain). A layer's conv (one such matrix per tap),
+// layer1x1 and head1x1 come this way (plan.h: wr_layer_layout; plan.cpp packs them).
+template <int OUT, int IN>
+struct WrMatM
+{
+  static constexpr int Q = wr_pad4(OUT) / 4, I4 = wr_pad4(IN) / 4;
+  f4 w[Q][I4];
+  f4 b[Q];
+};
+template <int OUT, int IN>
+__device__ __forceinline__ void wr_ld(WrMatM<OUT, IN>& m, const char* lds, unsigned wb, bool bias, unsigned bb)
+{
+  constexpr int Q = WrMatM<OUT, IN>::Q, I4 = WrMatM<OUT, IN>::I4;
+  const unsigned cls_b = (threadIdx.x & 3u) * (unsigned)(Q * I4 * 16);
+#pragma unroll
+  for (int q = 0; q < Q; q++)
+  {
+#pragma unroll
+    for (int c4 = 0; c4 < I4; c4++)
+      m.w[q][c4] = lds_ld4(lds, wb + cls_b + (unsigned)((q * I4 + c4) * 16));
+    m.b[q] = bias ? lds_ld4(lds, bb + (unsigned)q * 16u) : f4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+// acc (pairs) = b + W in
+template <int OUT, int IN>
+__device__ __forceinline__ void wr_mv(f2* acc, const float* in, const WrMatM<OUT, IN>& m)
+{
+  constexpr int Q = WrMatM<OUT, IN>::Q, P = wr_pairs(OUT);
+  f4 a[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++)
+    a[q] = m.b[q];
+#pragma unroll
+  for (int i = 0; i < IN; i++)
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+      a[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(m.w[q][i >> 2][i & 3], in[i], a[q], 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < Q; q++)
+  {
+    acc[2 * q] = f2{a[q][0], a[q][1]};
+    if (2 * q + 1 < P)
+      acc[2 * q + 1] = f2{a[q][2], a[q][3]};
+  }
+}
+// acc (pairs) += W in  (no bias: the caller seeded acc)
+template <int OUT, int IN>
+__device__ __forceinline__ void wr_mv_acc(f2* acc, const float* in, const WrMatM<OUT, IN>& m)
+{
+  constexpr int Q = WrMatM<OUT, IN>::Q, P = wr_pairs(OUT);
+  f4 a[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++)
+  {
+    const f2 lo = acc[2 * q], hi = 2 * q + 1 < P ? acc[2 * q + 1] : f2{0.f, 0.f};
+    a[q] = f4{lo[0], lo[1], hi[0], hi[1]};
+  }
+#pragma unroll
+  for (int i = 0; i < IN; i++)
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+      a[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(m.w[q][i >> 2][i & 3], in[i], a[q], 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < Q; q++)
+  {
+    acc[2 * q] = f2{a[q][0], a[q][1]};
+    if (2 * q + 1 < P)
+      acc[2 * q + 1] = f2{a[q][2], a[q][3]};
+  }
+}
+
 // film.h:76-204 — v[d] = v[d] * scale[d] (+ shift[d]);  scale = Ws cond + bs, shift = Wh cond + bh
 // block at `fb`: Ws, Wh, bs [pad4(D)], bh [pad4(D)]. The two matrices come in one of two forms (plan.cpp: WrBuilder packs what
 // wr_film_matrix_form says):
@@ -451,14 +526,17 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
   WrFilm<ZC, COND> f_mpost, f_cpost, f_apre;
   // the conv matrix [K * C][pad4(ZC)]: whole in registers while the taps arrive — or, for long kernels / wide layers
   // (more than 256 weights per lane), tap by tap, so that a per-model build never spills its way through a layer
-  constexpr bool kConvByTap = K * C * wr_pad4(ZC) > 256;
-  WrMat<ZC, kConvByTap ? C : K * C> m_conv;
+  // the conv: one matrix-form matrix per tap; all of them in registers while the taps arrive — or, for long kernels on wide
+  // layers (more than 256 floats of rows per lane), tap by tap, so that a per-model build never spills its way through a layer
+  constexpr bool kConvByTap = K * wr_pad4(ZC) * wr_pad4(C) / 4 > 256;
+  constexpr unsigned kTapB = (unsigned)(wr_pad4(ZC) * wr_pad4(C) * 4); // bytes of one tap's matrix
+  WrMatM<ZC, C> m_conv[kConvByTap ? 1 : K];
   WrFilm<B, COND> f_apost;
   WrActP<G ? B : ZC> a_1;
   WrActP<B> a_2;
-  WrMat<C, B> m_l1;
+  WrMatM<C, B> m_l1;
   WrFilm<C, COND> f_l1;
-  WrMat<(HO > 0 ? HO : 1), B> m_h1;
+  WrMatM<(HO > 0 ? HO : 1), B> m_h1;
   WrFilm<HO, COND> f_h1;
 
   if (on(FILM_CONV_PRE))
@@ -520,7 +598,9 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
     for (int i = 0; i < COND; i++)
       mi[i] = r.cond[i];
   }
-  wr_ld(m_conv, lds, wb + L.conv * 4u, true, wb + L.conv_b * 4u); // (by tap: tap 0 and the bias)
+#pragma unroll
+  for (int k = 0; k < (kConvByTap ? 1 : K); k++) // (by tap: tap 0 and the bias)
+    wr_ld(m_conv[k], lds, wb + L.conv * 4u + (unsigned)k * kTapB, k == 0, wb + L.conv_b * 4u);
   wr_fence();
   f2 m[wr_pairs(ZC)];
   wr_mv(m, mi, m_mix);
@@ -535,15 +615,21 @@ __device__ __forceinline__ void wr_layer(WrRegs& r, const WrOpS& op, char* lds, 
 
   // Step 1b: the convolution (+ post FiLM); z = conv + mixin — model.cpp:189-221
   f2 z[wr_pairs(ZC)];
-  wr_mv(z, taps, m_conv);
-  if constexpr (kConvByTap)
+  wr_mv(z, taps, m_conv[0]);
+  if constexpr (!kConvByTap)
+  {
+#pragma unroll
+    for (int k = 1; k < K; k++)
+      wr_mv_acc(z, taps + k * C, m_conv[k]);
+  }
+  else
   {
 #pragma unroll
     for (int k = 1; k < K; k++)
     {
-      wr_ld(m_conv, lds, wb + (unsigned)(L.conv + k * C * wr_pad4(ZC)) * 4u, false, 0u);
+      wr_ld(m_conv[0], lds, wb + L.conv * 4u + (unsigned)k * kTapB, false, 0u);
       wr_fence();
-      wr_mv_acc(z, taps + k * C, m_conv);
+      wr_mv_acc(z, taps + k * C, m_conv[0]);
     }
   }
   wr_ld(a_1, lds, wb + L.act * 4u);

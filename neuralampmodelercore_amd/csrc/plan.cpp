@@ -1704,19 +1704,31 @@ struct WrBuilder
           off = reserve(L.total);
           float* d = &wr.blob[(size_t)off];
           // the flat stream order is conv, mixin, layer1x1, head1x1, then the 8 FiLMs (model.cpp:152-181)
-          dense(d + L.conv, w, C, zc, K, A.groups_input);
+          // [in][pad4(out)] (dense) -> the matrix form [output row % 4][quad][pad4(in)] (kernel_wn_reg.hip: WrMatM)
+          std::vector<float> tm;
+          auto matrix_form = [&](float* dst, int in_n, int out_n, int k_taps, int groups) {
+            const int o4 = wr_pad4(out_n), i4 = wr_pad4(in_n), Q = o4 / 4;
+            tm.assign((size_t)k_taps * in_n * o4, 0.0f);
+            dense(tm.data(), w, in_n, out_n, k_taps, groups); // [tap * in_n + input][o4]
+            for (int k = 0; k < k_taps; k++)
+              for (int cls = 0; cls < 4; cls++)
+                for (int q = 0; q < Q; q++)
+                  for (int c = 0; c < in_n; c++)
+                    dst[(size_t)k * o4 * i4 + (size_t)(cls * Q + q) * i4 + c] = tm[(size_t)(k * in_n + c) * o4 + 4 * q + cls];
+          };
+          matrix_form(d + L.conv, C, zc, K, A.groups_input);
           for (int i = 0; i < zc; i++)
             d[L.conv_b + i] = *(w++);
           dense(d + L.mixin, w, cond_dim, zc, 1, A.groups_input_mixin);
           if (A.layer1x1_active)
           {
-            dense(d + L.l1, w, B, C, 1, A.layer1x1_groups);
+            matrix_form(d + L.l1, B, C, 1, A.layer1x1_groups);
             for (int i = 0; i < C; i++)
               d[L.l1_b + i] = *(w++);
           }
           if (A.head1x1_active)
           {
-            dense(d + L.h1, w, B, h1o, 1, A.head1x1_groups);
+            matrix_form(d + L.h1, B, h1o, 1, A.head1x1_groups);
             for (int i = 0; i < h1o; i++)
               d[L.h1_b + i] = *(w++);
           }

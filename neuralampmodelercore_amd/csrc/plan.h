@@ -579,23 +579,25 @@ constexpr bool wr_film_matrix_form(int cond)
 }
 constexpr WrLayerLayout wr_layer_layout(int cond, int C, int B, bool gating, int K, int HO)
 {
-  // every matrix is stored TRANSPOSED, [in][pad4(out)]: one b128 read = the weights of four outputs for one input,
+  // the conv (one matrix per tap), layer1x1 and head1x1 in the MATRIX form (kernel_wn_reg.hip: WrMatM): [lane % 4 = output row of
+  // a quad][pad4(out) / 4 quads][pad4(in)] — the lane's own row, the A operand of v_mfma_f32_4x4x1 —; the mixin (and a FiLM on a
+  // condition that is not 4 or 8 values) TRANSPOSED, [in][pad4(out)]: one b128 read = the weights of four outputs for one input,
   // i.e. two packed FMAs (v_pk_fma_f32: two outputs per instruction) with the input broadcast to both halves
   WrLayerLayout L{};
   const int zc = gating ? 2 * B : B;
   int o = 0;
-  L.conv = o; // [K * C][pad4(zc)], row = tap * C + channel
-  o += K * C * wr_pad4(zc);
+  L.conv = o; // K x [4][pad4(zc) / 4][pad4(C)]
+  o += K * wr_pad4(zc) * wr_pad4(C);
   L.conv_b = o;
   o += wr_pad4(zc);
   L.mixin = o; // [cond][pad4(zc)]
   o += cond * wr_pad4(zc);
-  L.l1 = o; // [B][pad4(C)]
-  o += B * wr_pad4(C);
+  L.l1 = o; // [4][pad4(C) / 4][pad4(B)]
+  o += wr_pad4(C) * wr_pad4(B);
   L.l1_b = o;
   o += wr_pad4(C);
-  L.h1 = o; // [B][pad4(HO)]
-  o += B * wr_pad4(HO);
+  L.h1 = o; // [4][pad4(HO) / 4][pad4(B)]
+  o += wr_pad4(HO) * wr_pad4(B);
   L.h1_b = o;
   o += wr_pad4(HO);
   const int dims[8] = {C, zc, cond, zc, zc, B, C, HO};
