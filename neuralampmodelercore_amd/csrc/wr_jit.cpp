@@ -140,6 +140,15 @@ std::string wr_jit_build(const WrShapeSet& shapes, std::string& why)
   for (const char* f : kSources)
     h = fnv(read_file(src + "/" + f), h);
   h = fnv(hipcc, h);
+  // (developer switch: extra compiler arguments, e.g. -DNAM_WR_... knobs of kernel_wn_reg.hip, for A/B runs; part of the key)
+  std::vector<std::string> extra;
+  if (const char* e = std::getenv("NAM_HIP_JIT_FLAGS"))
+  {
+    std::istringstream is(e);
+    for (std::string t; is >> t;)
+      extra.push_back(t);
+    h = fnv(std::string(e), h);
+  }
   char key[32];
   std::snprintf(key, sizeof(key), "%016llx", h);
 
@@ -193,18 +202,20 @@ std::string wr_jit_build(const WrShapeSet& shapes, std::string& why)
     std::ofstream f(hdr);
     f << "// generated by libnam_hip.so (wr_jit.cpp): the layer shapes of one model\n" << text;
   }
-  int rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                         "-include", hdr, "-I" + src, "-c", "-o", tmp, src + "/kernel_wn_reg.hip"},
-                        log);
+  std::vector<std::string> cmd = {hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                                  "-include", hdr, "-I" + src, "-c", "-o", tmp, src + "/kernel_wn_reg.hip"};
+  cmd.insert(cmd.end(), extra.begin(), extra.end());
+  int rc = run_compiler(cmd, log);
   if (rc != 0 || !readable(tmp))
   {
     // once more with the compiler's own choice of where matrix-instruction results live: forcing them into vector registers
     // (-amdgpu-mfma-vgpr-form: fewer moves) crashes ROCm 7.2's "Rewrite AGPR-Copy-MFMA" pass on some register-hungry layer
     // shapes (a gated 16-row layer with every FiLM on a 4-value condition: tools/fuzz_models.py 160 7707, model 123)
     std::remove(tmp.c_str());
-    rc = run_compiler({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-include", hdr, "-I" + src, "-c", "-o", tmp,
-                       src + "/kernel_wn_reg.hip"},
-                      log);
+    cmd = {hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-include", hdr, "-I" + src, "-c", "-o", tmp,
+           src + "/kernel_wn_reg.hip"};
+    cmd.insert(cmd.end(), extra.begin(), extra.end());
+    rc = run_compiler(cmd, log);
   }
   if (!std::getenv("NAM_HIP_JIT_KEEP")) // (developer switch: the generated shapes header stays next to the code object)
     std::remove(hdr.c_str());
