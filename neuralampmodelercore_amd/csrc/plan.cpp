@@ -2049,8 +2049,13 @@ std::string WrShapeSet::header_text() const
 
 // Two- / four-stage launches (kernel_wn_reg.hip, NST) cut the program where the work balances; an op's weights are a fair
 // measure of its arithmetic (every weight is one multiply-add per frame): op i owns the blob from its offset to the next
-// larger one (`weights_end`: the first table behind the weights). split[q] = the cut closest to (q + 1) / 4 of the work.
-static void wr_program_cuts(const std::vector<WrOp>& ops, int weights_end, int split[3])
+// larger one (`weights_end`: the first table behind the weights). split[q], q = 0 .. 2 = the cut closest to (q + 1) / 4 of the work
+// (four wavefronts per stream); split[3] = the TWO-wave cut, which also counts an activation evaluation as sixteen weights (ten
+// vector instructions, two of them at a quarter of the rate: a gated 12-row layer of a condition_dsp is a third activations) —
+// calibrated on config 4, same-box: the second of two waves from op 5 / 6 / 7 / 8 on reads 4.49 / 4.23 / 4.58 / 5.84 us per step
+// (the term picks 6); with the same term the four-wave cuts become {2, 6, 11} and 256 streams read 3.68 us instead of 3.14 for
+// {2, 7, 12}: four short parts are dominated by their matrix work, two long ones are not.
+static void wr_program_cuts(const std::vector<WrOp>& ops, int weights_end, int split[4])
 {
   auto weighs = [](const WrOp& op) {
     return op.type == WR_LAYER || op.type == WR_RUN || op.type == WR_ARRAY_BEGIN || op.type == WR_ARRAY_END || op.type == WR_ARRAY_END_K
