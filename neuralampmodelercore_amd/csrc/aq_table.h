@@ -1,4 +1,4 @@
-// aq_table.h — the job / stage / LDS tables of nam_a1_q_kernel (kernel_a1_q.hip), shared with the planner (plan.cpp:
+// aq_table.h — the job / stage / LDS tables of nam_a1_q_kernel (kernel_a1_q.hip), shared with the planner (plan_a1.cpp:
 // build_a1_q packs the weight block these offsets describe and checks the model against this topology).
 //
 // Topology: the official A1 "standard" WaveNet — two layer arrays of ten layers, kernel size 3, dilations 1 .. 512,
@@ -84,7 +84,7 @@ constexpr int in_rows(int job) { return res(job) ? ring_len(job) : takes_area(jo
 constexpr int plane_b(int job) { return (in_rows(job) * 16 + 255) / 256 * 256; }
 constexpr int in_bytes(int job) { return plane_b(job) * (chans(job) / 4); }
 
-// ---- weight block in the blob (floats), copied to LDS as it lies (plan.cpp: build_a1_q) ----
+// ---- weight block in the blob (floats), copied to LDS as it lies (plan_a1.cpp: build_a1_q) ----
 // 4x4x1 tiles [lane class i = lane % 4][h][c] = W[out = 4 h + i][in = c]
 constexpr int kTileT = 4 * 2 * 16; // 16 -> 8: 128 floats
 constexpr int kTileM = 4 * 2 * 8; // 8 -> 8 (and the head's 8 -> 1: class 0, half 0 only): 64 floats

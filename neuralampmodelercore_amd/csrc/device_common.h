@@ -90,7 +90,7 @@ __device__ __forceinline__ float d_lut(const float* __restrict__ tbl, float x)
 }
 
 // run-time (wave-uniform) dispatch. An activation type a kernel does not know must never fall through to identity:
-// it traps (the host-side eligibility checks in plan.cpp are the only other guard).
+// it traps (the host-side eligibility checks in plan_a1.cpp are the only other guard).
 __device__ __forceinline__ float d_act_rt(int type, float x, float p0, float p1, float p2, float p3, float slope)
 {
   switch (type)
@@ -124,12 +124,12 @@ using mf_f4 = __attribute__((ext_vector_type(4))) float;
 // ------------------------------------------------------------------------------------------------
 // Every matrix product of the model is (C x Kdim) * (Kdim x 64 frames); compute wave w owns frames
 // [16w, 16w+16) and issues v_mfma_f32_16x16x4_f32 (exact fp32: bitwise an ordered fmaf chain).
-// Lane l = (g = l >> 4, j = l & 15) of wave w, FULL layout (plan.cpp describes the HALF layout of
+// Lane l = (g = l >> 4, j = l & 15) of wave w, FULL layout (plan_a1.cpp describes the HALF layout of
 // 8-channel arrays):
 //   D (4 VGPR)  out channels 4g + r, r = 0..3, of frame 16w + j          (residual x, head, z live here)
 //   B operand   k-step s feeds row k = g with channel 4g + s of frame 16w + j — THE LANE'S OWN D VALUES,
 //               so the current tap, the 1x1, the rechannel and the head need no data movement at all
-//   A operand   tile value W[out = j][in = 4g + s] (plan.cpp packs the tiles for exactly this mapping)
+//   A operand   tile value W[out = j][in = 4g + s] (plan_a1.cpp packs the tiles for exactly this mapping)
 // Only the time-shifted taps leave the registers: each lane fetches its channels of frame
 // (16w + j - L) with ONE LDS read from a frame-major window (lookback L <= 64: [previous 64 |
 // current 64] frames) or tap buffer (L > 64), both filled from the stream's frame-major history ring
@@ -188,7 +188,7 @@ __device__ __forceinline__ float act_hw(int type, float x, float p0)
     }
     case ACT_SOFTSIGN: return x * rcp(1.0f + fabsf(x));
     case ACT_IDENTITY: return x;
-    default: __builtin_trap(); return x; // unknown type: never a silent identity (plan.cpp gates what reaches here)
+    default: __builtin_trap(); return x; // unknown type: never a silent identity (the planner gates what reaches here)
   }
 }
 // whole-vector activation; ACT_T >= 0 resolves the type at compile time (the two kernels that matter:

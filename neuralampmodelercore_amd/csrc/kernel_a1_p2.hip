@@ -9,7 +9,7 @@ namespace namhip
 // nam_a1_p2_kernel<C0, C1> — the interleaved-frame mapping (plan.h, "Interleaved-frame MFMA kernel": frames t = 4 j + w per
 // compute wave, DPP / ring / exchange jobs, request slots) for ONE topology: two arrays of ten layers, kernel
 // size 3, dilations 1 ... 512 — every official WaveNet size (standard 16 / 8 channels, lite 12 / 6 -> 8, feather
-// 8 / 4). The job table is plan.h's constexpr p2::desc / p2::fetch evaluated at compile time (plan.cpp only selects
+// 8 / 4). The job table is plan.h's constexpr p2::desc / p2::fetch evaluated at compile time (plan_a1.cpp only selects
 // this kernel when those functions reproduce the model's run-time tables bit for bit), so a block is twenty
 // straight-line jobs: no descriptor loads, no kind / layout / flag tests, immediate LDS offsets and ring constants.
 // Why it exists: with one compute wave per SIMD the INSTRUCTION COUNT is the time. The descriptor-driven kernel

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(aq::kNst * 64) void nam_a1_q_kernel(const float* __
     // transition, which takes it at once
     constexpr int DIN = aq::depth_in(J0), DOUT = JN == aq::kJobT ? 4 : aq::depth_in(JN);
     static_assert(aq::is_big(JN) || JN == aq::kJobT, "aq: array 0's last stage hands over to the transition");
-    // ---- this stage's weights: registers for the whole launch. Tile q of job j (plan.cpp: build_a1_ws, FULL layout):
+    // ---- this stage's weights: registers for the whole launch. Tile q of job j (plan_a1.cpp: build_a1_ws, FULL layout):
     // lane (g, i) holds W[out = i][in = 4 g + s], s = 0 .. 3 — the A operand of k-step s ----
     aq_stagger<SS>();
     f4 W[NJS][4];
@@ -1127,7 +1127,7 @@ hipError_t launch_q_act(const A1Args& a, int n_blocks, hipStream_t stream)
 }
 } // namespace
 
-// a.tiles_off: blob offset (floats) of the kernel's own weight block (plan.cpp: build_a1_q; aq_table.h), a.consts_off: of the
+// a.tiles_off: blob offset (floats) of the kernel's own weight block (plan_a1.cpp: build_a1_q; aq_table.h), a.consts_off: of the
 // big layers' register tiles = the A1 kernels' tile area (A1Plan::ws_tiles_off, FULL layout)
 bool a1_q_takes(int act)
 {

@@ -187,7 +187,7 @@ __device__ __forceinline__ void a1_array(const A1Array* __restrict__ A, const fl
   }
 
   // head rechannel: a Conv1D over the head accumulator (model.cpp:399-400, 547-548). K = 1: a plain 1x1 into any
-  // number of output channels. K > 1 (A2: 16 taps): a single output channel (plan.cpp); the accumulator goes
+  // number of output channels. K > 1 (A2: 16 taps): a single output channel (plan_a1.cpp); the accumulator goes
   // through hbuf / its own ring exactly like a layer input.
   const int KH = A->head_k;
   const float* __restrict__ wh = w + A->head_off;

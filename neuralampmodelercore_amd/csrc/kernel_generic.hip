@@ -34,7 +34,7 @@ namespace namhip
 // its issue slot and every dependent memory round trip is exposed. The first interpreter (round 1) spent 16 k scalar
 // and 9 k vector instructions per 64-frame block of wavenet_a2_max for 2.3 k FMAs, with one LDS round trip per input
 // channel and one HBM round trip per history tap and channel. This one is built around three rules:
-//   * every tensor owns a multiple of FOUR rows and every weight matrix is zero-padded to match (plan.cpp), so rows
+//   * every tensor owns a multiple of FOUR rows and every weight matrix is zero-padded to match (plan_ops.cpp), so rows
 //     are read, combined and written four at a time with compile-time trip counts — no per-row tests or clamps;
 //   * an op's operands are all requested before the first one is used: a conv block costs one LDS round trip per
 //     8 input channels (CI4 = 1 or 2 four-row chunks, CB = 4 .. 16 accumulators: template instances picked by a
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
   {
     const int nvalid = min(kBlock, a.n_frames - f0);
     // the descriptor of the op after this one is requested before this op runs (the program ends with OP_END and
-    // plan.cpp pads it with one more so that pc + 1 is always readable)
+    // plan_ops.cpp pads it with one more so that pc + 1 is always readable)
     NamOp next_op = ops[0];
     for (int pc = 0;; pc++)
     {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void nam_generic_kernel(const NamOp* __restrict
           // a run of op.cout staging ops (this one first): request every ring's last `lookback` frames, then write
           // them to LDS — one memory round trip for all of them. Frame-major in both places: element e of the
           // history is float ((wp - lookback) * cin + e) mod (R * cin) of the ring.
-          constexpr int kMax = 16; // plan.cpp: Builder::kMaxStages
+          constexpr int kMax = 16; // plan_ops.cpp: Builder::kMaxStages
           const int n = op.cout;
           float v[kMax];
 #pragma unroll

@@ -14,7 +14,7 @@ namespace namhip
 // buffer at 256 streams). At 8 channels rows 8 .. 15 of every 16 x 16 x 4 tile are zero, and an fp32 MFMA and a vector
 // instruction never execute at the same time on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0): both halves of that cost add up.
 // (Round 3's first answer, a pipeline of three four-wave sets on the same tiles — nam_kp_kernel, 13.1 us per buffer — was
-// retired in round 5: this kernel took over its activations.) This kernel is compiled for the topology (kp_table.h; plan.cpp:
+// retired in round 5: this kernel took over its activations.) This kernel is compiled for the topology (kp_table.h; plan_a1.cpp:
 // build_a1_kp checks a model against it), keeps the K-tap kernel's state (rings, write positions: the two alternate freely on
 // one stream) and the session protocol of the A1 pipelines, and changes the shape of the work:
 //   * lane t of a wave = frame t of the buffer; the lane holds the layer's 8 input channels (x), the head accumulator and
@@ -831,7 +831,7 @@ hipError_t launch_kq_act(const A1Args& a, int n_blocks, hipStream_t stream)
 }
 } // namespace
 
-// a.tiles_off: blob offset (floats) of the kernel's weight block (plan.cpp: build_a1_kp — tiles | constants | rechannel column).
+// a.tiles_off: blob offset (floats) of the kernel's weight block (plan_a1.cpp: build_a1_kp — tiles | constants | rechannel column).
 // Instantiated: the A2 activation (LeakyReLU with a slope <= 1, as max(v, slope v) — ReLU is its slope 0), Tanh and Fasttanh
 // (NAM/activations.h:59-98). The run-time-dispatch form does not fit 168 registers: any other activation on this topology runs
 // nam_kt_mfma_kernel, one launch per buffer (the reference's own fused path takes LeakyReLU(0.01) only: a2_fast.cpp:617).

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void nam_kt_mfma_kernel(const A1Plan* __restri
       s.tt[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, Dq.tile_off * 4 + i * 1024, 0));
     s.cn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, frame4, uni((blk + ahead + 1) * (kBlock * 4)), 0));
   };
-  auto wrap = [&](int c) { return c >= NCH ? c - NCH : c; }; // NCH > D (plan.cpp)
+  auto wrap = [&](int c) { return c >= NCH ? c - NCH : c; }; // NCH > D (plan_a1.cpp)
 
   int nvalid = min(kBlock, a.n_frames);
   unsigned par = 0;
@@ -264,7 +264,7 @@ hipError_t launch_kt_mfma(const A1Args& a, int n_blocks, int nk, int channels, i
   const bool wt = a.n_frames <= 2 * kBlock; // short launches write ring appends through (see ring_store)
   const int lds_bytes = (2 * (kBlock + 1) * (channels + 4) + lds_aux_floats) * (int)sizeof(float);
   if (lds_bytes > 64 * 1024)
-    return hipErrorInvalidValue; // (plan.cpp keeps the LDS copy small; 16-channel models with 32 layers stay below)
+    return hipErrorInvalidValue; // (plan_a1.cpp keeps the LDS copy small; 16-channel models with 32 layers stay below)
 #define NAM_KT(NK, WT, ACT) \
   hipLaunchKernelGGL((nam_kt_mfma_kernel<NK, WT, ACT>), dim3(n_blocks), dim3(256), lds_bytes, stream, a.plan, a.blob, a)
 #define NAM_KT_ACT(NK, WT) \

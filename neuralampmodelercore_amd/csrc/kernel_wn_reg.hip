@@ -238,7 +238,7 @@ __device__ __forceinline__ void wr_mv_acc(f2* acc, const float* in, const WrMat<
 // 4 x 4 blocks of the instruction are four frames each): ONE matrix instruction per input and output quad instead of two packed
 // FMAs, one b128 read per four inputs instead of one per input, a quarter of the registers. Same sums in the same order as
 // wr_mv / wr_mv_acc (bias, then the inputs in order: an fp32 MFMA is the fmaf chain). A layer's conv (one such matrix per tap),
-// layer1x1 and head1x1 come this way (plan.h: wr_layer_layout; plan.cpp packs them).
+// layer1x1 and head1x1 come this way (plan.h: wr_layer_layout; plan_wr.cpp packs them).
 template <int OUT, int IN>
 struct WrMatM
 {
@@ -309,7 +309,7 @@ __device__ __forceinline__ void wr_mv_acc(f2* acc, const float* in, const WrMatM
 }
 
 // film.h:76-204 — v[d] = v[d] * scale[d] (+ shift[d]);  scale = Ws cond + bs, shift = Wh cond + bh
-// block at `fb`: Ws, Wh, bs [pad4(D)], bh [pad4(D)]. The two matrices come in one of two forms (plan.cpp: WrBuilder packs what
+// block at `fb`: Ws, Wh, bs [pad4(D)], bh [pad4(D)]. The two matrices come in one of two forms (plan_wr.cpp: WrBuilder packs what
 // wr_film_matrix_form says):
 //   * vector form [COND][pad4(D)]: one broadcast b128 = four outputs' weights for one input = two v_pk_fma_f32;
 //   * MATRIX form (a condition of 4 or 8 values — every FiLM of a model behind a condition_dsp): [lane % 4][pad4(D) / 4][COND] —
@@ -909,7 +909,7 @@ __device__ __forceinline__ void wr_post_head(WrRegs& r, const WrOpS& op, char* l
   wr_unpack<HS>(r.hout, o);
 }
 
-// ---- A model's op PROGRAMS compiled in (round 6; NAM_WR_PROGRAMS, generated by plan.cpp: WrShapeSet::header_text) ----
+// ---- A model's op PROGRAMS compiled in (round 6; NAM_WR_PROGRAMS, generated by plan_wr.cpp: WrShapeSet::header_text) ----
 // The per-model build used to compile the model's layer SHAPES and still walk its program as data: every op cost a fetch
 // (four LDS reads, thirteen v_readfirstlane), a two-level switch, and its offsets / ring length / dilation / slot / flags as
 // scalar registers feeding address arithmetic — about a fifth of the instructions a lone wavefront issues per buffer (and a
@@ -920,7 +920,7 @@ __device__ __forceinline__ void wr_post_head(WrRegs& r, const WrOpS& op, char* l
 // (CUT = 1: what two / four wavefronts per stream share — kWrProgSplit are the cuts of that form)
 constexpr WrOpS kWrProgOps[2][NAM_WR_N_PROGRAMS][NAM_WR_MAX_OPS] = {NAM_WR_PROGRAM_OPS, NAM_WR_PROGRAM_OPS_CUT};
 constexpr int kWrProgCount[2][NAM_WR_N_PROGRAMS] = {NAM_WR_PROGRAM_COUNTS, NAM_WR_PROGRAM_COUNTS_CUT};
-constexpr int kWrProgSplit[NAM_WR_N_PROGRAMS][4] = NAM_WR_PROGRAM_SPLITS; // [0 .. 2]: four waves per stream, [3]: two (plan.cpp: wr_program_cuts)
+constexpr int kWrProgSplit[NAM_WR_N_PROGRAMS][4] = NAM_WR_PROGRAM_SPLITS; // [0 .. 2]: four waves per stream, [3]: two (plan_wr.cpp: wr_program_cuts)
 constexpr int kWrRunRecs[][4] = NAM_WR_RUN_RECS; // WR_RUN: {-, ring area float offset, R, dilation | slot << 24} per layer; op.slot = first row
 
 template <int I0, int I1, class F>

@@ -1,5 +1,5 @@
 // kp_table.h — the topology nam_kq_kernel (kernel_kq.hip) is compiled for, shared with the planner, which checks a model
-// against it layer by layer before the kernel may run it (plan.cpp: build_a1_kp).
+// against it layer by layer before the kernel may run it (plan_a1.cpp: build_a1_kp).
 //
 // Default: the A2 architecture — one layer array of 8 channels, 23 layers with kernel sizes 6 / 15 and the dilation
 // pattern below, a head rechannel with 16 taps; the shape the reference's own fused path is written for
@@ -19,7 +19,7 @@ constexpr int kDs[kLayers + 1] = {1, 3, 7, 17, 41, 101, 239, 1, 3, 7, 17, 41, 10
 #endif
 constexpr int kC = 8; // channels (the half layout of the MFMA kernels: two k-steps per matrix)
 constexpr int kJobs = kLayers + 1;
-constexpr int kTapsPerChunk = 6; // == kKtTaps: the tap tiles are nam_kt_mfma_kernel's (plan.cpp: build_a1_kt)
+constexpr int kTapsPerChunk = 6; // == kKtTaps: the tap tiles are nam_kt_mfma_kernel's (plan_a1.cpp: build_a1_kt)
 constexpr int kTable = 64; // write-position words in front of a stream's rings
 
 constexpr int chunks_of(int K) { return (K + kTapsPerChunk - 1) / kTapsPerChunk; }

@@ -217,7 +217,7 @@ constexpr int kIlWinB = 2 * kBlock * kIlWinRowB; // one window: [previous 64 | c
 // ---- The official A1 topology at compile time (nam_a1_p2_kernel) ----------------------------------------------
 // Every official WaveNet size (standard 16/8, lite 12/6, feather 8/4 channels) is two arrays of ten layers, kernel
 // size 3, dilations 1, 2, 4, ... 512. For that topology the whole job table of the interleaved-frame kernel is a
-// function of the two (padded) channel counts: these constexpr functions restate plan.cpp's build_a1_il for it, the
+// function of the two (padded) channel counts: these constexpr functions restate plan_a1.cpp's build_a1_il for it, the
 // kernel instantiates them as compile-time constants (no descriptor loads, no kind / layout / flag branches, immediate
 // LDS offsets), and plan.cpp sets A1Plan::p2_ok only if they reproduce the model's il_desc / il_fetch tables exactly.
 namespace p2
@@ -313,7 +313,7 @@ struct KtDesc // 16 x int32
 {
   int32_t flags;
   int32_t ntaps; // taps in this chunk (1..kKtTaps)
-  int32_t tile_off; // blob float offset of the chunk's tap tiles (plan.cpp: build_a1_kt for the record layout)
+  int32_t tile_off; // blob float offset of the chunk's tap tiles (plan_a1.cpp: build_a1_kt for the record layout)
   int32_t w1_off; // byte offset, inside the kernel's LDS copy, of the layer's 1x1 tile [64 lanes][NK]
   int32_t consts_off; // byte offset, same region, of the layer's constants in the lane layout: bias | mixin | 1x1 bias, 16 floats each
   int32_t ring_b; // byte offset of the layer's ring in the stream state
@@ -335,7 +335,7 @@ struct A1Plan
   int32_t ring_len_by_id[64]; // R of ring r (for the per-block write-position update)
   A1Array arr[kA1MaxArrays];
   // MFMA kernel
-  int32_t ws_ok = 0; // nam_a1_mfma_kernel can run this model (plan.cpp: build_a1_ws)
+  int32_t ws_ok = 0; // nam_a1_mfma_kernel can run this model (plan_a1.cpp: build_a1_ws)
   int32_t ws_jobs = 0; // jobs per block (even)
   int32_t ws_tiles_off = 0, ws_consts_off = 0, ws_r1_off = 0; // blob offsets: tiles [jobs][1024], consts [jobs][64], 16 floats
   int32_t ws_xt_off = 0, ws_n_xt = 0; // blob offset / count of the extra tiles [n][256]
@@ -354,15 +354,15 @@ struct A1Plan
   int32_t p2_ok = 0; // nam_a1_p2_kernel<p2_c0, p2_c1> runs this model (the official topology, see namespace p2)
   int32_t p2_c0 = 0, p2_c1 = 0; // the two arrays' (padded) channel counts
   // K-tap MFMA kernel
-  int32_t kt_ok = 0; // nam_kt_mfma_kernel can run this model (plan.cpp: build_a1_kt)
+  int32_t kt_ok = 0; // nam_kt_mfma_kernel can run this model (plan_a1.cpp: build_a1_kt)
   int32_t kt_chunks = 0; // chunks per block
   int32_t kt_nk = 4; // k-steps per matrix: 2 = half layout (C = 8), 4 = full layout
   int32_t kt_rech_off = 0; // blob float offset: rechannel column in the lane layout (16 floats)
   int32_t kt_lds_src_off = 0, kt_lds_floats = 0; // blob region copied to LDS at kernel start: 1x1 tiles | constants
   KtDesc kt_desc[kKtChunkMax];
-  int32_t kp_ok = 0; // nam_kq_kernel can run this model: it IS the topology of kp_table.h (plan.cpp: build_a1_kp)
+  int32_t kp_ok = 0; // nam_kq_kernel can run this model: it IS the topology of kp_table.h (plan_a1.cpp: build_a1_kp)
   int32_t kq_w_off = 0; // blob float offset of nam_kq_kernel's weight block (tiles | constants | rechannel column; kernel_kq.hip)
-  int32_t q_ok = 0; // nam_a1_q_kernel runs this model: it IS the topology of aq_table.h (plan.cpp: build_a1_q)
+  int32_t q_ok = 0; // nam_a1_q_kernel runs this model: it IS the topology of aq_table.h (plan_a1.cpp: build_a1_q)
   int32_t q_w_off = 0; // blob float offset of its weight block (aq_table.h: kWrOff .. kBlockFloats)
 };
 
@@ -454,7 +454,7 @@ struct WrPlan
   int tab_ops = 0; // ... of the ops (16 ints each): the kernel reads its program from the LDS copy
   int program = -1; // per-model compile with the programs compiled in: this plan's program in the model's code object (WrShapeSet::programs)
   std::vector<std::array<int32_t, 4>> run_recs; // (planner) the records of this plan's WR_RUN layers, in op order; WrOp::pad[0] of a WR_RUN = its first
-  int split_op[4] = {0, 0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its work (four wavefronts per stream), [3]: the two-wave cut (plan.cpp: wr_program_cuts; kernel_wn_reg.hip, NST)
+  int split_op[4] = {0, 0, 0, 0}; // pipelined launches: cuts of the program at 1/4, 1/2, 3/4 of its work (four wavefronts per stream), [3]: the two-wave cut (plan_wr.cpp: wr_program_cuts; kernel_wn_reg.hip, NST)
   // per-model compile (wr_jit.cpp): the op shapes are ids into the model's own WrShapeSet; `jit_module` is the code
   // object compiled for it ("" until api_launch.cpp: build_model has prepared it — the plan is not runnable before)
   bool jit = false;
@@ -666,7 +666,7 @@ struct Plan
   int generic_blob_floats = 0; // leading part of `blob` the op program reads (weights, biases, activation parameters)
   int n_rings = 0;
   int state_floats = 0; // per-stream state size (floats), multiple of 64; first n_rings words = write positions
-  // true when the A1 kernels run a zero-padded copy of the model (plan.cpp: pad_channels_for_mfma): their rings are
+  // true when the A1 kernels run a zero-padded copy of the model (plan_a1.cpp: pad_channels_for_mfma): their rings are
   // [R][C_padded] while the op program's are [R][C] — two state layouts, so switching between the generic kernel and
   // the A1 kernels needs freshly reset state (api_launch.cpp: launch_group enforces it)
   bool a1_padded_layout = false;

@@ -26,7 +26,7 @@ SPECS = {
     "synth_a1_c8": dict(arrays=[(8, [1, 2, 4, 8, 16], "Tanh", False), (8, [32, 64, 128, 256, 512], "Tanh", True)], seed=13),
     # mixed activations -> run-time dispatch; three arrays (16 -> 8 -> 4); 15 layers -> 16 jobs
     # the official "lite" shape: 12 -> 6 channels, ten layers each; 6 is not a multiple of 4 — the plan compiler
-    # zero-pads it to 8 for the A1 kernels (plan.cpp: pad_channels_for_mfma)
+    # zero-pads it to 8 for the A1 kernels (plan_a1.cpp: pad_channels_for_mfma)
     "synth_a1_lite": dict(arrays=[(12, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
                                   (6, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=15),
     # the official "feather" shape: 8 -> 4 channels, ten layers each (half layout first, then a single channel quad):
@@ -34,7 +34,7 @@ SPECS = {
     "synth_a1_feather": dict(arrays=[(8, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", False),
                                      (4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "Tanh", True)], seed=17),
     # the feather shape with another activation: nam_a1_q_kernel is compiled for Tanh / Fasttanh, so this one keeps its own
-    # width (no padding to 16 / 8: plan.cpp: official_standard_topology) and its pipeline is nam_a1_p4_kernel<8, 4>
+    # width (no padding to 16 / 8: plan_a1.cpp: official_standard_topology) and its pipeline is nam_a1_p4_kernel<8, 4>
     "synth_a1_feather_relu": dict(arrays=[(8, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "ReLU", False),
                                           (4, [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], "ReLU", True)], seed=27),
     # the official "nano" shape: 4 -> 2 channels, ten layers each. Too narrow for the matrix-core kernels (2 channels):

@@ -54,15 +54,15 @@ def test_a1_standard_has_no_sample_rate_and_fast_kernels(nam_lib):
     ("synth_posthead", 16), ("wavenet", 17),
     ("lstm", 0)])
 def test_kernel_eligibility_reported_by_the_plan_compiler(nam_lib, name, bits):
-    """has_a1_kernel: bit 0 = the VALU A1 kernel, bit 1 = one of the MFMA kernels (plan.cpp: build_a1 / build_a1_ws /
+    """has_a1_kernel: bit 0 = the VALU A1 kernel, bit 1 = one of the MFMA kernels (plan_a1.cpp: build_a1 / build_a1_ws /
     build_a1_kt), bit 2 = the interleaved-frame MFMA kernel (build_a1_il), bit 3 = its compile-time-topology
-    form for the official sizes (plan.h: namespace p2), bit 4 = nam_wn_reg_kernel (plan.cpp: build_wr). Decided on the host at load time, so it is checkable without a GPU."""
+    form for the official sizes (plan.h: namespace p2), bit 4 = nam_wn_reg_kernel (plan_wr.cpp: build_wr). Decided on the host at load time, so it is checkable without a GPU."""
     assert nam_lib.get_dsp(model_path(name)).info.has_a1_kernel == bits
 
 
 def test_the_a2_pipeline_kernel_is_offered_to_the_a2_topology_only(nam_lib):
     """nam_kq_kernel is compiled for ONE topology (csrc/kp_table.h: the A2 stack of the reference's fused path,
-    wavenet/a2_fast.cpp): plan.cpp: build_a1_kp checks a model against the table layer by layer — kernel sizes, dilations,
+    wavenet/a2_fast.cpp): plan_a1.cpp: build_a1_kp checks a model against the table layer by layer — kernel sizes, dilations,
     ring geometry, chunk and tile offsets — and only A2.nam's 8-channel submodel passes; other K-tap models keep the
     descriptor-driven kernel (kt_mfma=1, kp=0); A2-Lite (3 channels) runs on nam_wn_reg_kernel."""
     d = nam_lib.get_dsp(model_path("A2")).describe()
